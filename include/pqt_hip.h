@@ -1,0 +1,190 @@
+/* =====================================================================================
+ * pqt_hip.h -- C-ABI of libpqt_hip.so: the MI355X (gfx950) Product-Quantization-Tree
+ * query engine.  This is the drop-in boundary for the reference's query hot path
+ * (per-query distance tables -> two-level traversal -> bin enumeration -> ADC line
+ * rerank -> top-k).  Plain pointers and sizes only; no C++/torch types cross it.
+ *
+ * Semantics follow the reference's cpu_version (treequantizer<T,D,C1,C2,P,W,LP>,
+ * cpu_version/quantizer/treequantizer.hpp); the class surface it sits under is the CUDA
+ * library's pqt::PerturbationProTree (pqt/PerturbationProTree.hh).  Each entry point
+ * cites the reference interface it replaces.  All citations are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *   - every function returns 0 (PQT_OK) or a negative pqt_status; pqt_last_error()
+ *     returns a thread-local message for the last failure.  Nothing throws across
+ *     the ABI and nothing calls exit() (the reference aborts: PerturbationProTree.cu:8229-8232).
+ *   - "host" / "dev" in a parameter name says where the pointer must live.
+ *   - a handle owns its device copies and a persistent scratch arena; the query
+ *     path performs no allocation once the arena has been sized by a first call
+ *     with the same (QN, Bv, Bb) or larger.
+ *   - a handle is thread-compatible: one query batch in flight per handle.
+ *   - there is NO CPU fallback: if no gfx950 device is usable the calls fail.
+ * ===================================================================================== */
+#ifndef PQT_HIP_H
+#define PQT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pqt_index pqt_index; /* opaque */
+
+typedef enum {
+  PQT_OK = 0,
+  PQT_ERR_INVALID = -1,   /* bad argument / parameter combination            */
+  PQT_ERR_DEVICE = -2,    /* HIP runtime error (no device, OOM, launch fail) */
+  PQT_ERR_STATE = -3,     /* index not fully populated for this call         */
+  PQT_ERR_LIMIT = -4,     /* request exceeds an implementation limit         */
+  PQT_ERR_IO = -5         /* file error (host-side helpers)                  */
+} pqt_status;
+
+/* Template parameters of treequantizer<T,D,C1,C2,P,W,LP> (treequantizer.hpp:15-26) /
+ * constructor + file values of PerturbationProTree(dim,p,p2) (PerturbationProTree.hh:37).
+ * Constraints: dim % p == 0, dim % lp == 0, lp % p == 0, 1 <= w <= c1 <= 256, c2 <= 256, p <= 8. */
+typedef struct {
+  uint32_t dim; /* D  */
+  uint32_t p;   /* P  : parts of the product quantizer                      */
+  uint32_t c1;  /* C1 : first-level centroids per part                      */
+  uint32_t c2;  /* C2 : second-level centroids per first-level cell         */
+  uint32_t w;   /* W  : first-level cells expanded per part (CUDA: k1)      */
+  uint32_t lp;  /* LP : line parts of the rerank code (CUDA: lineparts)     */
+} pqt_params;
+
+/* Per-batch statistics of the last pqt_query* call on a handle. */
+typedef struct {
+  uint64_t queries;          /* QN of the last call                                      */
+  uint64_t candidates;       /* sum over queries of reranked candidates (nCand)          */
+  uint64_t bins_visited;     /* sum over queries of heuristic rows enumerated            */
+  uint64_t bins_nonempty;    /* sum over queries of included non-empty bins              */
+  uint64_t ties_l1;          /* exact float ties seen while ordering L1 cells            */
+  uint64_t ties_l2;          /* ... while ordering the W*C2 second-level entries         */
+  uint64_t ties_bins;        /* ... between adjacent bins of the sorted bin order        */
+  uint64_t ties_final;       /* ... between adjacent candidates of the sorted result     */
+  float ms_tables;           /* device time of the distance-table kernel (stage a1+a2)   */
+  float ms_bins;             /* bin enumeration + probe + cut + candidate gather (a4-a6) */
+  float ms_rerank;           /* ADC line rerank (a7)                                     */
+  float ms_select;           /* final sort / top-k (a8)                                  */
+  float ms_total;            /* whole batch on the device                                */
+  uint32_t max_bin;          /* largest bin population in the index                      */
+  uint32_t reserved;
+} pqt_stats;
+
+const char* pqt_last_error(void);
+/* number of visible HIP devices with gcnArchName gfx950 (0 => nothing will work) */
+int pqt_device_count(void);
+
+/* ---- lifetime ---------------------------------------------------------------------
+ * replaces: treequantizer() ctor (treequantizer.hpp:38-50) / PerturbationProTree(dim,p,p2)
+ * (PerturbationProTree.hh:37) + cudaSetDevice(FLAGS_device) (tool_query.cpp:74). */
+int pqt_index_create(const pqt_params* prm, int device, pqt_index** out);
+void pqt_index_destroy(pqt_index* idx);
+int pqt_index_params(const pqt_index* idx, pqt_params* out);
+
+/* ---- tree ---------------------------------------------------------------------------
+ * replaces: loadTree payload (treequantizer.hpp:782-837) / readTreeFromFile payload
+ * (PerturbationProTree.cu:118-220): cb1[C1][D], cb2[P][C1][C2][D/P], f32 host pointers,
+ * copied.  Also runs the coarse-table kernel = computeLookupTable (treequantizer.hpp:183-203)
+ * / computeCBL1L1Dist (PerturbationProTree.cu:1902-1917). */
+int pqt_index_set_codebooks(pqt_index* idx, const float* cb1_host, const float* cb2_host);
+/* coarse[LP][C1][C1] (cpu layout (lp*C1 + A)*C1 + B) copied back to the host */
+int pqt_index_get_coarse(const pqt_index* idx, float* out_host);
+
+/* ---- traversal heuristic ----------------------------------------------------------------
+ * replaces: prepareHeuristic (treequantizer.hpp:75-127) / prepareDistSequence (ProTree.cu:128-207).
+ * build: enumerates all (W*C2)^P tuples and sorts them by squared norm on the host exactly as the
+ * reference does (same comparator, std::sort), keeping the first `rows` rows.
+ * set: takes a caller-supplied prefix tuples[rows][P] (e.g. dumped from a reference run). */
+int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows);
+int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples_host, uint64_t rows);
+int pqt_index_get_heuristic(const pqt_index* idx, uint32_t* out_host, uint64_t rows);
+
+/* ---- bin store ----------------------------------------------------------------------------
+ * replaces: loadBins bin section (treequantizer.hpp:845-872): nbins records {bin id, size, members}.
+ * bin_ids[nbins] (any order, unique), bin_sizes[nbins], members[sum sizes] (vector ids, bin by bin,
+ * insertion order).  Host pointers, copied. */
+int pqt_index_set_bins(pqt_index* idx, uint64_t nbins, const uint32_t* bin_ids_host,
+                       const uint32_t* bin_sizes_host, const uint32_t* members_host);
+/* Range shard for multi-GPU: same full description of the global bins, but only members with
+ * id in [id_lo, id_hi) are kept on this device; every bin keeps its GLOBAL population so that all
+ * shards apply the identical "finish the bin, then stop" cut (treequantizer.hpp:468-476). */
+int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* bin_ids_host,
+                             const uint32_t* bin_sizes_host, const uint32_t* members_host,
+                             uint32_t id_lo, uint32_t id_hi);
+/* replaces: PerturbationProTree::setDB(N, prefix, counts, dbIdx) (PerturbationProTree.hh:66,
+ * .cu:1184-1229): the CUDA library's dense hashed CSR, slot = bin id % hash_size.  Host pointers. */
+int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix_host,
+                            const uint32_t* counts_host, const uint32_t* dbidx_host, uint32_t hash_size);
+
+/* ---- line codes -------------------------------------------------------------------------------
+ * replaces: loadBins code section (treequantizer.hpp:874-889) / the `_hlines` argument of
+ * queryBIGKNNRerank2 (PerturbationProTree.hh:81) + prepareEmptyLambda/getLine (:101-103).
+ * codes[nvec][LP], 4 bytes each = code_t {u8 p1; u8 p2; u16 lambda} (cpu_version/helper.hpp:39-90).
+ * Row r holds the code of vector id (id_base + r).  _host copies; _dev adopts a device buffer
+ * (caller keeps ownership and must keep it alive). */
+int pqt_index_set_lines_host(pqt_index* idx, const uint32_t* codes_host, uint64_t nvec, uint64_t id_base);
+int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t nvec, uint64_t id_base);
+
+/* ---- offline build on the device ("next" row: insert / prepareReranking) ------------------------
+ * replaces: treequantizer::insert (treequantizer.hpp:212-217) = id() (:640-688) + prepareReranking
+ * (:356-412) for n vectors; CUDA counterparts buildKBestDB / lineDist (PerturbationProTree.cu:1231,7663).
+ * vecs_dev[n][D] f32 device pointer.  out_bin_dev[n] u32 bin ids, out_codes_dev[n][LP] line codes. */
+int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n,
+                            uint32_t* out_bin_dev, uint32_t* out_codes_dev, void* hip_stream);
+
+/* ---- query ----------------------------------------------------------------------------------------
+ * replaces: treequantizer::query(boundVectors, boundBins, vec, out) (treequantizer.hpp:323-350) for a
+ * batch, / PerturbationProTree::queryKNN(resIdx,resDist,Q,QN,nVec) (PerturbationProTree.hh:72).
+ *   q_dev[QN][D] f32 device pointer; out_idx_dev[QN][k] u32; out_dist_dev[QN][k] f32;
+ *   out_count_dev[QN] u32 (may be NULL) = candidate-list length nCand of each query.
+ * Row q holds the first min(k, nCand) entries of the reference's sorted candidate list; unused slots
+ * are 0xffffffff / +inf.  Equal distances are ordered by candidate visiting position (stable).
+ * hip_stream: a hipStream_t to enqueue on (NULL = the handle's own stream); the call returns after
+ * the work is enqueued unless `sync` != 0. */
+int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins,
+              uint32_t k, uint32_t* out_idx_dev, float* out_dist_dev, uint32_t* out_count_dev,
+              void* hip_stream, int sync);
+/* Host-pointer convenience wrapper (copies in/out, synchronous); the rate through this entry point
+ * includes PCIe and is never the benchmark value. */
+int pqt_query_host(pqt_index* idx, const float* q_host, uint32_t qn, uint32_t bound_vectors,
+                   uint32_t bound_bins, uint32_t k, uint32_t* out_idx_host, float* out_dist_host,
+                   uint32_t* out_count_host);
+/* Multi-GPU merge helper: out of `nshards` per-shard results laid out [shard][QN][k] (as gathered by
+ * an all-gather of pqt_query_shard outputs) produce the global first-k per query.  Device pointers. */
+int pqt_merge_topk(pqt_index* idx, uint32_t nshards, uint32_t qn, uint32_t k,
+                   const uint32_t* idx_dev, const float* dist_dev, const uint32_t* pos_dev,
+                   uint32_t* out_idx_dev, float* out_dist_dev, void* hip_stream, int sync);
+/* Shard-local query: like pqt_query but also returns each result's global visiting position
+ * (out_pos_dev[QN][k]) so that merges break ties exactly like the unsharded engine. */
+int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors,
+                    uint32_t bound_bins, uint32_t k, uint32_t* out_idx_dev, float* out_dist_dev,
+                    uint32_t* out_pos_dev, uint32_t* out_count_dev, void* hip_stream, int sync);
+
+/* ---- stage-level read-back (parity tests; not a fast path) ------------------------------------------
+ * After a pqt_query* call the handle still holds the intermediates of that batch:
+ *   l1virt[QN][LP][C1]                      = _L1distancesVirtual   (treequantizer.hpp:914)
+ *   seg_d2[QN][P][W*C2], seg_bin[...]       = segmentInfo output sorted by d2 (:597-630); seg_bin = l1*C2+l2
+ *   cand_idx[QN][stride], cand_dist[...]    = candidates in visiting order (rerankVectors before its sort)
+ * Each pointer may be NULL.  Host pointers.  stride is returned by pqt_debug_stride(). */
+uint64_t pqt_debug_stride(const pqt_index* idx);
+int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt_host, float* seg_d2_host,
+                   uint32_t* seg_bin_host, uint32_t* cand_idx_host, float* cand_dist_host,
+                   uint32_t* ncand_host);
+
+int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
+/* duration (ms) of each launch of the dominant kernel (rerank) in the last call, via HIP events on the
+ * stream it ran on; returns the number of launches written (<= cap). */
+int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
+
+/* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------
+ * computed ON THE DEVICE by a one-thread kernel, so they pin the kernels' arithmetic, not the host's. */
+int pqt_dev_triangle(const float* a_host, const float* b_host, const float* c_host, const float* l_host,
+                     uint32_t n, float* out_dist_host, float* out_ratio_host, uint16_t* out_lambda_u16_host,
+                     float* out_lambda_roundtrip_host, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQT_HIP_H */

@@ -1,0 +1,250 @@
+"""product-quantization-tree_amd -- MI355X (gfx950) Product-Quantization-Tree query engine.
+
+The product is the C-ABI shared library ``csrc/libpqt_hip.so`` (declared in ``include/pqt_hip.h``) plus the
+C++ host layer in ``host/`` (``pqt::ProQuantization`` / ``ProTree`` / ``PerturbationProTree`` shims and the
+``tool_query`` / ``tool_createdb`` front-ends).  This Python module is only the ctypes glue that tests, bench.py
+and __graft_entry__ use to drive the same C-ABI with torch-owned device buffers; it contains no compute and NO
+fallback: if the HIP library is missing or no gfx950 device is usable, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libpqt_hip.so")
+_LIB = None
+
+u32p = C.POINTER(C.c_uint32)
+f32p = C.POINTER(C.c_float)
+
+
+class PqtError(RuntimeError):
+    pass
+
+
+class pqt_params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("dim", "p", "c1", "c2", "w", "lp")]
+
+
+class pqt_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("queries", "candidates", "bins_visited", "bins_nonempty", "ties_l1",
+                                          "ties_l2", "ties_bins", "ties_final")] + \
+               [(n, C.c_float) for n in ("ms_tables", "ms_bins", "ms_rerank", "ms_select", "ms_total")] + \
+               [("max_bin", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+# every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)
+EXPORTS = [
+    "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
+    "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
+    "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
+    "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
+    "pqt_merge_topk", "pqt_query_shard", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
+    "pqt_get_rerank_launch_ms", "pqt_dev_triangle",
+]
+
+
+def build(force=False):
+    """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h")] + \
+           [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", CSRC, "libpqt_hip.so"])
+    return LIB_PATH
+
+
+def lib():
+    """Load libpqt_hip.so; raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PqtError("libpqt_hip.so is not built (%s); run __graft_entry__.build() / make -C %s" % (LIB_PATH, CSRC))
+    L = C.CDLL(LIB_PATH)
+    L.pqt_last_error.restype = C.c_char_p
+    L.pqt_device_count.restype = C.c_int
+    L.pqt_index_create.argtypes = [C.POINTER(pqt_params), C.c_int, C.POINTER(C.c_void_p)]
+    L.pqt_index_destroy.argtypes = [C.c_void_p]
+    L.pqt_index_destroy.restype = None
+    L.pqt_index_params.argtypes = [C.c_void_p, C.POINTER(pqt_params)]
+    L.pqt_index_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
+    L.pqt_index_get_coarse.argtypes = [C.c_void_p, f32p]
+    L.pqt_index_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
+    L.pqt_index_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
+    L.pqt_index_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
+    L.pqt_index_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p]
+    L.pqt_index_set_bins_shard.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint32, C.c_uint32]
+    L.pqt_index_set_db_hashed.argtypes = [C.c_void_p, C.c_uint32, u32p, u32p, u32p, C.c_uint32]
+    L.pqt_index_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64, C.c_uint64]
+    L.pqt_index_set_lines_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
+    L.pqt_build_assign_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pqt_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_query_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
+    L.pqt_merge_topk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_debug_stride.argtypes = [C.c_void_p]
+    L.pqt_debug_stride.restype = C.c_uint64
+    L.pqt_debug_read.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, u32p, u32p, f32p, u32p]
+    L.pqt_get_stats.argtypes = [C.c_void_p, C.POINTER(pqt_stats)]
+    L.pqt_get_rerank_launch_ms.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.pqt_dev_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_uint16), f32p, C.c_int]
+    _LIB = L
+    return L
+
+
+def _chk(rc):
+    if rc < 0:
+        raise PqtError("pqt error %d: %s" % (rc, lib().pqt_last_error().decode()))
+    return rc
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dt)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class PqtIndex:
+    """Handle on a device-resident PQT index (thin wrapper over the C-ABI; see include/pqt_hip.h)."""
+
+    def __init__(self, D, P, C1, C2, W, LP, device=0):
+        self.L = lib()
+        self.D, self.P, self.C1, self.C2, self.W, self.LP = D, P, C1, C2, W, LP
+        self.device = device
+        self.h = C.c_void_p()
+        prm = pqt_params(D, P, C1, C2, W, LP)
+        _chk(self.L.pqt_index_create(C.byref(prm), device, C.byref(self.h)))
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.pqt_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- population ---------------------------------------------------------------------------
+    def set_codebooks(self, cb1, cb2):
+        cb1 = _np(cb1, np.float32).reshape(self.C1, self.D)
+        cb2 = _np(cb2, np.float32).reshape(self.P, self.C1, self.C2, self.D // self.P)
+        _chk(self.L.pqt_index_set_codebooks(self.h, _p(cb1, f32p), _p(cb2, f32p)))
+
+    def coarse(self):
+        out = np.zeros((self.LP, self.C1, self.C1), np.float32)
+        _chk(self.L.pqt_index_get_coarse(self.h, _p(out, f32p)))
+        return out
+
+    def build_heuristic(self, rows):
+        _chk(self.L.pqt_index_build_heuristic(self.h, rows))
+
+    def set_heuristic(self, tuples):
+        t = _np(tuples, np.uint32).reshape(-1, self.P)
+        _chk(self.L.pqt_index_set_heuristic(self.h, _p(t, u32p), t.shape[0]))
+
+    def heuristic(self, rows):
+        out = np.zeros((rows, self.P), np.uint32)
+        _chk(self.L.pqt_index_get_heuristic(self.h, _p(out, u32p), rows))
+        return out
+
+    def set_bins(self, ids, sizes, members):
+        ids, sizes, members = _np(ids, np.uint32), _np(sizes, np.uint32), _np(members, np.uint32)
+        _chk(self.L.pqt_index_set_bins(self.h, ids.shape[0], _p(ids, u32p), _p(sizes, u32p), _p(members, u32p)))
+
+    def set_bins_shard(self, ids, sizes, members, id_lo, id_hi):
+        ids, sizes, members = _np(ids, np.uint32), _np(sizes, np.uint32), _np(members, np.uint32)
+        _chk(self.L.pqt_index_set_bins_shard(self.h, ids.shape[0], _p(ids, u32p), _p(sizes, u32p), _p(members, u32p),
+                                             id_lo, id_hi))
+
+    def set_db_hashed(self, prefix, counts, dbidx, hash_size):
+        prefix, counts, dbidx = _np(prefix, np.uint32), _np(counts, np.uint32), _np(dbidx, np.uint32)
+        _chk(self.L.pqt_index_set_db_hashed(self.h, dbidx.shape[0], _p(prefix, u32p), _p(counts, u32p), _p(dbidx, u32p),
+                                            hash_size))
+
+    def set_lines(self, codes, id_base=0):
+        codes = _np(codes, np.uint32).reshape(-1, self.LP)
+        _chk(self.L.pqt_index_set_lines_host(self.h, _p(codes, u32p), codes.shape[0], id_base))
+
+    def set_lines_dev(self, codes_tensor, id_base=0):
+        """Adopt a torch int32/uint32 CUDA tensor [n, LP] as the line store (kept alive by this object)."""
+        assert codes_tensor.is_cuda and codes_tensor.is_contiguous() and codes_tensor.element_size() == 4
+        self._keep.append(codes_tensor)
+        _chk(self.L.pqt_index_set_lines_dev(self.h, codes_tensor.data_ptr(), codes_tensor.shape[0], id_base))
+
+    # ---- device-pointer entry points (torch tensors own the memory) ---------------------------------------
+    def query_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_count=None, stream=None, sync=False):
+        _chk(self.L.pqt_query(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
+                              out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
+
+    def query_shard_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_pos, out_count=None, stream=None, sync=False):
+        _chk(self.L.pqt_query_shard(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
+                                    out_pos.data_ptr(), out_count.data_ptr() if out_count is not None else None,
+                                    stream, int(sync)))
+
+    def merge_topk_dev(self, nshards, qn, k, idx_all, dist_all, pos_all, out_idx, out_dist, stream=None, sync=False):
+        _chk(self.L.pqt_merge_topk(self.h, nshards, qn, k, idx_all.data_ptr(), dist_all.data_ptr(), pos_all.data_ptr(),
+                                   out_idx.data_ptr(), out_dist.data_ptr(), stream, int(sync)))
+
+    def assign_encode_dev(self, vecs, out_bin, out_codes, stream=None):
+        _chk(self.L.pqt_build_assign_encode(self.h, vecs.data_ptr(), vecs.shape[0], out_bin.data_ptr(),
+                                            out_codes.data_ptr(), stream))
+
+    # ---- host-pointer convenience -----------------------------------------------------------------------------
+    def query(self, Q, Bv, Bb, k):
+        Q = _np(Q, np.float32).reshape(-1, self.D)
+        qn = Q.shape[0]
+        idx = np.zeros((qn, k), np.uint32)
+        dist = np.zeros((qn, k), np.float32)
+        cnt = np.zeros(qn, np.uint32)
+        _chk(self.L.pqt_query_host(self.h, _p(Q, f32p), qn, Bv, Bb, k, _p(idx, u32p), _p(dist, f32p), _p(cnt, u32p)))
+        return idx, dist, cnt
+
+    def stats(self):
+        s = pqt_stats()
+        _chk(self.L.pqt_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def rerank_launch_ms(self, cap=64):
+        out = np.zeros(cap, np.float32)
+        n = _chk(self.L.pqt_get_rerank_launch_ms(self.h, _p(out, f32p), cap))
+        return out[:n].copy()
+
+    def debug_read(self, qn, cands=True):
+        stride = self.L.pqt_debug_stride(self.h)
+        WC = self.W * self.C2
+        l1 = np.zeros((qn, self.LP, self.C1), np.float32)
+        sd = np.zeros((qn, self.P, WC), np.float32)
+        sb = np.zeros((qn, self.P, WC), np.uint32)
+        nc = np.zeros(qn, np.uint32)
+        ci = np.zeros((qn, stride), np.uint32) if cands else None
+        cd = np.zeros((qn, stride), np.float32) if cands else None
+        _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p), _p(sb, u32p),
+                                   _p(ci, u32p) if cands else None, _p(cd, f32p) if cands else None, _p(nc, u32p)))
+        return dict(l1virt=l1, seg_d2=sd, seg_bin=sb, ncand=nc, cand_idx=ci, cand_dist=cd, stride=stride)
+
+
+def dev_triangle(a, b, c, l, device=0):
+    """extractDistance / calcRatio / lambda codec evaluated by a kernel on the device."""
+    a, b, c, l = (_np(x, np.float32).ravel() for x in (a, b, c, l))
+    n = a.shape[0]
+    d = np.zeros(n, np.float32)
+    r = np.zeros(n, np.float32)
+    u = np.zeros(n, np.uint16)
+    f = np.zeros(n, np.float32)
+    _chk(lib().pqt_dev_triangle(_p(a, f32p), _p(b, f32p), _p(c, f32p), _p(l, f32p), n, _p(d, f32p), _p(r, f32p),
+                                u.ctypes.data_as(C.POINTER(C.c_uint16)), _p(f, f32p), device))
+    return d, r, u, f

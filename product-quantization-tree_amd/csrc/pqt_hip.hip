@@ -1,0 +1,657 @@
+// pqt_hip.hip -- libpqt_hip.so: index management + launch logic behind the C-ABI of include/pqt_hip.h.
+// gfx950 (MI355X) only.  Build: see csrc/Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pqt_hip.h"
+#include "pqt_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(PQT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+uint32_t upow(uint32_t x, uint32_t n) { uint32_t r = 1; for (uint32_t i = 0; i < n; ++i) r = x * r; return r; }
+uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
+
+enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_RERANK, EV_SELECT, EV_COUNT };
+constexpr int kMaxChunks = 64;
+
+}  // namespace
+
+struct pqt_index {
+  pqt_params prm{};
+  PqtDevParams dp{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // tree
+  float* d_cb1 = nullptr; float* d_cb2 = nullptr; float* d_coarse = nullptr;
+  bool haveTree = false;
+  // heuristic prefix (a3)
+  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr;
+  uint64_t maxMultiIndex = 0;
+  // bin store (a5)
+  PqtBinEntry* d_table = nullptr; uint32_t* d_lower = nullptr; uint32_t tableBits = 0;
+  uint32_t* d_ids = nullptr; uint64_t nIds = 0; uint32_t maxBin = 0; bool sharded = false; bool haveBins = false;
+  uint64_t nTotal = 0;  // database size (all shards)
+  // line codes (a7)
+  uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;
+  // scratch arena
+  float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
+  uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
+  uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr;
+  uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
+  unsigned long long* d_counters = nullptr;  // 8
+  uint64_t stride = 0;
+  // results of the last call
+  pqt_stats stats{};
+  uint32_t lastQn = 0;
+  hipEvent_t ev[kMaxChunks][EV_COUNT]{}; int nChunks = 0; bool evCreated = false;
+  size_t scratchBudget = (size_t)24 << 30;
+};
+
+namespace {
+
+int setDevice(const pqt_index* idx) {
+  HIPCHK(hipSetDevice(idx->device));
+  return PQT_OK;
+}
+
+template <class T>
+int devAlloc(T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
+  return PQT_OK;
+}
+
+int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
+  if (qn <= idx->qCap) return PQT_OK;
+  const PqtDevParams& d = idx->dp;
+  int rc;
+  if ((rc = devAlloc(&idx->d_qL1virt, (size_t)qn * d.LP * d.C1))) return rc;
+  if ((rc = devAlloc(&idx->d_segD, (size_t)qn * d.P * d.WC))) return rc;
+  if ((rc = devAlloc(&idx->d_segBin, (size_t)qn * d.P * d.WC))) return rc;
+  if ((rc = devAlloc(&idx->d_nCand, (size_t)qn))) return rc;
+  if ((rc = devAlloc(&idx->d_nLocal, (size_t)qn))) return rc;
+  idx->qCap = qn;
+  return PQT_OK;
+}
+
+int ensureCandScratch(pqt_index* idx, uint64_t slots) {
+  if (slots <= idx->candCap) return PQT_OK;
+  int rc;
+  if ((rc = devAlloc(&idx->d_cand, slots))) return rc;
+  if ((rc = devAlloc(&idx->d_candDist, slots))) return rc;
+  if (idx->sharded) { if ((rc = devAlloc(&idx->d_candPos, slots))) return rc; }
+  idx->candCap = slots;
+  return PQT_OK;
+}
+
+// host-side construction of the open-addressing bin table
+struct BinDesc { uint32_t key, gcount, lstart, lcount, lower; };
+int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vector<uint32_t>& localIds, bool sharded) {
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  uint32_t bits = 4;
+  while (((uint64_t)1 << bits) < 2 * (uint64_t)bins.size() && bits < 31) ++bits;
+  if (((uint64_t)1 << bits) < bins.size() + 1) return fail(PQT_ERR_LIMIT, "too many bins for the table");
+  const size_t tsz = (size_t)1 << bits;
+  std::vector<PqtBinEntry> table(tsz);
+  memset(table.data(), 0, tsz * sizeof(PqtBinEntry));
+  std::vector<uint32_t> lower;
+  if (sharded) lower.assign(tsz, 0);
+  uint32_t maxBin = 0;
+  const uint32_t mask = (uint32_t)(tsz - 1);
+  for (const BinDesc& b : bins) {
+    if (b.gcount == 0) continue;
+    uint32_t slot = (b.key * 0x9E3779B1u) >> (32u - bits);
+    for (;;) {
+      if (table[slot].gcount == 0) break;
+      if (table[slot].key == b.key) return fail(PQT_ERR_INVALID, "duplicate bin id in bin list");
+      slot = (slot + 1) & mask;
+    }
+    table[slot].key = b.key; table[slot].gcount = b.gcount; table[slot].lstart = b.lstart; table[slot].lcount = b.lcount;
+    if (sharded) lower[slot] = b.lower;
+    maxBin = std::max(maxBin, b.gcount);
+  }
+  if ((rc = devAlloc(&idx->d_table, tsz))) return rc;
+  HIPCHK(hipMemcpy(idx->d_table, table.data(), tsz * sizeof(PqtBinEntry), hipMemcpyHostToDevice));
+  if (idx->d_lower) { (void)hipFree(idx->d_lower); idx->d_lower = nullptr; }
+  if (sharded) {
+    if ((rc = devAlloc(&idx->d_lower, tsz))) return rc;
+    HIPCHK(hipMemcpy(idx->d_lower, lower.data(), tsz * 4, hipMemcpyHostToDevice));
+  }
+  if ((rc = devAlloc(&idx->d_ids, localIds.size()))) return rc;
+  if (!localIds.empty()) HIPCHK(hipMemcpy(idx->d_ids, localIds.data(), localIds.size() * 4, hipMemcpyHostToDevice));
+  idx->nIds = localIds.size();
+  idx->tableBits = bits; idx->maxBin = maxBin; idx->sharded = sharded; idx->haveBins = true;
+  // candidate scratch layout depends on sharded-ness
+  idx->candCap = 0;
+  return PQT_OK;
+}
+
+size_t ldsTables(const PqtDevParams& d) { return (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P * d.W + d.P * d.WC) * 4; }
+size_t ldsBins(const PqtDevParams& d, uint32_t He, uint32_t HeP2, bool sharded) {
+  return (size_t)HeP2 * 8 + (size_t)He * 4 * (sharded ? 4 : 2) + (size_t)d.P * d.WC * 8 + (PQT_BLOCK / 64 + 1 + 4) * 4;
+}
+size_t ldsSelect(uint32_t kP2) { return (size_t)kP2 * 8 + (256 + 8 + PQT_BLOCK / 64 + 1) * 4; }
+size_t ldsEncode(const PqtDevParams& d) {
+  return (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P + d.P * d.C2 + ((d.P * d.C2 + d.P) & 1)) * 4 + (size_t)PQT_BLOCK * 8;
+}
+constexpr size_t kMaxLds = 160 * 1024;
+
+template <class K>
+int allowLds(K kernel, size_t bytes) {
+  if (bytes > kMaxLds) return fail(PQT_ERR_LIMIT, "request needs more than 160 KiB of LDS per workgroup");
+  if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return PQT_OK;
+}
+
+int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
+              uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
+  if (!idx) return fail(PQT_ERR_INVALID, "null index");
+  if (!idx->haveTree || !idx->haveBins || !idx->d_codes || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic, bins and line codes before querying");
+  if (qn == 0) return PQT_OK;
+  if (k == 0 || !q_dev || !outIdx || !outDist) return fail(PQT_ERR_INVALID, "bad query arguments");
+  if (idx->sharded && !outPos) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  if (!st) st = idx->stream;
+  const PqtDevParams& d = idx->dp;
+  // number of heuristic rows enumerated (treequantizer.hpp:552)
+  uint64_t He64 = std::min<uint64_t>(Bb, idx->maxMultiIndex);
+  if (He64 > idx->heurRows) return fail(PQT_ERR_STATE, "bound_bins exceeds the heuristic rows held by the index (build/set a longer prefix)");
+  const uint32_t He = (uint32_t)He64;
+  const uint32_t HeP2 = np2(std::max<uint32_t>(He, 2));
+  const size_t lBins = ldsBins(d, He, HeP2, idx->sharded);
+  if (lBins > kMaxLds) return fail(PQT_ERR_LIMIT, "bound_bins too large for the LDS-resident bin sort");
+  // candidate list bound: the reference overshoots Bv by at most the bin that crosses it
+  uint64_t stride = std::min<uint64_t>((uint64_t)Bv + idx->maxBin + 1, (uint64_t)He * idx->maxBin + 1);
+  stride = (stride + 63) & ~(uint64_t)63;
+  idx->stride = stride;
+  const bool fullSort = (k > 4096);
+  const uint32_t kP2 = np2(std::max<uint32_t>(k, 2));
+  const size_t perQueryBytes = stride * (idx->sharded ? 12 : 8) + (fullSort ? (size_t)np2((uint32_t)stride) * 8 : 0);
+  uint32_t qChunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(qn, idx->scratchBudget / perQueryBytes));
+  int nChunks = (int)((qn + qChunk - 1) / qChunk);
+  if (nChunks > kMaxChunks) { qChunk = (qn + kMaxChunks - 1) / kMaxChunks; nChunks = (int)((qn + qChunk - 1) / qChunk); }
+  if ((rc = ensureQueryScratch(idx, qn))) return rc;
+  if ((rc = ensureCandScratch(idx, (uint64_t)qChunk * stride))) return rc;
+  const uint32_t sortP2 = np2((uint32_t)stride);
+  if (fullSort && (uint64_t)qChunk * sortP2 > idx->sortCap) {
+    if ((rc = devAlloc(&idx->d_sortKeys, (size_t)qChunk * sortP2))) return rc;
+    idx->sortCap = (uint64_t)qChunk * sortP2;
+  }
+  if (!idx->evCreated) {
+    for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) HIPCHK(hipEventCreate(&idx->ev[c][e]));
+    idx->evCreated = true;
+  }
+  HIPCHK(hipMemsetAsync(idx->d_counters, 0, 8 * sizeof(unsigned long long), st));
+
+  const size_t lTab = ldsTables(d);
+  if ((rc = allowLds(pqt_k_tables, lTab))) return rc;
+  if (idx->sharded) { if ((rc = allowLds(pqt_k_bins<true>, lBins))) return rc; } else { if ((rc = allowLds(pqt_k_bins<false>, lBins))) return rc; }
+  const size_t lRer = (size_t)d.LP * d.C1 * 4;
+  const size_t lSel = ldsSelect(kP2);
+  if (!fullSort) { if (idx->sharded) { if ((rc = allowLds(pqt_k_select<true>, lSel))) return rc; } else { if ((rc = allowLds(pqt_k_select<false>, lSel))) return rc; } }
+
+  idx->nChunks = nChunks;
+  for (int c = 0; c < nChunks; ++c) {
+    const uint32_t q0 = (uint32_t)c * qChunk;
+    const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
+    HIPCHK(hipEventRecord(idx->ev[c][EV_BEGIN], st));
+    hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
+                       idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                       idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_counters);
+    HIPCHK(hipEventRecord(idx->ev[c][EV_TABLES], st));
+    if (idx->sharded)
+      hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, stride,
+                         idx->d_counters);
+    else
+      hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, stride,
+                         idx->d_counters);
+    HIPCHK(hipEventRecord(idx->ev[c][EV_BINS], st));
+    if (d.LP % 4 == 0)
+      hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
+                         idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
+                         idx->d_nLocal + q0, stride, d);
+    else
+      hipLaunchKernelGGL(pqt_k_rerank<1>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
+                         idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
+                         idx->d_nLocal + q0, stride, d);
+    HIPCHK(hipEventRecord(idx->ev[c][EV_RERANK], st));
+    uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
+    uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
+    if (fullSort) {
+      if (idx->sharded)
+        hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
+      else
+        hipLaunchKernelGGL(pqt_k_fullsort<false>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
+    } else {
+      if (idx->sharded)
+        hipLaunchKernelGGL(pqt_k_select<true>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
+      else
+        hipLaunchKernelGGL(pqt_k_select<false>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
+    }
+    HIPCHK(hipEventRecord(idx->ev[c][EV_SELECT], st));
+  }
+  if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  idx->lastQn = qn;
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* pqt_last_error(void) { return g_err.c_str(); }
+
+int pqt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; ++i) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+  }
+  return ok;
+}
+
+int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
+  if (!prm || !out) return fail(PQT_ERR_INVALID, "null argument");
+  const pqt_params& p = *prm;
+  if (!p.dim || !p.p || !p.c1 || !p.c2 || !p.w || !p.lp || p.dim % p.p || p.dim % p.lp || p.lp % p.p || p.w > p.c1 ||
+      p.c1 > 256 || p.c2 > 256 || p.p > PQT_MAXP || (uint64_t)p.w * p.c2 > 65536)
+    return fail(PQT_ERR_INVALID, "invalid parameters: need dim%p==0, dim%lp==0, lp%p==0, 1<=w<=c1<=256, c2<=256, p<=8");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(PQT_ERR_DEVICE, "no such HIP device");
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PQT_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  pqt_index* idx = new pqt_index();
+  idx->prm = p; idx->device = device;
+  PqtDevParams& d = idx->dp;
+  d.D = p.dim; d.P = p.p; d.C1 = p.c1; d.C2 = p.c2; d.W = p.w; d.LP = p.lp;
+  d.S = p.dim / p.p; d.SS = p.dim / p.lp; d.R = p.lp / p.p; d.WC = p.w * p.c2; d.hashMod = 0;
+  for (uint32_t i = 0; i < PQT_MAXP; ++i) d.powers[i] = i < p.p ? upow(p.c1 * p.c2, i) : 0;  // treequantizer.hpp:45-49
+  idx->maxMultiIndex = upow(d.WC, p.p);  // treequantizer.hpp:40-41 (wraps in uint32 like the reference)
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&idx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+    delete idx;
+    return fail(PQT_ERR_DEVICE, "stream/counter allocation failed");
+  }
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
+  *out = idx;
+  return PQT_OK;
+}
+
+void pqt_index_destroy(pqt_index* idx) {
+  if (!idx) return;
+  (void)hipSetDevice(idx->device);
+  (void)hipDeviceSynchronize();
+  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_coarse, idx->d_heur, idx->d_table, idx->d_lower, idx->d_ids,
+                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
+                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_sortKeys, idx->d_counters};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (idx->evCreated) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->ev[c][e]);
+  if (idx->stream) (void)hipStreamDestroy(idx->stream);
+  delete idx;
+}
+
+int pqt_index_params(const pqt_index* idx, pqt_params* out) {
+  if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  *out = idx->prm;
+  return PQT_OK;
+}
+
+int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) {
+  if (!idx || !cb1 || !cb2) return fail(PQT_ERR_INVALID, "null argument");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  const PqtDevParams& d = idx->dp;
+  const size_t n1 = (size_t)d.C1 * d.D, n2 = (size_t)d.P * d.C1 * d.C2 * d.S, nc = (size_t)d.LP * d.C1 * d.C1;
+  if ((rc = devAlloc(&idx->d_cb1, n1))) return rc;
+  if ((rc = devAlloc(&idx->d_cb2, n2))) return rc;
+  if ((rc = devAlloc(&idx->d_coarse, nc))) return rc;
+  HIPCHK(hipMemcpy(idx->d_cb1, cb1, n1 * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(idx->d_cb2, cb2, n2 * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pqt_k_coarse, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, idx->stream, idx->d_cb1, idx->d_coarse, d);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  idx->haveTree = true;
+  return PQT_OK;
+}
+
+int pqt_index_get_coarse(const pqt_index* idx, float* out) {
+  if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  if (!idx->haveTree) return fail(PQT_ERR_STATE, "no codebooks");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, idx->d_coarse, (size_t)idx->dp.LP * idx->dp.C1 * idx->dp.C1 * 4, hipMemcpyDeviceToHost));
+  return PQT_OK;
+}
+
+static int uploadHeuristic(pqt_index* idx) {
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  const uint32_t P = idx->dp.P;
+  std::vector<uint16_t> h16(idx->heurRows * P);
+  for (size_t i = 0; i < h16.size(); ++i) {
+    if (idx->heurHost[i] >= idx->dp.WC) return fail(PQT_ERR_INVALID, "heuristic digit out of range (must be < W*C2)");
+    h16[i] = (uint16_t)idx->heurHost[i];
+  }
+  if ((rc = devAlloc(&idx->d_heur, h16.size()))) return rc;
+  if (!h16.empty()) HIPCHK(hipMemcpy(idx->d_heur, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+  return PQT_OK;
+}
+
+// prepareHeuristic (treequantizer.hpp:75-127): every tuple of {0..W*C2-1}^P (digit p of idx in base W*C2),
+// ordered by squared norm with std::sort and the reference's comparator, so the order of equal norms is the
+// one the reference's own build (same libstdc++ introsort) produces.  Only `rows` rows are kept.
+int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows) {
+  if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  const uint64_t M = idx->maxMultiIndex;
+  if (M == 0) return fail(PQT_ERR_LIMIT, "(W*C2)^P wraps to 0 in uint32: the reference enumerates no bins for this configuration");
+  if (M > ((uint64_t)1 << 28)) return fail(PQT_ERR_LIMIT, "(W*C2)^P > 2^28 tuples: supply a prefix with pqt_index_set_heuristic");
+  const uint32_t base = idx->dp.WC, P = idx->dp.P;
+  std::vector<float> norm(M);
+  std::vector<uint32_t> order(M);
+  for (uint64_t i = 0; i < M; ++i) {
+    uint32_t dec = (uint32_t)i;
+    float dig[PQT_MAXP] = {0};
+    uint32_t p = 0;
+    while (dec > 0) { dig[p] = (float)(dec % base); dec /= base; ++p; }
+    float s = 0.f;
+    for (uint32_t j = 0; j < P; ++j) s += dig[j] * dig[j];
+    norm[i] = s; order[i] = (uint32_t)i;
+  }
+  const float* nptr = norm.data();
+  std::sort(order.begin(), order.end(), [nptr](const uint32_t& l, const uint32_t& r) { return nptr[l] < nptr[r]; });
+  rows = std::min<uint64_t>(rows, M);
+  idx->heurHost.assign(rows * P, 0);
+  for (uint64_t h = 0; h < rows; ++h) {
+    uint32_t dec = order[h], p = 0;
+    while (dec > 0) { idx->heurHost[h * P + p] = dec % base; dec /= base; ++p; }
+  }
+  idx->heurRows = rows;
+  return uploadHeuristic(idx);
+}
+
+int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples, uint64_t rows) {
+  if (!idx || (!tuples && rows)) return fail(PQT_ERR_INVALID, "null argument");
+  idx->heurHost.assign(tuples, tuples + rows * idx->dp.P);
+  idx->heurRows = rows;
+  return uploadHeuristic(idx);
+}
+
+int pqt_index_get_heuristic(const pqt_index* idx, uint32_t* out, uint64_t rows) {
+  if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  rows = std::min<uint64_t>(rows, idx->heurRows);
+  memcpy(out, idx->heurHost.data(), rows * idx->dp.P * 4);
+  return PQT_OK;
+}
+
+int pqt_index_set_bins(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* sizes, const uint32_t* members) {
+  if (!idx || (nbins && (!ids || !sizes || !members))) return fail(PQT_ERR_INVALID, "null argument");
+  std::vector<BinDesc> bins(nbins);
+  uint64_t off = 0;
+  for (uint64_t b = 0; b < nbins; ++b) {
+    if (off > 0xffffffffull) return fail(PQT_ERR_LIMIT, "more than 2^32 members");
+    bins[b] = {ids[b], sizes[b], (uint32_t)off, sizes[b], 0};
+    off += sizes[b];
+  }
+  std::vector<uint32_t> local(members, members + off);
+  idx->dp.hashMod = 0;
+  idx->nTotal = off;
+  return uploadBins(idx, bins, local, false);
+}
+
+int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* sizes, const uint32_t* members,
+                             uint32_t id_lo, uint32_t id_hi) {
+  if (!idx || (nbins && (!ids || !sizes || !members))) return fail(PQT_ERR_INVALID, "null argument");
+  std::vector<BinDesc> bins(nbins);
+  std::vector<uint32_t> local;
+  uint64_t off = 0;
+  for (uint64_t b = 0; b < nbins; ++b) {
+    // the local members of a bin must be one contiguous run of its member list (true for id-range shards of the
+    // reference's insertion-ordered lists): lower = members before the run
+    uint32_t lower = 0, cnt = 0; bool started = false, ended = false;
+    const uint32_t lstart = (uint32_t)local.size();
+    for (uint32_t j = 0; j < sizes[b]; ++j) {
+      const uint32_t v = members[off + j];
+      const bool in = v >= id_lo && v < id_hi;
+      if (in) {
+        if (ended) return fail(PQT_ERR_INVALID, "shard members of a bin are not contiguous in its member list");
+        if (!started) { started = true; lower = j; }
+        local.push_back(v); ++cnt;
+      } else if (started) ended = true;
+    }
+    bins[b] = {ids[b], sizes[b], lstart, cnt, lower};
+    off += sizes[b];
+  }
+  idx->dp.hashMod = 0;
+  idx->nTotal = off;
+  return uploadBins(idx, bins, local, true);
+}
+
+int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix, const uint32_t* counts, const uint32_t* dbidx,
+                            uint32_t hash_size) {
+  if (!idx || !prefix || !counts || !dbidx || !hash_size) return fail(PQT_ERR_INVALID, "null argument");
+  std::vector<BinDesc> bins;
+  for (uint32_t s = 0; s < hash_size; ++s)
+    if (counts[s]) {
+      if ((uint64_t)prefix[s] + counts[s] > n) return fail(PQT_ERR_INVALID, "prefix/count outside dbIdx");
+      bins.push_back({s, counts[s], prefix[s], counts[s], 0});
+    }
+  std::vector<uint32_t> local(dbidx, dbidx + n);
+  idx->dp.hashMod = hash_size;
+  idx->nTotal = n;
+  return uploadBins(idx, bins, local, false);
+}
+
+int pqt_index_set_lines_host(pqt_index* idx, const uint32_t* codes, uint64_t nvec, uint64_t id_base) {
+  if (!idx || (!codes && nvec)) return fail(PQT_ERR_INVALID, "null argument");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  if (idx->codesOwned && idx->d_codes) (void)hipFree(idx->d_codes);
+  idx->d_codes = nullptr;
+  if ((rc = devAlloc(&idx->d_codes, (size_t)nvec * idx->dp.LP))) return rc;
+  idx->codesOwned = true;
+  if (nvec) HIPCHK(hipMemcpy(idx->d_codes, codes, (size_t)nvec * idx->dp.LP * 4, hipMemcpyHostToDevice));
+  idx->nCodes = nvec; idx->idBase = id_base;
+  return PQT_OK;
+}
+
+int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t nvec, uint64_t id_base) {
+  if (!idx || !codes_dev) return fail(PQT_ERR_INVALID, "null argument");
+  if (((uintptr_t)codes_dev & 15) != 0) return fail(PQT_ERR_INVALID, "line-code buffer must be 16-byte aligned");
+  if (idx->codesOwned && idx->d_codes) { (void)hipSetDevice(idx->device); (void)hipFree(idx->d_codes); }
+  idx->d_codes = const_cast<uint32_t*>(codes_dev);
+  idx->codesOwned = false; idx->nCodes = nvec; idx->idBase = id_base;
+  return PQT_OK;
+}
+
+int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n, uint32_t* out_bin, uint32_t* out_codes, void* stream) {
+  if (!idx || !vecs_dev || !out_bin || !out_codes) return fail(PQT_ERR_INVALID, "null argument");
+  if (!idx->haveTree) return fail(PQT_ERR_STATE, "no codebooks");
+  if (idx->dp.C1 < 2) return fail(PQT_ERR_INVALID, "line encoding needs C1 >= 2");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
+  const size_t lds = ldsEncode(idx->dp);
+  if ((rc = allowLds(pqt_k_assign_encode, lds))) return rc;
+  const uint64_t maxGrid = 1u << 30;
+  for (uint64_t v0 = 0; v0 < n; v0 += maxGrid) {
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(maxGrid, n - v0);
+    hipLaunchKernelGGL(pqt_k_assign_encode, dim3(nb), dim3(PQT_BLOCK), lds, st, vecs_dev + v0 * idx->dp.D, idx->d_cb1, idx->d_cb2,
+                       idx->d_coarse, idx->dp, out_bin + v0, out_codes + v0 * idx->dp.LP);
+  }
+  HIPCHK(hipGetLastError());
+  if (!stream) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
+int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
+              float* outDist, uint32_t* outCount, void* stream, int sync) {
+  if (idx && idx->sharded) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard + pqt_merge_topk");
+  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, nullptr, outCount, (hipStream_t)stream, sync);
+}
+
+int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
+                    float* outDist, uint32_t* outPos, uint32_t* outCount, void* stream, int sync) {
+  if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard");
+  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync);
+}
+
+int pqt_query_host(pqt_index* idx, const float* q, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
+                   float* outDist, uint32_t* outCount) {
+  if (!idx || !q || !outIdx || !outDist) return fail(PQT_ERR_INVALID, "null argument");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  float* dq = nullptr; uint32_t* dI = nullptr; float* dD = nullptr; uint32_t* dC = nullptr;
+  const size_t nq = (size_t)qn * idx->dp.D, nk = (size_t)qn * k;
+  if ((rc = devAlloc(&dq, nq)) || (rc = devAlloc(&dI, nk)) || (rc = devAlloc(&dD, nk)) || (rc = devAlloc(&dC, (size_t)qn))) {
+    if (dq) (void)hipFree(dq); if (dI) (void)hipFree(dI); if (dD) (void)hipFree(dD); if (dC) (void)hipFree(dC);
+    return rc;
+  }
+  hipError_t e = hipMemcpy(dq, q, nq * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = pqt_query(idx, dq, qn, Bv, Bb, k, dI, dD, dC, nullptr, 1);
+    if (rc == PQT_OK) {
+      e = hipMemcpy(outIdx, dI, nk * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(outDist, dD, nk * 4, hipMemcpyDeviceToHost);
+      if (e == hipSuccess && outCount) e = hipMemcpy(outCount, dC, (size_t)qn * 4, hipMemcpyDeviceToHost);
+    }
+  }
+  (void)hipFree(dq); (void)hipFree(dI); (void)hipFree(dD); (void)hipFree(dC);
+  if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
+  return rc;
+}
+
+int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const uint32_t* inIdx, const float* inDist,
+                   const uint32_t* inPos, uint32_t* outIdx, float* outDist, void* stream, int sync) {
+  if (!idx || !inIdx || !inDist || !inPos || !outIdx || !outDist || !nsh || !k) return fail(PQT_ERR_INVALID, "null argument");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
+  const uint32_t mP2 = np2(std::max<uint32_t>(nsh * k, 2));
+  const size_t lds = (size_t)mP2 * 12;
+  if ((rc = allowLds(pqt_k_merge, lds))) return rc;
+  if (qn) hipLaunchKernelGGL(pqt_k_merge, dim3(qn), dim3(PQT_BLOCK), lds, st, inIdx, inDist, inPos, nsh, qn, k, mP2, outIdx, outDist);
+  HIPCHK(hipGetLastError());
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
+uint64_t pqt_debug_stride(const pqt_index* idx) { return idx ? idx->stride : 0; }
+
+int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd, uint32_t* segbin, uint32_t* candIdx,
+                   float* candDist, uint32_t* ncand) {
+  if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  if (qn > idx->lastQn) return fail(PQT_ERR_STATE, "no such batch held");
+  if (idx->nChunks > 1 && (candIdx || candDist)) return fail(PQT_ERR_STATE, "last batch ran in several chunks; candidates of earlier chunks are gone");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  const PqtDevParams& d = idx->dp;
+  HIPCHK(hipDeviceSynchronize());
+  if (l1virt) HIPCHK(hipMemcpy(l1virt, idx->d_qL1virt, (size_t)qn * d.LP * d.C1 * 4, hipMemcpyDeviceToHost));
+  if (segd) HIPCHK(hipMemcpy(segd, idx->d_segD, (size_t)qn * d.P * d.WC * 4, hipMemcpyDeviceToHost));
+  if (segbin) HIPCHK(hipMemcpy(segbin, idx->d_segBin, (size_t)qn * d.P * d.WC * 4, hipMemcpyDeviceToHost));
+  if (candIdx) HIPCHK(hipMemcpy(candIdx, idx->d_cand, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
+  if (candDist) HIPCHK(hipMemcpy(candDist, idx->d_candDist, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
+  if (ncand) HIPCHK(hipMemcpy(ncand, idx->d_nLocal, (size_t)qn * 4, hipMemcpyDeviceToHost));
+  return PQT_OK;
+}
+
+int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
+  if (!cidx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  pqt_index* idx = const_cast<pqt_index*>(cidx);
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  unsigned long long c[8] = {0};
+  HIPCHK(hipMemcpy(c, idx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  pqt_stats s{};
+  s.queries = idx->lastQn; s.ties_l1 = c[0]; s.ties_l2 = c[1]; s.ties_bins = c[2]; s.ties_final = c[3];
+  s.candidates = c[4]; s.bins_visited = c[5]; s.bins_nonempty = c[6]; s.max_bin = idx->maxBin;
+  for (int ch = 0; ch < idx->nChunks; ++ch) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BEGIN], idx->ev[ch][EV_TABLES]) == hipSuccess) s.ms_tables += ms;
+    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_TABLES], idx->ev[ch][EV_BINS]) == hipSuccess) s.ms_bins += ms;
+    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BINS], idx->ev[ch][EV_RERANK]) == hipSuccess) s.ms_rerank += ms;
+    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_RERANK], idx->ev[ch][EV_SELECT]) == hipSuccess) s.ms_select += ms;
+  }
+  if (idx->nChunks > 0) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, idx->ev[0][EV_BEGIN], idx->ev[idx->nChunks - 1][EV_SELECT]) == hipSuccess) s.ms_total = ms;
+  }
+  idx->stats = s;
+  *out = s;
+  return PQT_OK;
+}
+
+int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
+  if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  if (hipSetDevice(idx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(PQT_ERR_DEVICE, "sync failed");
+  int n = 0;
+  for (int ch = 0; ch < idx->nChunks && n < cap; ++ch) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BINS], idx->ev[ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
+    out[n++] = ms;
+  }
+  return n;
+}
+
+int pqt_dev_triangle(const float* a, const float* b, const float* c, const float* l, uint32_t n, float* outDist, float* outRatio,
+                     uint16_t* outU16, float* outRound, int device) {
+  if (!a || !b || !c || !l || !outDist || !outRatio || !outU16 || !outRound) return fail(PQT_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(device));
+  float* d = nullptr; uint16_t* du = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)n * 7 * 4 + 16));
+  HIPCHK(hipMalloc((void**)&du, (size_t)n * 2 + 16));
+  float *da = d, *db = d + n, *dc = d + 2 * (size_t)n, *dl = d + 3 * (size_t)n, *dD = d + 4 * (size_t)n, *dR = d + 5 * (size_t)n, *dF = d + 6 * (size_t)n;
+  hipError_t e = hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dc, c, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dl, l, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pqt_k_triangle, dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dc, dl, n, dD, dR, du, dF);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(outDist, dD, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(outRatio, dR, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(outRound, dF, (size_t)n * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(outU16, du, (size_t)n * 2, hipMemcpyDeviceToHost);
+  (void)hipFree(d); (void)hipFree(du);
+  if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
+  return PQT_OK;
+}
+
+}  // extern "C"

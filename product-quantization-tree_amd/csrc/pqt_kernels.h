@@ -1,0 +1,620 @@
+// pqt_kernels.h -- the gfx950 kernels of the PQT query hot path (and the offline encode kernel).
+// Included once by pqt_hip.hip.  Stage names follow SURVEY.md §8a (a1..a10).
+//
+// All floating-point here is f32 with the exact association of the reference's cpu_version source,
+// summed left to right with separate multiply and add (the TU is built with -ffp-contract=off), so
+// tables, bin distances and ADC distances are bit-identical to the oracle and every sort sees the
+// same keys.  Sorts are by (key, original position): the result equals any comparison sort of the
+// reference whenever no two keys are exactly equal, and is the stable order otherwise.
+#pragma once
+#include "pqt_device.h"
+
+#define PQT_BLOCK 256
+
+// ---------------------------------------------------------------------------------------------------
+// setup (a9): coarse[(lp*C1 + i)*C1 + j] = || cb1[i]_lp - cb1[j]_lp ||^2     (treequantizer.hpp:183-203)
+// The reference evaluates (AV - BV) with i <= j and mirrors; x-y and y-x square identically, so
+// evaluating every (i,j) directly gives the same bits.
+// ---------------------------------------------------------------------------------------------------
+__global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ coarse, PqtDevParams prm) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t total = prm.LP * prm.C1 * prm.C1;
+  if (t >= total) return;
+  const uint32_t j = t % prm.C1, i = (t / prm.C1) % prm.C1, lp = t / (prm.C1 * prm.C1);
+  const uint32_t a = i < j ? i : j, b = i < j ? j : i;  // AV = row min, BV = row max, like the reference
+  const float* x = cb1 + (size_t)a * prm.D + lp * prm.SS;
+  const float* y = cb1 + (size_t)b * prm.D + lp * prm.SS;
+  float s = 0.f;
+  for (uint32_t d = 0; d < prm.SS; ++d) { const float df = x[d] - y[d]; s = s + df * df; }
+  coarse[t] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage a1 + a2: per-query distance tables and the sorted second-level entry lists.
+//   one workgroup per query.
+//   a1  L1virt[lp][c] = ||q_lp - cb1[c]_lp||^2 ; L1[p][c] = sum_pp L1virt[p*R+pp][c]   (treequantizer.hpp:640-661)
+//       W nearest cells per part in ascending order                                      (:663-671)
+//   a2  for the W cells: d2[h1*C2+h2] = ||q_p - cb2[p][c1][h2]||^2, sorted by d2         (:597-630, vectorquantizer.hpp:104-115)
+// outputs: qL1virt[q][LP*C1] ; segD[q][P][WC] ascending ; segBin[q][P][WC] = c1*C2+h2 in the same order
+// LDS: D + LP*C1 + P*C1 + P*W + P*WC words.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
+    const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2, PqtDevParams prm,
+    float* __restrict__ qL1virt, float* __restrict__ segD, uint32_t* __restrict__ segBin,
+    unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, W = prm.W, LP = prm.LP, S = prm.S, SS = prm.SS,
+                 R = prm.R, WC = prm.WC;
+  float* sQ = smem;
+  float* sVirt = sQ + D;
+  float* sL1 = sVirt + LP * C1;
+  uint32_t* sOrd = (uint32_t*)(sL1 + P * C1);
+  float* sD2 = (float*)(sOrd + P * W);
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+
+  for (uint32_t i = tid; i < D; i += PQT_BLOCK) sQ[i] = Q[(size_t)q * D + i];
+  __syncthreads();
+
+  // a1: one accumulator per (centroid, line part); t = c*LP + lp walks cb1 contiguously
+  for (uint32_t t = tid; t < C1 * LP; t += PQT_BLOCK) {
+    const uint32_t c = t / LP, lp = t % LP;
+    const float* cen = cb1 + (size_t)c * D + lp * SS;
+    const float* qq = sQ + lp * SS;
+    float s = 0.f;
+    for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+    sVirt[lp * C1 + c] = s;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) qL1virt[(size_t)q * LP * C1 + t] = sVirt[t];
+  for (uint32_t t = tid; t < P * C1; t += PQT_BLOCK) {
+    const uint32_t p = t / C1, c = t % C1;
+    float d = 0.f;
+    for (uint32_t pp = 0; pp < R; ++pp) d = d + sVirt[(p * R + pp) * C1 + c];
+    sL1[t] = d;
+  }
+  __syncthreads();
+  // rank of each cell inside its part by (distance, index): the W smallest land in sOrd in order
+  uint32_t ties = 0;
+  for (uint32_t t = tid; t < P * C1; t += PQT_BLOCK) {
+    const uint32_t p = t / C1, c = t % C1;
+    const float my = sL1[t];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < C1; ++o) {
+      const float v = sL1[p * C1 + o];
+      rank += (v < my) || (v == my && o < c);
+      ties += (v == my && o < c);
+    }
+    if (rank < W) sOrd[p * W + rank] = c;
+  }
+  if (ties) atomicAdd(&counters[0], (unsigned long long)ties);
+  __syncthreads();
+  // a2: second-level distances of the W expanded cells
+  for (uint32_t t = tid; t < P * WC; t += PQT_BLOCK) {
+    const uint32_t p = t / WC, pos = t % WC, h1 = pos / C2, h2 = pos % C2;
+    const uint32_t c1 = sOrd[p * W + h1];
+    const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
+    const float* qq = sQ + p * S;
+    float s = 0.f;
+    for (uint32_t d = 0; d < S; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+    sD2[t] = s;
+  }
+  __syncthreads();
+  ties = 0;
+  for (uint32_t t = tid; t < P * WC; t += PQT_BLOCK) {
+    const uint32_t p = t / WC, pos = t % WC, h1 = pos / C2, h2 = pos % C2;
+    const float my = sD2[t];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < WC; ++o) {
+      const float v = sD2[p * WC + o];
+      rank += (v < my) || (v == my && o < pos);
+      ties += (v == my && o < pos);
+    }
+    const size_t base = ((size_t)q * P + p) * WC;
+    segD[base + rank] = my;
+    segBin[base + rank] = sOrd[p * W + h1] * C2 + h2;
+  }
+  if (ties) atomicAdd(&counters[1], (unsigned long long)ties);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage a4 + a5 + a6: bin enumeration, probe, exact ordering, cut and candidate gather.
+//   one workgroup per query.
+//   a4  for h < He: dist_h = sum_p segD[p][heur[h][p]] ; glob_h = sum_p segBin[p][..]*powers[p] (uint32 wrap)
+//       then order the bins by dist_h                                                  (treequantizer.hpp:548-588)
+//   a5  probe the bin table for (start, population)                                    (:462-463, std::map lookup)
+//   a6  visit bins in order, take whole bins, stop after the bin during which the running count
+//       exceeded Bv (strict >)                                                         (:450-477)
+// outputs: cand[q*stride + j] = vector id of the j-th candidate in visiting order (local members only
+//          when sharded), candPos (sharded only) = global visiting position, nCand[q] = GLOBAL candidate
+//          count, nLocal[q] = local candidate count.
+// LDS: P*WC*2 words + NP2(He) u64 keys + He*3 words (gcount/lstart/lcount by h) + scan scratch.
+// ---------------------------------------------------------------------------------------------------
+template <bool SHARDED>
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
+    const float* __restrict__ segD, const uint32_t* __restrict__ segBin, const uint16_t* __restrict__ heur,
+    uint32_t He, uint32_t HeP2, uint32_t Bv, PqtDevParams prm, const PqtBinEntry* __restrict__ table,
+    const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids,
+    uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos, uint32_t* __restrict__ nCand,
+    uint32_t* __restrict__ nLocal, uint64_t stride, unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t P = prm.P, WC = prm.WC;
+  uint64_t* sKey = (uint64_t*)smem_raw;                 // HeP2
+  uint32_t* sG = (uint32_t*)(sKey + HeP2);              // He : global population by h
+  uint32_t* sLs = sG + He;                              // He : local start by h
+  uint32_t* sLc = sLs + He;                             // He : local count by h   (SHARDED)
+  uint32_t* sLo = sLc + (SHARDED ? He : 0);             // He : lower count by h   (SHARDED)
+  float* sSegD = (float*)(sLo + (SHARDED ? He : 0));    // P*WC
+  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);        // P*WC
+  uint32_t* sPart = sSegB + P * WC;                     // PQT_BLOCK/64 + 1
+  uint32_t* sMisc = sPart + (PQT_BLOCK / 64 + 1);       // 4
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+
+  for (uint32_t t = tid; t < P * WC; t += PQT_BLOCK) {
+    sSegD[t] = segD[(size_t)q * P * WC + t];
+    sSegB[t] = segBin[(size_t)q * P * WC + t];
+  }
+  __syncthreads();
+
+  for (uint32_t h = tid; h < HeP2; h += PQT_BLOCK) {
+    if (h >= He) { sKey[h] = ~0ull; continue; }
+    uint32_t glob = 0;
+    float fine = 0.f;
+    for (uint32_t p = 0; p < P; ++p) {
+      const uint32_t idx = heur[(size_t)h * P + p];
+      fine = fine + sSegD[p * WC + idx];
+      glob += sSegB[p * WC + idx] * prm.powers[p];
+    }
+    if (prm.hashMod) glob %= prm.hashMod;
+    // probe (linear probing; gcount == 0 terminates)
+    uint32_t slot = pqt_hash_slot(glob, tableBits);
+    const uint32_t mask = (1u << tableBits) - 1u;
+    uint32_t g = 0, ls = 0, lc = 0, lo = 0;
+    for (;;) {
+      const PqtBinEntry e = table[slot];
+      if (e.gcount == 0) break;
+      if (e.key == glob) { g = e.gcount; ls = e.lstart; lc = e.lcount; if (SHARDED) lo = lower[slot]; break; }
+      slot = (slot + 1) & mask;
+    }
+    sG[h] = g; sLs[h] = ls;
+    if (SHARDED) { sLc[h] = lc; sLo[h] = lo; }
+    sKey[h] = ((uint64_t)pqt_f2key(fine) << 32) | h;
+  }
+  __syncthreads();
+  pqt_bitonic_sort_u64<PQT_BLOCK>(sKey, HeP2);
+
+  // exclusive scan of the global populations in visiting order; each thread owns a contiguous chunk
+  const uint32_t per = (He + PQT_BLOCK - 1) / PQT_BLOCK;
+  const uint32_t i0 = tid * per, i1 = (i0 + per < He) ? i0 + per : He;
+  uint32_t loc = 0, locL = 0, ties = 0;
+  for (uint32_t i = i0; i < i1; ++i) {
+    const uint32_t h = (uint32_t)sKey[i];
+    loc += sG[h];
+    if (SHARDED) locL += sLc[h];
+    if (i + 1 < He && (uint32_t)(sKey[i] >> 32) == (uint32_t)(sKey[i + 1] >> 32)) ++ties;
+  }
+  if (ties) atomicAdd(&counters[2], (unsigned long long)ties);
+  uint32_t total;
+  uint32_t run = pqt_block_excl_scan<PQT_BLOCK>(loc, sPart, &total);
+  // number of included bins nb = #{i : excl[i] <= Bv}; excl is non-decreasing so this is a prefix
+  if (tid == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; }
+  __syncthreads();
+  uint32_t myIncl = 0, myCand = 0;
+  {
+    uint32_t r = run;
+    for (uint32_t i = i0; i < i1; ++i) {
+      const uint32_t h = (uint32_t)sKey[i];
+      if (r <= Bv) { ++myIncl; myCand = r + sG[h]; }
+      r += sG[h];
+    }
+  }
+  if (myIncl) { atomicAdd(&sMisc[0], myIncl); atomicMax(&sMisc[1], myCand); }
+  __syncthreads();
+  const uint32_t nb = sMisc[0];
+  const uint32_t nGlobal = sMisc[1];
+  // second pass: rewrite keys as (start of the bin in the candidate list << 32 | h) for the gather.
+  // unsharded: list position == global position.  sharded: local list position, from a scan of lcount.
+  uint32_t runL = run;
+  if (SHARDED) {
+    uint32_t totalL;
+    // only included bins contribute local candidates
+    uint32_t locIncl = 0;
+    { uint32_t r = run; for (uint32_t i = i0; i < i1; ++i) { const uint32_t h = (uint32_t)sKey[i]; if (r <= Bv) locIncl += sLc[h]; r += sG[h]; } }
+    runL = pqt_block_excl_scan<PQT_BLOCK>(locIncl, sPart, &totalL);
+    if (tid == 0) sMisc[2] = totalL;
+  }
+  {
+    uint32_t r = run, rl = runL;
+    for (uint32_t i = i0; i < i1; ++i) {
+      const uint32_t h = (uint32_t)sKey[i];
+      const uint32_t g = sG[h];
+      if (SHARDED) {
+        // stash the global start of the bin in sG[h] (no longer needed as a count once lcount is separate)
+        sKey[i] = ((uint64_t)rl << 32) | h;
+        sG[h] = r;
+        if (r <= Bv) rl += sLc[h];
+      } else {
+        sKey[i] = ((uint64_t)r << 32) | h;
+      }
+      r += g;
+    }
+  }
+  __syncthreads();
+  const uint32_t nLoc = SHARDED ? sMisc[2] : nGlobal;
+  if (tid == 0) {
+    nCand[q] = nGlobal;
+    nLocal[q] = nLoc;
+    atomicAdd(&counters[4], (unsigned long long)nLoc);
+    atomicAdd(&counters[5], (unsigned long long)He);
+    atomicAdd(&counters[6], (unsigned long long)nb);
+  }
+  // a6 gather: candidate j lives in the last included bin whose list start is <= j
+  for (uint32_t j = tid; j < nLoc; j += PQT_BLOCK) {
+    uint32_t lo = 0, hi = nb;  // invariant: start[lo] <= j, answer in [lo, hi)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint32_t)(sKey[mid] >> 32) <= j) lo = mid; else hi = mid;
+    }
+    const uint32_t h = (uint32_t)sKey[lo];
+    const uint32_t off = j - (uint32_t)(sKey[lo] >> 32);
+    cand[(size_t)q * stride + j] = ids[sLs[h] + off];
+    if (SHARDED) candPos[(size_t)q * stride + j] = sG[h] + sLo[h] + off;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage a7: ADC line rerank.  One workgroup per query, one lane per candidate; the lane streams the
+// candidate's LP 4-byte codes (one 64/128-byte row, read as 16-byte vectors) and accumulates
+//   sum_{p<LP} extractDistance(a = L1virt[p][B], b = L1virt[p][A], c = coarse[p][A][B], lambda)
+// in p order -- treequantizer.hpp:423-439 + helper.hpp:132-136 -- so the sum is bit-identical.
+// L1virt of the query sits in LDS; coarse[LP][C1][C1] is read through L2 (64 KB..512 KB, resident).
+// ---------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_rerank(
+    const uint32_t* __restrict__ codes, uint64_t idBase, const float* __restrict__ qL1virt,
+    const float* __restrict__ coarse, const uint32_t* __restrict__ cand, float* __restrict__ candDist,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, PqtDevParams prm) {
+  extern __shared__ __attribute__((aligned(16))) float sVirt[];
+  const uint32_t C1 = prm.C1, LP = prm.LP;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = nLocal[q];
+  if (n == 0) return;
+  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
+  __syncthreads();
+  for (uint32_t j = tid; j < n; j += PQT_BLOCK) {
+    const uint32_t id = cand[(size_t)q * stride + j];
+    const uint32_t* row = codes + ((size_t)id - idBase) * LP;
+    float acc = 0.f;
+    if (VEC == 4) {
+      const uint4* row4 = reinterpret_cast<const uint4*>(row);
+      for (uint32_t p4 = 0; p4 < LP / 4; ++p4) {
+        const uint4 v = row4[p4];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t p = p4 * 4 + u;
+          const uint32_t A = w[u] & 0xffu, B = (w[u] >> 8) & 0xffu;
+          const float lam = pqt_lambda_decode(w[u] >> 16);
+          const float sb = sVirt[p * C1 + A];
+          const float sa = sVirt[p * C1 + B];
+          const float sc = coarse[((size_t)p * C1 + A) * C1 + B];
+          acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+        }
+      }
+    } else {
+      for (uint32_t p = 0; p < LP; ++p) {
+        const uint32_t w = row[p];
+        const uint32_t A = w & 0xffu, B = (w >> 8) & 0xffu;
+        const float lam = pqt_lambda_decode(w >> 16);
+        const float sb = sVirt[p * C1 + A];
+        const float sa = sVirt[p * C1 + B];
+        const float sc = coarse[((size_t)p * C1 + A) * C1 + B];
+        acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+      }
+    }
+    candDist[(size_t)q * stride + j] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage a8: top-k of the candidate list by (distance, visiting position)   (treequantizer.hpp:479-483)
+//   one workgroup per query.  Radix select of the k-th key (4 x 8-bit passes over the f32 keys), ordered
+//   resolution of ties at the threshold, then a bitonic sort of the <= k survivors in LDS.
+//   SHARDED: the tie-break position is candPos (global visiting position) and is written to outPos.
+// LDS: 256 + 8 words histogram/misc, NP2(k) u64.
+// ---------------------------------------------------------------------------------------------------
+template <bool SHARDED>
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_select(
+    const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t kP2,
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
+    unsigned long long* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* sSel = (uint64_t*)smem_raw;        // kP2
+  uint32_t* sHist = (uint32_t*)(sSel + kP2);   // 256
+  uint32_t* sMisc = sHist + 256;               // 8
+  uint32_t* sPart = sMisc + 8;                 // PQT_BLOCK/64+1
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = nLocal[q];
+  const float* dist = candDist + (size_t)q * stride;
+  const uint32_t* cid = cand + (size_t)q * stride;
+  const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
+  const uint32_t kk = n < k ? n : k;  // number of real results
+
+  for (uint32_t i = tid; i < kP2; i += PQT_BLOCK) sSel[i] = ~0ull;
+  if (tid == 0) sMisc[0] = 0;
+  __syncthreads();
+
+  if (n <= k) {
+    for (uint32_t j = tid; j < n; j += PQT_BLOCK) sSel[j] = ((uint64_t)pqt_f2key(dist[j]) << 32) | j;
+  } else {
+    // ---- radix select: find T = k-th smallest key, m = #{key < T}
+    uint32_t prefix = 0, want = k;  // want-th smallest (1-based) among keys matching `prefix` on the bits fixed so far
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      sHist[tid] = 0;  // PQT_BLOCK == 256
+      __syncthreads();
+      const uint32_t himask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      for (uint32_t j = tid; j < n; j += PQT_BLOCK) {
+        const uint32_t key = pqt_f2key(dist[j]);
+        if ((key & himask) == prefix) atomicAdd(&sHist[(key >> shift) & 0xffu], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t acc = 0, d = 0;
+        for (; d < 256; ++d) { if (acc + sHist[d] >= want) break; acc += sHist[d]; }
+        sMisc[1] = d; sMisc[2] = want - acc;
+      }
+      __syncthreads();
+      prefix |= sMisc[1] << shift;
+      want = sMisc[2];
+      __syncthreads();
+    }
+    const uint32_t T = prefix;
+    const uint32_t r = want;  // how many of the key == T group are needed (>= 1), in position order
+    // ---- collect key < T (any order; the final sort fixes it)
+    for (uint32_t j = tid; j < n; j += PQT_BLOCK) {
+      const uint32_t key = pqt_f2key(dist[j]);
+      if (key < T) { const uint32_t s = atomicAdd(&sMisc[0], 1u); sSel[s] = ((uint64_t)key << 32) | j; }
+    }
+    __syncthreads();
+    const uint32_t m = sMisc[0];  // == k - r
+    // ---- key == T: the r smallest tie-break positions.  Unsharded: position == j, so an ordered sweep
+    // (chunks of PQT_BLOCK in j order with a block scan) accepts exactly the first r.  Sharded: positions
+    // are increasing in j as well (local list order follows global visiting order), same sweep.
+    uint32_t taken = 0;
+    for (uint32_t base = 0; base < n && taken < r; base += PQT_BLOCK) {
+      const uint32_t j = base + tid;
+      const uint32_t flag = (j < n && pqt_f2key(dist[j]) == T) ? 1u : 0u;
+      uint32_t tot;
+      const uint32_t ex = pqt_block_excl_scan<PQT_BLOCK>(flag, sPart, &tot);
+      if (flag && taken + ex < r) sSel[m + taken + ex] = ((uint64_t)T << 32) | j;
+      taken += tot;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  // sort by (key, tie-break position).  Low word currently holds j; for the sharded case swap in the
+  // global position for sorting, but keep j recoverable: positions are monotone in j, so sorting by j
+  // is equivalent -- no swap needed.
+  pqt_bitonic_sort_u64<PQT_BLOCK>(sSel, kP2);
+  uint32_t ties = 0;
+  for (uint32_t i = tid; i < k; i += PQT_BLOCK) {
+    if (i < kk) {
+      const uint32_t j = (uint32_t)sSel[i];
+      outIdx[(size_t)q * k + i] = cid[j];
+      outDist[(size_t)q * k + i] = dist[j];
+      if (SHARDED) outPos[(size_t)q * k + i] = cpos[j];
+      if (i + 1 < kk && (uint32_t)(sSel[i] >> 32) == (uint32_t)(sSel[i + 1] >> 32)) ++ties;
+    } else {
+      outIdx[(size_t)q * k + i] = 0xffffffffu;
+      outDist[(size_t)q * k + i] = __uint_as_float(0x7f800000u);
+      if (SHARDED) outPos[(size_t)q * k + i] = 0xffffffffu;
+    }
+  }
+  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+}
+
+// full sort of every candidate list through a global-memory key buffer (parity / large-k path):
+// keys[q][nP2] u64, one workgroup per query.
+template <bool SHARDED>
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
+    const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint64_t* __restrict__ keys, uint32_t nP2max,
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
+    unsigned long long* __restrict__ counters) {
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = nLocal[q];
+  uint32_t nP2 = 1;
+  while (nP2 < n) nP2 <<= 1;
+  if (nP2 < 2) nP2 = 2;
+  uint64_t* a = keys + (size_t)q * nP2max;
+  const float* dist = candDist + (size_t)q * stride;
+  for (uint32_t j = tid; j < nP2; j += PQT_BLOCK) a[j] = j < n ? (((uint64_t)pqt_f2key(dist[j]) << 32) | j) : ~0ull;
+  __syncthreads();
+  pqt_bitonic_sort_u64<PQT_BLOCK>(a, nP2);
+  const uint32_t kk = n < k ? n : k;
+  uint32_t ties = 0;
+  for (uint32_t i = tid; i < k; i += PQT_BLOCK) {
+    if (i < kk) {
+      const uint32_t j = (uint32_t)a[i];
+      outIdx[(size_t)q * k + i] = cand[(size_t)q * stride + j];
+      outDist[(size_t)q * k + i] = dist[j];
+      if (SHARDED) outPos[(size_t)q * k + i] = candPos[(size_t)q * stride + j];
+      if (i + 1 < kk && (uint32_t)(a[i] >> 32) == (uint32_t)(a[i + 1] >> 32)) ++ties;
+    } else {
+      outIdx[(size_t)q * k + i] = 0xffffffffu;
+      outDist[(size_t)q * k + i] = __uint_as_float(0x7f800000u);
+      if (SHARDED) outPos[(size_t)q * k + i] = 0xffffffffu;
+    }
+  }
+  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU merge: per query, the nsh*k gathered (dist, pos, id) triples -> first k by (dist, pos).
+// Bitonic sort of slot indices with a (distance key, global visiting position) comparator in LDS.
+// LDS: mP2 u32 indices + m u32 keys + m u32 positions.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
+    const uint32_t* __restrict__ inIdx, const float* __restrict__ inDist, const uint32_t* __restrict__ inPos,
+    uint32_t nsh, uint32_t qn, uint32_t k, uint32_t mP2, uint32_t* __restrict__ outIdx, float* __restrict__ outDist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t* sI = (uint32_t*)smem_raw;  // mP2 slot indices (0xffffffff = padding)
+  uint32_t* sK = sI + mP2;             // mP2 distance keys
+  uint32_t* sP = sK + mP2;             // mP2 positions
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t m = nsh * k;
+  for (uint32_t i = tid; i < mP2; i += PQT_BLOCK) {
+    uint32_t key = 0xffffffffu, pos = 0xffffffffu;
+    if (i < m) {
+      const size_t o = ((size_t)(i / k) * qn + q) * k + (i % k);
+      if (inIdx[o] != 0xffffffffu) { key = pqt_f2key(inDist[o]); pos = inPos[o]; }
+    }
+    sI[i] = i; sK[i] = key; sP[i] = pos;
+  }
+  __syncthreads();
+  for (uint32_t kk = 2; kk <= mP2; kk <<= 1)
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < (mP2 >> 1); i += PQT_BLOCK) {
+        const uint32_t lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+        const bool up = ((lo & kk) == 0);
+        const uint32_t x = sI[lo], y = sI[hi];
+        const uint64_t kx = ((uint64_t)sK[x] << 32) | sP[x], ky = ((uint64_t)sK[y] << 32) | sP[y];
+        const bool gt = kx > ky || (kx == ky && x > y);
+        if (gt == up) { sI[lo] = y; sI[hi] = x; }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = tid; i < k; i += PQT_BLOCK) {
+    const uint32_t s = sI[i];
+    uint32_t id = 0xffffffffu; float d = __uint_as_float(0x7f800000u);
+    if (s < m) {
+      const size_t o = ((size_t)(s / k) * qn + q) * k + (s % k);
+      id = inIdx[o]; d = inDist[o];
+    }
+    outIdx[(size_t)q * k + i] = id;
+    outDist[(size_t)q * k + i] = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// offline ("next" row): insert = id() + prepareReranking for a batch of database vectors.
+//   one workgroup per vector.  bin id: nearest first-level cell per part, nearest second-level centroid
+//   inside it (treequantizer.hpp:673-684); line code per line part: the pair A < B minimising the
+//   projection error, first minimum in (A,B) scan order (:356-391).
+// LDS: D + LP*C1 + P*C1 + P + C2*P words + reduction scratch.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
+    const float* __restrict__ X, const float* __restrict__ cb1, const float* __restrict__ cb2,
+    const float* __restrict__ coarse, PqtDevParams prm, uint32_t* __restrict__ outBin, uint32_t* __restrict__ outCodes) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, LP = prm.LP, S = prm.S, SS = prm.SS, R = prm.R;
+  float* sX = smem;
+  float* sVirt = sX + D;
+  float* sL1 = sVirt + LP * C1;
+  uint32_t* sBest1 = (uint32_t*)(sL1 + P * C1);   // P
+  float* sD2 = (float*)(sBest1 + P);              // P*C2
+  uint64_t* sRed = (uint64_t*)(sD2 + P * C2 + ((P * C2 + P) & 1));  // PQT_BLOCK  (8-byte aligned: D, LP*C1, P*C1 even in practice)
+  const size_t v = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < D; i += PQT_BLOCK) sX[i] = X[v * D + i];
+  __syncthreads();
+  for (uint32_t t = tid; t < C1 * LP; t += PQT_BLOCK) {
+    const uint32_t c = t / LP, lp = t % LP;
+    const float* cen = cb1 + (size_t)c * D + lp * SS;
+    const float* xx = sX + lp * SS;
+    float s = 0.f;
+    for (uint32_t d = 0; d < SS; ++d) { const float df = xx[d] - cen[d]; s = s + df * df; }
+    sVirt[lp * C1 + c] = s;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < P * C1; t += PQT_BLOCK) {
+    const uint32_t p = t / C1, c = t % C1;
+    float d = 0.f;
+    for (uint32_t pp = 0; pp < R; ++pp) d = d + sVirt[(p * R + pp) * C1 + c];
+    sL1[t] = d;
+  }
+  __syncthreads();
+  if (tid < P) {  // nearest cell per part, ties -> lowest index (stable order of the reference's sort)
+    uint32_t best = 0; float bd = sL1[tid * C1];
+    for (uint32_t c = 1; c < C1; ++c) { const float d = sL1[tid * C1 + c]; if (d < bd) { bd = d; best = c; } }
+    sBest1[tid] = best;
+  }
+  __syncthreads();
+  for (uint32_t t = tid; t < P * C2; t += PQT_BLOCK) {
+    const uint32_t p = t / C2, h2 = t % C2;
+    const float* cen = cb2 + (((size_t)p * C1 + sBest1[p]) * C2 + h2) * S;
+    const float* xx = sX + p * S;
+    float s = 0.f;
+    for (uint32_t d = 0; d < S; ++d) { const float df = xx[d] - cen[d]; s = s + df * df; }
+    sD2[t] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t bin = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+      uint32_t best = 0; float bd = sD2[p * C2];
+      for (uint32_t h = 1; h < C2; ++h) { const float d = sD2[p * C2 + h]; if (d < bd) { bd = d; best = h; } }
+      bin += (sBest1[p] * C2 + best) * prm.powers[p];
+    }
+    outBin[v] = bin;
+  }
+  // line codes: for each line part, search all pairs A < B.  pair index e enumerates (A,B) in the
+  // reference's scan order; reduce by (error key, e) so the first minimum wins like its strict '<'.
+  const uint32_t npairs = C1 * (C1 - 1) / 2;
+  for (uint32_t lp = 0; lp < LP; ++lp) {
+    uint64_t best = ~0ull;
+    for (uint32_t e = tid; e < npairs; e += PQT_BLOCK) {
+      // decode e -> (A,B), A<B, row-major over A
+      uint32_t A = 0, rem = e;
+      // rows have C1-1-A entries
+      while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; }
+      const uint32_t B = A + 1 + rem;
+      const float sb = sVirt[lp * C1 + A], sa = sVirt[lp * C1 + B];
+      const float sc = coarse[((size_t)lp * C1 + A) * C1 + B];
+      const float lam = pqt_calc_ratio(sa, sb, sc);
+      const float err = pqt_extract_distance(sa, sb, sc, lam);
+      // strict '<' against HUGE_VAL start: NaN errors never win, +inf never wins
+      if (err == err && err < __uint_as_float(0x7f800000u)) {
+        const uint64_t key = ((uint64_t)pqt_f2key(err) << 32) | e;
+        if (key < best) best = key;
+      }
+    }
+    sRed[tid] = best;
+    __syncthreads();
+    for (uint32_t s = PQT_BLOCK / 2; s > 0; s >>= 1) {
+      if (tid < s) { const uint64_t o = sRed[tid + s]; if (o < sRed[tid]) sRed[tid] = o; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const uint64_t w = sRed[0];
+      uint32_t code;
+      if (w == ~0ull) {
+        code = pqt_lambda_encode(0.f) << 16;  // best_id_A = best_id_B = 0, best_lambda = 0 (initial values, :362-365)
+      } else {
+        const uint32_t e = (uint32_t)w;
+        uint32_t A = 0, rem = e;
+        while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; }
+        const uint32_t B = A + 1 + rem;
+        const float sb = sVirt[lp * C1 + A], sa = sVirt[lp * C1 + B];
+        const float sc = coarse[((size_t)lp * C1 + A) * C1 + B];
+        const float lam = pqt_calc_ratio(sa, sb, sc);
+        code = (A & 0xffu) | ((B & 0xffu) << 8) | (pqt_lambda_encode(lam) << 16);
+      }
+      outCodes[v * LP + lp] = code;
+    }
+    __syncthreads();
+  }
+}
+
+// line-quantisation scalars evaluated on the device (known-answer tests, run.cu:33-113)
+__global__ void pqt_k_triangle(const float* a, const float* b, const float* c, const float* l, uint32_t n,
+                               float* outDist, float* outRatio, uint16_t* outU16, float* outRound) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  outDist[i] = pqt_extract_distance(a[i], b[i], c[i], l[i]);
+  outRatio[i] = pqt_calc_ratio(a[i], b[i], c[i]);
+  const uint32_t u = pqt_lambda_encode(l[i]);
+  outU16[i] = (uint16_t)u;
+  outRound[i] = pqt_lambda_decode(u);
+}

@@ -1,0 +1,117 @@
+"""Shared test helpers: synthetic SIFT-shaped data, quick codebooks, oracle/HIP index pairs."""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import Oracle  # noqa: E402  (test infrastructure)
+
+
+def pqt_pkg():
+    return importlib.import_module("product-quantization-tree_amd")
+
+
+def sift_like(n, D, seed, n_centers=64, latent=12, sigma=18.0):
+    """Integer-valued f32 vectors in [0,255] with low intrinsic dimension (mixture in a latent space)."""
+    rng = np.random.default_rng(seed)
+    A = rng.normal(0, 1, (latent, D)).astype(np.float32)
+    centers = rng.normal(0, 40, (n_centers, latent)).astype(np.float32)
+    which = rng.integers(0, n_centers, n)
+    z = centers[which] + rng.normal(0, 12, (n, latent)).astype(np.float32)
+    x = 110.0 + z @ A * 0.9 + rng.normal(0, sigma, (n, D)).astype(np.float32)
+    return np.clip(np.rint(x), 0, 255).astype(np.float32)
+
+
+def quick_codebooks(train, P, C1, C2, seed, iters=4):
+    """Fast Lloyd k-means (random init) producing cb1[C1][D], cb2[P][C1][C2][S]; any codebook is a valid tree."""
+    rng = np.random.default_rng(seed)
+    n, D = train.shape
+    S = D // P
+    cb1 = np.zeros((C1, D), np.float32)
+    cb2 = np.zeros((P, C1, C2, S), np.float32)
+
+    def lloyd(x, k):
+        k_eff = min(k, max(1, x.shape[0]))
+        cen = x[rng.choice(x.shape[0], k_eff, replace=False)].copy() if x.shape[0] else np.zeros((0, x.shape[1]), np.float32)
+        for _ in range(iters):
+            d = ((x[:, None, :] - cen[None]) ** 2).sum(-1)
+            a = d.argmin(1)
+            for c in range(k_eff):
+                m = a == c
+                if m.any():
+                    cen[c] = x[m].mean(0)
+        out = np.zeros((k, x.shape[1]), np.float32)
+        out[:k_eff] = cen
+        # distinct fillers for unused centroids (avoid exact duplicates unless a test wants them)
+        for c in range(k_eff, k):
+            out[c] = rng.uniform(0, 255, x.shape[1]).astype(np.float32)
+        a = ((x[:, None, :] - out[None]) ** 2).sum(-1).argmin(1) if x.shape[0] else np.zeros(0, np.int64)
+        return out, a
+
+    for p in range(P):
+        seg = train[:, p * S:(p + 1) * S]
+        cen, a = lloyd(seg, C1)
+        cb1[:, p * S:(p + 1) * S] = cen
+        for c in range(C1):
+            sub = seg[a == c]
+            cb2[p, c], _ = lloyd(sub, C2)
+    return cb1, cb2
+
+
+class Fixture:
+    """An oracle holding a small index plus everything needed to load the same index elsewhere."""
+
+    def __init__(self, D, P, C1, C2, W, LP, n_base, n_query, seed, heur_rows=4096, train=4000, data=None):
+        self.cfg = dict(D=D, P=P, C1=C1, C2=C2, W=W, LP=LP)
+        self.heur_rows = heur_rows
+        gen = data or sift_like
+        self.train = gen(train, D, seed + 1)
+        self.base = gen(n_base, D, seed + 2)
+        rng = np.random.default_rng(seed + 3)
+        pick = rng.integers(0, n_base, n_query)
+        self.queries = np.clip(np.rint(self.base[pick] + rng.normal(0, 6, (n_query, D))), 0, 255).astype(np.float32)
+        self.cb1, self.cb2 = quick_codebooks(self.train, P, C1, C2, seed + 4)
+        self.oracle = Oracle(D, P, C1, C2, W, LP, heur_keep=heur_rows)
+        self.oracle.set_codebooks(self.cb1, self.cb2)
+        self.oracle.insert(self.base)
+        self.bin_ids, self.bin_sizes, self.members = self.oracle.export_bins()
+        self.codes = self.oracle.export_codes()
+        self.heur = self.oracle.heuristic()
+
+    def hip_index(self, device=0, shard=None):
+        pkg = pqt_pkg()
+        c = self.cfg
+        idx = pkg.PqtIndex(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], device=device)
+        idx.set_codebooks(self.cb1, self.cb2)
+        idx.set_heuristic(self.heur)
+        if shard is None:
+            idx.set_bins(self.bin_ids, self.bin_sizes, self.members)
+        else:
+            idx.set_bins_shard(self.bin_ids, self.bin_sizes, self.members, shard[0], shard[1])
+        idx.set_lines(self.codes)
+        return idx
+
+
+_FIX = {}
+
+CONFIGS = {
+    # the reference tools' own default template parameters (cpu_version/tools/query.cpp:10-15)
+    "tools_default": dict(D=128, P=2, C1=16, C2=8, W=4, LP=32, n_base=20000, n_query=48, seed=11, heur_rows=1024),
+    # BASELINE cfg1/cfg2 shape (SIFT1M d=128 p=4 c1=32 c2=32 lineparts=16), W=2
+    "cfg2_small": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=20000, n_query=32, seed=22, heur_rows=4096),
+    # uint32 wrap-around of the bin id ((C1*C2)^P = 2^40) and aliased bins, small D for speed
+    "wrap": dict(D=32, P=4, C1=32, C2=32, W=1, LP=8, n_base=30000, n_query=32, seed=33, heur_rows=2048),
+    # odd sizes: LP not a multiple of 4 (scalar code reads), non-power-of-two everything
+    "odd": dict(D=24, P=2, C1=6, C2=4, W=3, LP=6, n_base=3000, n_query=32, seed=44, heur_rows=144),
+}
+
+
+def fixture(name):
+    if name not in _FIX:
+        _FIX[name] = Fixture(**CONFIGS[name])
+    return _FIX[name]

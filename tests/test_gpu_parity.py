@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact.  Tables, bin ids, candidate sequences, ADC distances and the sorted result lists must be
+identical (f32 compared as raw bits).  Order comparisons use the oracle in its reference-faithful mode
+(std::sort); when the engine reports exact float ties at a stage the oracle's stable mode is the canonical
+order (see DESIGN.md "ties").
+"""
+import numpy as np
+import pytest
+
+from common import CONFIGS, fixture, pqt_pkg
+
+pytestmark = pytest.mark.gpu
+
+BV_BB = {"tools_default": (2000, 500), "cfg2_small": (300, 500), "wrap": (100, 1000), "odd": (400, 144)}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def pair(request):
+    f = fixture(request.param)
+    idx = f.hip_index()
+    yield request.param, f, idx
+    idx.close()
+
+
+def test_library_loaded_and_device():
+    pkg = pqt_pkg()
+    assert pkg.lib().pqt_device_count() >= 1
+
+
+def test_triangle_known_answers_on_device():
+    """run.cu:33-104 -- the reference's only golden vectors, evaluated by a kernel."""
+    pkg = pqt_pkg()
+    a2 = np.array([1, 2, 2, 2, 2, 5], np.float32)
+    b2 = np.array([2, 2, 2, 5, 5, 2], np.float32)
+    c2 = np.array([1, 4, 2, 9, 1, 1], np.float32)
+    lam_exp = np.array([1, .5, .5, 2 / 3, 2, -1], np.float32)
+    d_exp = np.array([1, 1, 1.5, 1, 1, 1], np.float32)
+    _, ratio, _, _ = pkg.dev_triangle(a2, b2, c2, np.zeros(6, np.float32))
+    assert np.all(np.abs(ratio - lam_exp) < 1e-5)  # equal(): triangle.cuh:112 tolerance
+    dist, _, _, _ = pkg.dev_triangle(a2, b2, c2, ratio)
+    assert np.all(np.abs(dist - d_exp) < 1e-5)
+    # lambda codec sweep of run.cu:106-113 against the oracle's codec (bit exact)
+    from oracle.oracle import _lib
+    L = _lib()
+    f = (np.arange(-100, 100) / 10.0).astype(np.float32)
+    _, _, u16, rt = pkg.dev_triangle(f, f, f, f)
+    for i, x in enumerate(f):
+        assert int(u16[i]) == L.pqo_lambda_encode(float(x))
+        assert bits(rt[i:i + 1])[0] == bits(np.array([L.pqo_lambda_decode(int(u16[i]))], np.float32))[0]
+
+
+def test_coarse_table_bit_exact(pair):
+    _, f, idx = pair
+    assert np.array_equal(bits(idx.coarse()), bits(f.oracle.coarse()))
+
+
+def test_stage_tables_bit_exact(pair):
+    name, f, idx = pair
+    Bv, Bb = BV_BB[name]
+    idx.query(f.queries, Bv, Bb, 10)
+    st = idx.stats()
+    dbg = idx.debug_read(len(f.queries), cands=False)
+    o = f.oracle
+    for qi, q in enumerate(f.queries):
+        virt, _, _ = o.stage_l1(q)
+        assert np.array_equal(bits(dbg["l1virt"][qi]), bits(virt)), "L1virt differs q=%d" % qi
+        l1, l2, _, d2, order = o.stage_segments(q)
+        if st["ties_l1"] == 0 and st["ties_l2"] == 0:
+            for p in range(o.P):
+                srt = order[p]
+                assert np.array_equal(bits(dbg["seg_d2"][qi, p]), bits(d2[p][srt]))
+                assert np.array_equal(dbg["seg_bin"][qi, p], (l1[p][srt] * o.C2 + l2[p][srt]).astype(np.uint32))
+
+
+def _oracle_lists(f, q, Bv, Bb, stable):
+    o = f.oracle
+    o.set_sort_mode(1 if stable else 0)
+    try:
+        u_ids, u_d = o.query_unsorted(q, Bv, Bb)
+        s_ids, s_d = o.query(q, Bv, Bb)
+    finally:
+        o.set_sort_mode(0)
+    return u_ids, u_d, s_ids, s_d
+
+
+def test_candidates_and_full_sorted_list(pair):
+    """Candidate index sequence (visiting order), ADC distances, and the fully sorted list == oracle."""
+    name, f, idx = pair
+    Bv, Bb = BV_BB[name]
+    qn = len(f.queries)
+    kfull = 8192  # > 4096 -> full-sort path; larger than any candidate list of these fixtures
+    ids, dist, cnt = idx.query(f.queries, Bv, Bb, kfull)
+    st = idx.stats()
+    dbg = idx.debug_read(qn)
+    any_ties = st["ties_l1"] or st["ties_l2"] or st["ties_bins"]
+    total = 0
+    for qi, q in enumerate(f.queries):
+        u_ids, u_d, s_ids, s_d = _oracle_lists(f, q, Bv, Bb, stable=bool(any_ties))
+        n = int(cnt[qi])
+        total += n
+        assert n == len(u_ids), "candidate count differs q=%d: %d vs %d" % (qi, n, len(u_ids))
+        assert n <= kfull
+        assert np.array_equal(dbg["cand_idx"][qi, :n], u_ids), "candidate sequence differs q=%d" % qi
+        assert np.array_equal(bits(dbg["cand_dist"][qi, :n]), bits(u_d)), "ADC distances differ q=%d" % qi
+        # sorted list: distances must agree exactly; ids must agree wherever the distance is unique
+        assert np.array_equal(bits(dist[qi, :n]), bits(s_d))
+        if st["ties_final"] == 0 and not any_ties:
+            assert np.array_equal(ids[qi, :n], s_ids)
+        else:
+            so = f.oracle
+            so.set_sort_mode(1)
+            try:
+                st_ids, _ = so.query(q, Bv, Bb)
+            finally:
+                so.set_sort_mode(0)
+            assert np.array_equal(ids[qi, :n], st_ids)
+        assert np.all(ids[qi, n:] == 0xffffffff) and np.all(np.isinf(dist[qi, n:]))
+    assert st["candidates"] == total
+
+
+@pytest.mark.parametrize("k", [1, 10, 100, 1000])
+def test_topk_select_path(pair, k):
+    name, f, idx = pair
+    Bv, Bb = BV_BB[name]
+    ids, dist, cnt = idx.query(f.queries, Bv, Bb, k)
+    st = idx.stats()
+    stable = bool(st["ties_l1"] or st["ties_l2"] or st["ties_bins"] or st["ties_final"])
+    for qi, q in enumerate(f.queries):
+        f.oracle.set_sort_mode(1 if stable else 0)
+        try:
+            s_ids, s_d = f.oracle.query(q, Bv, Bb)
+        finally:
+            f.oracle.set_sort_mode(0)
+        assert int(cnt[qi]) == len(s_ids)
+        kk = min(k, len(s_ids))
+        assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk]))
+        # with ties beyond position k the select path must still return the stable-first ones
+        f.oracle.set_sort_mode(1)
+        try:
+            st_ids, _ = f.oracle.query(q, Bv, Bb)
+        finally:
+            f.oracle.set_sort_mode(0)
+        assert np.array_equal(ids[qi, :kk], st_ids[:kk])
+        assert np.all(ids[qi, kk:] == 0xffffffff)
+
+
+@pytest.mark.parametrize("bv,bb", [(0, 1), (0, 7), (1, 64), (10 ** 9, 64), (50, 0)])
+def test_edge_bounds(pair, bv, bb):
+    """Bv = 0 (first non-empty bin still taken: strict '>'), Bb = 1, Bb = 0, Bv beyond everything."""
+    name, f, idx = pair
+    bb = min(bb, len(f.heur))
+    bvq = min(bv, 2 ** 31)
+    qs = f.queries[:8]
+    ids, dist, cnt = idx.query(qs, bvq, bb, 6000)
+    for qi, q in enumerate(qs):
+        f.oracle.set_sort_mode(1)
+        try:
+            s_ids, s_d = f.oracle.query(q, bvq, bb)
+        finally:
+            f.oracle.set_sort_mode(0)
+        n = int(cnt[qi])
+        assert n == len(s_ids)
+        m = min(n, 6000)
+        assert np.array_equal(ids[qi, :m], s_ids[:m])
+        assert np.array_equal(bits(dist[qi, :m]), bits(s_d[:m]))
+
+
+def test_single_query_and_ragged_batches(pair):
+    name, f, idx = pair
+    Bv, Bb = BV_BB[name]
+    full_ids, full_d, full_c = idx.query(f.queries, Bv, Bb, 50)
+    for qn in (1, 3, 17):
+        ids, d, c = idx.query(f.queries[:qn], Bv, Bb, 50)
+        assert np.array_equal(ids, full_ids[:qn]) and np.array_equal(bits(d), bits(full_d[:qn])) and np.array_equal(c, full_c[:qn])
+
+
+def test_heuristic_built_by_library_matches_oracle(pair):
+    name, f, idx = pair
+    if f.oracle.max_multi_index > (1 << 22):
+        pytest.skip("full tuple space too large for a unit test")
+    rows = len(f.heur)
+    idx.build_heuristic(rows)
+    assert np.array_equal(idx.heuristic(rows), f.heur)
+    idx.set_heuristic(f.heur)
+
+
+def test_sharded_two_way_equals_unsharded(pair):
+    """Range-shard the database over two handles (same GPU), query each shard, merge: identical to unsharded."""
+    import torch
+    name, f, idx = pair
+    Bv, Bb = BV_BB[name]
+    k = 64
+    n = f.oracle.num_vectors
+    cut = n // 3
+    shards = [f.hip_index(shard=(0, cut)), f.hip_index(shard=(cut, n))]
+    try:
+        ref_ids, ref_d, ref_c = idx.query(f.queries, Bv, Bb, k)
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        I = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Dd = torch.empty((2, qn, k), dtype=torch.float32, device="cuda")
+        Pp = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Cc = torch.empty((2, qn), dtype=torch.int32, device="cuda")
+        for s, sh in enumerate(shards):
+            sh.query_shard_dev(q, Bv, Bb, k, I[s], Dd[s], Pp[s], Cc[s], sync=True)
+        oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)
+        got_ids = oI.cpu().numpy().view(np.uint32)
+        got_d = oD.cpu().numpy()
+        assert np.array_equal(Cc[0].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
+        assert np.array_equal(Cc[1].cpu().numpy().view(np.uint32), ref_c)
+        assert np.array_equal(got_ids, ref_ids)
+        assert np.array_equal(bits(got_d), bits(ref_d))
+    finally:
+        for sh in shards:
+            sh.close()
+
+
+def test_assign_encode_matches_oracle_insert(pair):
+    """Offline row: bin ids and 4-byte line codes of the database vectors, bit exact (insert/prepareReranking)."""
+    import torch
+    name, f, idx = pair
+    n = min(2000, f.base.shape[0])
+    x = torch.from_numpy(f.base[:n]).cuda()
+    ob = torch.empty(n, dtype=torch.int32, device="cuda")
+    oc = torch.empty((n, f.cfg["LP"]), dtype=torch.int32, device="cuda")
+    idx.assign_encode_dev(x, ob, oc)
+    torch.cuda.synchronize()
+    got_bins = ob.cpu().numpy().view(np.uint32)
+    got_codes = oc.cpu().numpy().view(np.uint32)
+    # oracle: bin of vector i from the exported bins
+    bin_of = np.zeros(f.oracle.num_vectors, np.uint32)
+    off = 0
+    for b, s in zip(f.bin_ids, f.bin_sizes):
+        bin_of[f.members[off:off + s]] = b
+        off += s
+    assert np.array_equal(got_bins, bin_of[:n])
+    assert np.array_equal(got_codes, f.codes[:n])
