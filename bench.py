@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""bench.py -- PQT query hot path on MI355X: queries/sec + recall, HBM roofline of the dominant kernel,
+CPU baseline beside it.
+
+One "step" = one pass of the whole hot path (distance tables -> traversal -> bin enumeration -> ADC line
+rerank -> top-k) over one batch of QN synthetic SIFT-shaped queries, inputs and outputs resident in HBM.
+
+    python bench.py                       # N=1, BASELINE.json configs[1] (SIFT1M shape, batch 10k)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU (--gpus N > 1): the database is range-sharded by vector id over the N ranks (each rank owns
+a slice of the bin/line store), every rank runs the traversal for the whole batch, reranks its own slice and the
+per-shard top-k lists are merged after ONE RCCL all-gather (SURVEY.md 8e / BASELINE.json north_star).  The
+database size is fixed as N grows => "scaling": "strong".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: "SIFT1M d=128, p=4, c1=32, c2=32 on 1xMI355X, batch=10k queries" (lineparts=16 per configs[0])
+    "sift1m": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=1_000_000, n_train=100_000, qn=10_000),
+    # small variant for quick checks (not a bench line)
+    "tiny": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=50_000, n_train=20_000, qn=1_000),
+}
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------
+# synthetic SIFT-shaped data (generated on the device; plumbing, not the product)
+# ------------------------------------------------------------------------------------------------------
+def sift_like(n, D, seed, dev, n_centers=4096, latent=24):
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC0DE00)  # the mixture itself is shared by train/base/query
+    A = torch.randn(latent, D, generator=g, device=dev)
+    centers = torch.randn(n_centers, latent, generator=g, device=dev) * 30.0
+    g.manual_seed(seed)
+    out = torch.empty((n, D), dtype=torch.float32, device=dev)
+    step = 1 << 18
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        which = torch.randint(0, n_centers, (m,), generator=g, device=dev)
+        z = centers[which] + torch.randn(m, latent, generator=g, device=dev) * 9.0
+        x = 100.0 + (z @ A) * 0.8 + torch.randn(m, D, generator=g, device=dev) * 10.0
+        out[s:s + m] = x.round().clamp_(0, 255)
+    return out
+
+
+def kmeans(x, k, iters, g):
+    n = x.shape[0]
+    if n == 0:
+        return torch.rand((k, x.shape[1]), device=x.device, generator=g) * 255.0
+    cen = x[torch.randperm(n, device=x.device, generator=g)[:k]].clone()
+    if cen.shape[0] < k:  # tiny cell: pad with jittered copies (distinct centroids, no exact duplicates)
+        extra = cen[torch.randint(0, cen.shape[0], (k - cen.shape[0],), device=x.device, generator=g)]
+        cen = torch.cat([cen, extra + torch.rand(extra.shape, device=x.device, generator=g) * 4.0 + 0.5])
+    for _ in range(iters):
+        a = torch.cdist(x, cen).argmin(1)
+        s = torch.zeros_like(cen).index_add_(0, a, x)
+        c = torch.zeros(k, device=x.device).index_add_(0, a, torch.ones(n, device=x.device))
+        cen = torch.where(c[:, None] > 0, s / c.clamp(min=1)[:, None], cen)
+    return cen
+
+
+def train_codebooks(train, P, C1, C2, seed):
+    dev = train.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    D = train.shape[1]
+    S = D // P
+    cb1 = torch.zeros((C1, D), device=dev)
+    cb2 = torch.zeros((P, C1, C2, S), device=dev)
+    for p in range(P):
+        seg = train[:, p * S:(p + 1) * S].contiguous()
+        cen = kmeans(seg, C1, 12, g)
+        cb1[:, p * S:(p + 1) * S] = cen
+        a = torch.cdist(seg, cen).argmin(1)
+        for c in range(C1):
+            cb2[p, c] = kmeans(seg[a == c], C2, 8, g)
+    return cb1.cpu().numpy(), cb2.cpu().numpy()
+
+
+def brute_force_gt(base, queries, k):
+    out = torch.empty((queries.shape[0], k), dtype=torch.int64, device=base.device)
+    bn = (base * base).sum(1)
+    for s in range(0, queries.shape[0], 2048):
+        q = queries[s:s + 2048]
+        d = bn[None, :] - 2.0 * (q @ base.T)
+        out[s:s + 2048] = d.topk(k, dim=1, largest=False).indices
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+def build_index(pkg, w, dev_index, seed_base=0xC0DE02, shard=None):
+    """Synthesise the database and load it into a PqtIndex.  Returns (index, base (device), meta)."""
+    dev = torch.device("cuda", dev_index)
+    D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
+    t0 = time.time()
+    train = sift_like(w["n_train"], D, 0xC0DE01, dev)
+    base = sift_like(w["n_base"], D, seed_base, dev)
+    cb1, cb2 = train_codebooks(train, P, C1, C2, 0xC0DE04)
+    del train
+    t1 = time.time()
+    idx = pkg.PqtIndex(D, P, C1, C2, W, LP, device=dev_index)
+    idx.set_codebooks(cb1, cb2)
+    n = base.shape[0]
+    bins = torch.empty(n, dtype=torch.int32, device=dev)
+    codes = torch.empty((n, LP), dtype=torch.int32, device=dev)
+    idx.assign_encode_dev(base, bins, codes)  # product kernel: insert = id() + prepareReranking
+    torch.cuda.synchronize(dev)
+    t2 = time.time()
+    # CSR by bin id (vector ids ascending inside a bin = the reference's insertion order)
+    key = (bins.to(torch.int64) & 0xffffffff)
+    order = torch.argsort(key, stable=True)
+    ukeys, counts = torch.unique_consecutive(key[order], return_counts=True)
+    bin_ids = ukeys.cpu().numpy().astype(np.uint32)
+    sizes = counts.cpu().numpy().astype(np.uint32)
+    members = order.cpu().numpy().astype(np.uint32)
+    if shard is None:
+        idx.set_bins(bin_ids, sizes, members)
+        idx.set_lines_dev(codes, 0)
+    else:
+        lo, hi = shard
+        idx.set_bins_shard(bin_ids, sizes, members, lo, hi)
+        local = codes[lo:hi].clone()
+        del codes
+        idx.set_lines_dev(local, lo)
+    t3 = time.time()
+    meta = dict(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), t_data=t1 - t0, t_encode=t2 - t1, t_csr=t3 - t2,
+                cb1=cb1, cb2=cb2, bin_ids=bin_ids, sizes=sizes, members=members)
+    return idx, base, meta
+
+
+def recall_at(ids, gt0, r):
+    r = min(r, ids.shape[1])
+    return float((ids[:, :r] == gt0[:, None]).any(1).float().mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sift1m", choices=list(WORKLOADS))
+    ap.add_argument("--bv", type=int, default=20000, help="boundVectors (reference default: query(20000, 500, ...))")
+    ap.add_argument("--bb", type=int, default=500, help="boundBins")
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pkg = importlib.import_module("product-quantization-tree_amd")
+    pkg.lib()  # fails loudly if the HIP library is missing
+    w = WORKLOADS[args.workload]
+    n = w["n_base"]
+    shard = None
+    if world > 1:
+        lo = rank * n // world
+        hi = (rank + 1) * n // world
+        shard = (lo, hi)
+    idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
+    t0 = time.time()
+    idx.build_heuristic(max(args.bb, 1))
+    log("[bench] index: N=%d bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
+        (n, meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"], meta["t_csr"], time.time() - t0))
+
+    # queries = perturbed base rows (seed 0xC0DE03), ground truth by exact brute force
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC0DE03)
+    qn = w["qn"]
+    pick = torch.randint(0, n, (qn,), generator=g, device=dev)
+    queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
+    gt = brute_force_gt(base, queries, 1)[:, 0]
+    del base
+    torch.cuda.empty_cache()
+
+    k = args.k
+    out_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if world > 1:
+        sh_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
+        sh_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
+        sh_pos = torch.empty((qn, k), dtype=torch.int32, device=dev)
+        all_idx = torch.empty((world, qn, k), dtype=torch.int32, device=dev)
+        all_dist = torch.empty((world, qn, k), dtype=torch.float32, device=dev)
+        all_pos = torch.empty((world, qn, k), dtype=torch.int32, device=dev)
+
+    def step():
+        if world == 1:
+            idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
+        else:
+            idx.query_shard_dev(queries, args.bv, args.bb, k, sh_idx, sh_dist, sh_pos, out_cnt, stream=stream)
+            # one RCCL all-gather of the per-shard top-k (three tensors coalesced by the process group)
+            dist.all_gather_into_tensor(all_idx, sh_idx)
+            dist.all_gather_into_tensor(all_dist, sh_dist)
+            dist.all_gather_into_tensor(all_pos, sh_pos)
+            idx.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage = dict(tables=0.0, bins=0.0, rerank=0.0, select=0.0)
+    rerank_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-stage device times of the last timed step (HIP events on the stream the kernels ran on)
+    st = idx.stats()
+    for kname in stage:
+        stage[kname] = st["ms_" + kname]
+    # live per-launch duration of the dominant kernel: re-run K steps reading the events each time (untimed region)
+    for _ in range(min(args.steps, 10)):
+        step()
+        torch.cuda.synchronize(dev)
+        rerank_ms.extend(idx.rerank_launch_ms().tolist())
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    ids_t = out_idx.to(torch.int64) & 0xffffffff
+    r1, r10, r100 = recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100)
+    ncand_mean = float(out_cnt.to(torch.int64).float().mean())
+    cand_local = st["candidates"]  # local candidates reranked on this rank in the last step
+    bins_visited = st["bins_visited"] / max(1, st["queries"])
+
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = qn * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (ADC line rerank, stage a7) ------------------------------------
+    # algorithmic bytes per launch = sum over queries of: LP*4 B code row + 4 B id read + 4 B distance write per
+    # candidate, + the query's L1virt table (LP*C1*4 B) staged to LDS.  (DESIGN.md "bytes")
+    LP, C1 = w["LP"], w["C1"]
+    rr_bytes = cand_local * (4 * LP + 8) + qn * LP * C1 * 4
+    rr_ms = float(np.mean(rerank_ms)) if rerank_ms else float("nan")
+    rr_gbs = rr_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
+    # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k
+    path_bytes_q = 4 * w["D"] + 8 * bins_visited + 4 * ncand_mean + 4 * LP * ncand_mean + 8 * k
+    dominant = max(stage, key=stage.get)
+
+    out = {
+        "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
+        "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "SIFT1M-shape synthetic: N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
+                               "query(boundVectors=%d, boundBins=%d), k=%d" %
+                               (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
+                   "parallelism": "1 GPU" if world == 1 else "db range-sharded x%d + RCCL all-gather top-k" % world,
+                   "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
+                   "mean_bins_visited": bins_visited, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
+                   "algorithmic_bytes_per_query": path_bytes_q,
+                   "path_GBps": path_bytes_q * qps / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qps / 1e9 / HBM_PEAK_GBS,
+                   "stage_ms": stage, "dominant_stage_by_time": dominant},
+        "roofline": {"bound": "hbm", "kernel": "pqt_k_rerank", "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": rr_ms,
+                     "algorithmic_bytes_per_launch": rr_bytes},
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
+    if world == 1 and not args.no_cpu:
+        from oracle import Oracle
+        o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=1)
+        o.set_heuristic(idx.heuristic(max(args.bb, 1)))
+        o.set_codebooks(meta["cb1"], meta["cb2"])
+        o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
+        codes_host = idx._keep[0].cpu().numpy().view(np.uint32)
+        o.import_codes(codes_host)
+        qh = queries.cpu().numpy()
+        cores = o.max_threads()
+        # calibrate on 64 queries, then size the sample to the budget
+        t = time.perf_counter()
+        o.query_batch(qh[:64], args.bv, args.bb, k, nthreads=cores)
+        per_q = (time.perf_counter() - t) / 64
+        sample = int(max(64, min(qn, args.cpu_seconds / max(per_q, 1e-9))))
+        t = time.perf_counter()
+        ci, cd, cc = o.query_batch(qh[:sample], args.bv, args.bb, k, nthreads=cores)
+        cpu_t = time.perf_counter() - t
+        t = time.perf_counter()
+        s1 = max(16, min(sample, int(3.0 / max(per_q * cores, 1e-9))))
+        o.query_batch(qh[:s1], args.bv, args.bb, k, nthreads=1)
+        cpu1_t = time.perf_counter() - t
+        # parity of the benchmark output itself on the sample (identical index sets)
+        gi = out_idx[:sample].cpu().numpy().view(np.uint32)
+        same = float(np.mean([np.array_equal(np.sort(gi[i]), np.sort(ci[i])) for i in range(sample)]))
+        out["cpu_baseline"] = {"value": sample / cpu_t, "unit": "queries/sec", "cores": cores, "kind": "port",
+                               "sample": "first %d of the %d bench queries, same index, all host threads (OpenMP over queries)"
+                                         % (sample, qn),
+                               "single_thread_qps": s1 / cpu1_t, "single_thread_ms_per_query": cpu1_t / s1 * 1e3,
+                               "topk_sets_identical_frac": same}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
