@@ -46,7 +46,11 @@ def log(*a):
 # ------------------------------------------------------------------------------------------------------
 # synthetic SIFT-shaped data (generated on the device; plumbing, not the product)
 # ------------------------------------------------------------------------------------------------------
-def sift_like(n, D, seed, dev, n_centers=4096, latent=24):
+GEN = dict(n_centers=4096, latent=24, lat_noise=4.0, iso_noise=6.0)
+
+
+def sift_like(n, D, seed, dev):
+    n_centers, latent = GEN['n_centers'], GEN['latent']
     g = torch.Generator(device=dev)
     g.manual_seed(0xC0DE00)  # the mixture itself is shared by train/base/query
     A = torch.randn(latent, D, generator=g, device=dev)
@@ -57,8 +61,8 @@ def sift_like(n, D, seed, dev, n_centers=4096, latent=24):
     for s in range(0, n, step):
         m = min(step, n - s)
         which = torch.randint(0, n_centers, (m,), generator=g, device=dev)
-        z = centers[which] + torch.randn(m, latent, generator=g, device=dev) * 9.0
-        x = 100.0 + (z @ A) * 0.8 + torch.randn(m, D, generator=g, device=dev) * 10.0
+        z = centers[which] + torch.randn(m, latent, generator=g, device=dev) * GEN['lat_noise']
+        x = 100.0 + (z @ A) * 0.8 + torch.randn(m, D, generator=g, device=dev) * GEN['iso_noise']
         out[s:s + m] = x.round().clamp_(0, 255)
     return out
 
@@ -164,6 +168,10 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
+    ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
+    ap.add_argument("--centers", type=int, default=GEN["n_centers"])
+    ap.add_argument("--query-mode", default="fresh", choices=["fresh", "perturbed"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,6 +188,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers)
     pkg = importlib.import_module("product-quantization-tree_amd")
     pkg.lib()  # fails loudly if the HIP library is missing
     w = WORKLOADS[args.workload]
@@ -199,8 +208,11 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(0xC0DE03)
     qn = w["qn"]
-    pick = torch.randint(0, n, (qn,), generator=g, device=dev)
-    queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
+    if args.query_mode == "perturbed":
+        pick = torch.randint(0, n, (qn,), generator=g, device=dev)
+        queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
+    else:  # fresh draws from the same mixture (like SIFT's separate query set)
+        queries = sift_like(qn, w["D"], 0xC0DE03, dev)
     gt = brute_force_gt(base, queries, 1)[:, 0]
     del base
     torch.cuda.empty_cache()

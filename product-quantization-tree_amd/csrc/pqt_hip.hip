@@ -51,13 +51,13 @@ struct pqt_index {
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
-  uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr;
+  uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // 8
   uint64_t stride = 0;
   // results of the last call
   pqt_stats stats{};
-  uint32_t lastQn = 0;
+  uint32_t lastQn = 0; uint32_t lastHe = 0;
   hipEvent_t ev[kMaxChunks][EV_COUNT]{}; int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
 };
@@ -86,6 +86,7 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_segBin, (size_t)qn * d.P * d.WC))) return rc;
   if ((rc = devAlloc(&idx->d_nCand, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_nLocal, (size_t)qn))) return rc;
+  if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
   idx->qCap = qn;
   return PQT_OK;
 }
@@ -220,13 +221,13 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (idx->sharded)
       hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                          idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
-                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, stride,
-                         idx->d_counters);
+                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                         stride, idx->d_counters);
     else
       hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                          idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
-                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, stride,
-                         idx->d_counters);
+                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                         stride, idx->d_counters);
     HIPCHK(hipEventRecord(idx->ev[c][EV_BINS], st));
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
@@ -258,7 +259,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   }
   if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
-  idx->lastQn = qn;
+  idx->lastQn = qn; idx->lastHe = He;
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
 }
@@ -318,7 +319,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_coarse, idx->d_heur, idx->d_table, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->ev[c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -600,7 +601,17 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   HIPCHK(hipMemcpy(c, idx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
   pqt_stats s{};
   s.queries = idx->lastQn; s.ties_l1 = c[0]; s.ties_l2 = c[1]; s.ties_bins = c[2]; s.ties_final = c[3];
-  s.candidates = c[4]; s.bins_visited = c[5]; s.bins_nonempty = c[6]; s.max_bin = idx->maxBin;
+  s.max_bin = idx->maxBin;
+  {
+    std::vector<uint32_t> nl(idx->lastQn), ni(idx->lastQn);
+    if (idx->lastQn) {
+      HIPCHK(hipMemcpy(nl.data(), idx->d_nLocal, (size_t)idx->lastQn * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ni.data(), idx->d_nIncl, (size_t)idx->lastQn * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t v : nl) s.candidates += v;
+    for (uint32_t v : ni) s.bins_nonempty += v;
+    s.bins_visited = (uint64_t)idx->lastHe * idx->lastQn;
+  }
   for (int ch = 0; ch < idx->nChunks; ++ch) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BEGIN], idx->ev[ch][EV_TABLES]) == hipSuccess) s.ms_tables += ms;

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     uint32_t He, uint32_t HeP2, uint32_t Bv, PqtDevParams prm, const PqtBinEntry* __restrict__ table,
     const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids,
     uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos, uint32_t* __restrict__ nCand,
-    uint32_t* __restrict__ nLocal, uint64_t stride, unsigned long long* __restrict__ counters) {
+    uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
+    unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t P = prm.P, WC = prm.WC;
   uint64_t* sKey = (uint64_t*)smem_raw;                 // HeP2
@@ -185,11 +186,10 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
   // exclusive scan of the global populations in visiting order; each thread owns a contiguous chunk
   const uint32_t per = (He + PQT_BLOCK - 1) / PQT_BLOCK;
   const uint32_t i0 = tid * per, i1 = (i0 + per < He) ? i0 + per : He;
-  uint32_t loc = 0, locL = 0, ties = 0;
+  uint32_t loc = 0, ties = 0;
   for (uint32_t i = i0; i < i1; ++i) {
     const uint32_t h = (uint32_t)sKey[i];
     loc += sG[h];
-    if (SHARDED) locL += sLc[h];
     if (i + 1 < He && (uint32_t)(sKey[i] >> 32) == (uint32_t)(sKey[i + 1] >> 32)) ++ties;
   }
   if (ties) atomicAdd(&counters[2], (unsigned long long)ties);
@@ -240,12 +240,10 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
   }
   __syncthreads();
   const uint32_t nLoc = SHARDED ? sMisc[2] : nGlobal;
-  if (tid == 0) {
+  if (tid == 0) {  // per-query outputs only: shared counters would serialise 10^4 workgroups on one L2 line
     nCand[q] = nGlobal;
     nLocal[q] = nLoc;
-    atomicAdd(&counters[4], (unsigned long long)nLoc);
-    atomicAdd(&counters[5], (unsigned long long)He);
-    atomicAdd(&counters[6], (unsigned long long)nb);
+    nIncl[q] = nb;
   }
   // a6 gather: candidate j lives in the last included bin whose list start is <= j
   for (uint32_t j = tid; j < nLoc; j += PQT_BLOCK) {
