@@ -195,9 +195,7 @@ def main():
     n = w["n_base"]
     shard = None
     if world > 1:
-        lo = rank * n // world
-        hi = (rank + 1) * n // world
-        shard = (lo, hi)
+        shard = importlib.import_module("product-quantization-tree_amd.sharding").shard_range(rank, world, n)
     idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
     t0 = time.time()
     idx.build_heuristic(max(args.bb, 1))
@@ -222,24 +220,20 @@ def main():
     out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
     out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
     if world > 1:
-        sh_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
-        sh_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
-        sh_pos = torch.empty((qn, k), dtype=torch.int32, device=dev)
-        all_idx = torch.empty((world, qn, k), dtype=torch.int32, device=dev)
-        all_dist = torch.empty((world, qn, k), dtype=torch.float32, device=dev)
-        all_pos = torch.empty((world, qn, k), dtype=torch.int32, device=dev)
+        sbuf = sharding.ShardBuffers(world, qn, k, dev)
+        engine = sharding.PqtShardEngine(idx)
 
     def step():
         if world == 1:
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
         else:
-            idx.query_shard_dev(queries, args.bv, args.bb, k, sh_idx, sh_dist, sh_pos, out_cnt, stream=stream)
-            # one RCCL all-gather of the per-shard top-k (three tensors coalesced by the process group)
-            dist.all_gather_into_tensor(all_idx, sh_idx)
-            dist.all_gather_into_tensor(all_dist, sh_dist)
-            dist.all_gather_into_tensor(all_pos, sh_pos)
-            idx.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=stream)
+            # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
+            oi, od, oc = sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf)
+            out_idx.copy_(oi)
+            out_dist.copy_(od)
+            out_cnt.copy_(oc)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,71 @@
+"""Multi-GPU driver logic of the range-sharded query: pure host code, no compute.
+
+One process per GPU.  Rank r owns the database slice with vector ids in shard_range(r, world, N) -- its rows of the
+line store and its members of every bin -- while the tree, the heuristic prefix and every bin's GLOBAL population are
+replicated, so all ranks apply the identical cut.  Each rank runs the traversal for the whole query batch, reranks
+its own slice, and the per-shard top-k lists (id, distance, global visiting position) are exchanged with ONE
+all-gather over RCCL/xGMI and merged by (distance, position) -- exactly the order of the unsharded engine.
+
+The functions take an `engine` exposing
+    query_shard(q, bv, bb, k, out_idx, out_dist, out_pos, out_count)
+    merge_topk(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist)
+so the same code drives the HIP library (PqtShardEngine below) and, in the CPU test-suite, a stand-in over gloo.
+"""
+import torch
+
+
+def shard_range(rank, world, n):
+    """Half-open id range [lo, hi) of rank `rank` (contiguous, ordered by rank, covers [0, n))."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+class ShardBuffers:
+    def __init__(self, world, qn, k, device):
+        i32, f32 = torch.int32, torch.float32
+        self.sh_idx = torch.empty((qn, k), dtype=i32, device=device)
+        self.sh_dist = torch.empty((qn, k), dtype=f32, device=device)
+        self.sh_pos = torch.empty((qn, k), dtype=i32, device=device)
+        self.count = torch.empty(qn, dtype=i32, device=device)
+        # one buffer for the single collective: [world][3][qn][k] 32-bit words (idx | dist bits | pos)
+        self.pack = torch.empty((3, qn, k), dtype=i32, device=device)
+        self.gathered = torch.empty((world, 3, qn, k), dtype=i32, device=device)
+        self.all_idx = torch.empty((world, qn, k), dtype=i32, device=device)
+        self.all_dist = torch.empty((world, qn, k), dtype=f32, device=device)
+        self.all_pos = torch.empty((world, qn, k), dtype=i32, device=device)
+        self.out_idx = torch.empty((qn, k), dtype=i32, device=device)
+        self.out_dist = torch.empty((qn, k), dtype=f32, device=device)
+
+
+def sharded_query(engine, dist, world, q, bv, bb, k, buf):
+    """One step of the sharded hot path.  Returns (out_idx, out_dist, count) views into `buf`."""
+    qn = q.shape[0]
+    engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
+    if world == 1:
+        engine.merge_topk(1, qn, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.out_idx, buf.out_dist)
+        return buf.out_idx, buf.out_dist, buf.count
+    buf.pack[0].copy_(buf.sh_idx)
+    buf.pack[1].copy_(buf.sh_dist.view(torch.int32))
+    buf.pack[2].copy_(buf.sh_pos)
+    # the one exchange step of the path (output viewed as the dim-0 concatenation every backend accepts)
+    dist.all_gather_into_tensor(buf.gathered.view(world * 3, qn, k), buf.pack)
+    buf.all_idx.copy_(buf.gathered[:, 0])
+    buf.all_dist.copy_(buf.gathered[:, 1].view(torch.float32))
+    buf.all_pos.copy_(buf.gathered[:, 2])
+    engine.merge_topk(world, qn, k, buf.all_idx, buf.all_dist, buf.all_pos, buf.out_idx, buf.out_dist)
+    return buf.out_idx, buf.out_dist, buf.count
+
+
+class PqtShardEngine:
+    """Adapter of a sharded PqtIndex (HIP) to the engine protocol; enqueues on the current torch stream."""
+
+    def __init__(self, index):
+        self.index = index
+
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def query_shard(self, q, bv, bb, k, out_idx, out_dist, out_pos, out_count):
+        self.index.query_shard_dev(q, bv, bb, k, out_idx, out_dist, out_pos, out_count, stream=self._stream())
+
+    def merge_topk(self, world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist):
+        self.index.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=self._stream())

@@ -1,0 +1,225 @@
+"""CPU tests: the oracle against every golden vector that pins it, file formats, and restatement invariants."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from common import fixture, Fixture
+from oracle import Oracle, ref_helper, ref_triangle
+from oracle.oracle import _lib
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_run_cu_known_answers():
+    """run.cu:33-104: project/dist known answers with the reference's tolerance equal(.,1e-5) (triangle.cuh:112)."""
+    k = np.load(os.path.join(G, "run_cu_known.npz"))
+    L = _lib()
+    eps = float(k["eps"][0])
+    for a2, b2, c2, lam, d2 in zip(k["a2"], k["b2"], k["c2"], k["lam"], k["d2"]):
+        l = L.pqo_calc_ratio(float(a2), float(b2), float(c2))
+        assert abs(l - lam) < eps
+        assert abs(L.pqo_extract_distance(float(a2), float(b2), float(c2), l) - d2) < eps
+    # lambda sweep of run.cu:106-113: codec round trip error < one quantisation step inside [-4,4), clamps outside
+    for f in k["sweep"]:
+        u = L.pqo_lambda_encode(float(f))
+        r = L.pqo_lambda_decode(u)
+        if -4 <= f < 4:
+            assert 0 <= f - r < 8.0 / 65536 + 1e-6
+        elif f >= 4:
+            assert u == 65535
+        else:
+            assert u == 0
+
+
+def test_oracle_line_math_matches_genuine_reference_functions():
+    """Golden outputs of cpu_version/helper.hpp and pqt/triangle.cuh (tests/golden/make_golden.py) -- bit exact."""
+    g = np.load(os.path.join(G, "ref_line_math.npz"))
+    L = _lib()
+    a, b, c, lam = g["a"], g["b"], g["c"], g["lam"]
+    ed = np.array([L.pqo_extract_distance(float(x), float(y), float(z), float(l)) for x, y, z, l in zip(a, b, c, lam)], np.float32)
+    assert np.array_equal(bits(ed), bits(g["extract_distance"]))
+    assert np.array_equal(bits(ed), bits(g["tri_dist"]))  # CPU and CUDA headers agree on the formula
+    cr = np.array([L.pqo_calc_ratio(float(x), float(y), float(z)) for x, y, z in zip(a, b, c)], np.float32)
+    assert np.array_equal(bits(cr), bits(g["calc_ratio"]))
+    assert np.array_equal(bits(cr), bits(g["tri_project"]))
+    us = np.array([L.pqo_lambda_encode(float(l)) for l in lam], np.uint16)
+    assert np.array_equal(us, g["to_ushort"]) and np.array_equal(us, g["to_ushort_triangle"])
+    packed = np.array([L.pqo_code_pack(int(x), int(y), float(l)) for x, y, l in zip(g["pa"], g["pb"], lam)], np.uint32)
+    assert np.array_equal(packed, g["packed"])
+    assert np.array_equal(packed & 0xff, g["unpack_a"]) and np.array_equal((packed >> 8) & 0xff, g["unpack_b"])
+    dec = np.array([L.pqo_lambda_decode(int(u)) for u in range(65536)], np.float32)
+    assert np.array_equal(bits(dec), bits(g["decode_all_u16"]))
+    assert np.array_equal(bits(dec[packed >> 16]), bits(g["unpack_lambda"]))
+    for bi, base in enumerate(g["pow_bases"]):
+        for e in range(9):
+            assert L.pqo_upow(int(base), e) == int(g["pow_table"][bi, e])
+    assert int(g["sizeof_code"][0]) == 4
+
+
+def test_live_reference_functions_when_built():
+    """When oracle/_ref is present (built from /root/reference), compare live on fresh random inputs."""
+    H, T = ref_helper(), ref_triangle()
+    if H is None or T is None:
+        pytest.skip("oracle/_ref not built here")
+    L = _lib()
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        a, b, c = (float(np.float32(rng.uniform(0, 1e5))) for _ in range(3))
+        l = float(np.float32(rng.uniform(-6, 6)))
+        assert bits(np.float32(L.pqo_extract_distance(a, b, c, l))) == bits(np.float32(H.ref_extract_distance(a, b, c, l)))
+        assert bits(np.float32(L.pqo_calc_ratio(a, b, c + 1e-3))) == bits(np.float32(H.ref_calc_ratio(a, b, c + 1e-3)))
+        assert L.pqo_lambda_encode(l) == H.ref_to_ushort(l) == T.reftri_to_ushort(l)
+        assert bits(np.float32(T.reftri_dist(a, b, c, l))) == bits(np.float32(L.pqo_extract_distance(a, b, c, l)))
+
+
+def test_oracle_regression_fixture():
+    g = np.load(os.path.join(G, "oracle_small.npz"))
+    D, P, C1, C2, W, LP = (int(x) for x in g["cfg"])
+    o = Oracle(D, P, C1, C2, W, LP, heur_keep=64)
+    o.set_codebooks(g["cb1"], g["cb2"])
+    assert np.array_equal(o.heuristic(), g["heur"])
+    assert np.array_equal(bits(o.coarse()), bits(g["coarse"]))
+    o.insert(g["base"])
+    ids, sizes, members = o.export_bins()
+    assert np.array_equal(ids, g["bin_ids"]) and np.array_equal(sizes, g["bin_sizes"]) and np.array_equal(members, g["members"])
+    assert np.array_equal(o.export_codes(), g["codes"])
+    bv, bb = (int(x) for x in g["bv_bb"])
+    off = 0
+    for qi, q in enumerate(g["queries"]):
+        i, d = o.query(q, bv, bb)
+        n = int(g["n_each"][qi])
+        assert len(i) == n
+        assert np.array_equal(i, g["ids"][off:off + n]) and np.array_equal(bits(d), bits(g["dist"][off:off + n]))
+        off += n
+
+
+def test_heuristic_order_and_prefix():
+    """prepareHeuristic (treequantizer.hpp:75-127): tuples sorted by squared norm; the comment's example prefix."""
+    o = Oracle(8, 2, 4, 5, 2, 2, heur_keep=100)  # base 10, P=2 -> 100 tuples, like the (9,2) example in the source comment
+    h = o.heuristic()
+    assert h.shape == (100, 2)
+    n = (h.astype(np.int64) ** 2).sum(1)
+    assert np.all(np.diff(n) >= 0)
+    assert sorted(map(tuple, h.tolist())) == sorted((a, b) for a in range(10) for b in range(10))
+    assert h[0].tolist() == [0, 0] and h[-1].tolist() == [9, 9]
+    assert o.max_multi_index == 100
+
+
+def test_uint32_wraparound_of_bin_ids():
+    """(C1*C2)^p wraps mod 2^32 exactly like pow<uint> (treequantizer.hpp:45-49, matlab/readme.md:26)."""
+    f = fixture("wrap")
+    L = _lib()
+    assert L.pqo_upow(1024, 3) == (1024 ** 3) % 2 ** 32 and L.pqo_upow(1024, 4) == 0
+    cfg = f.cfg
+    powers = [(cfg["C1"] * cfg["C2"]) ** p % 2 ** 32 for p in range(cfg["P"])]
+    q = f.base[7]
+    virt, l1, order = f.oracle.stage_l1(q)
+    S = cfg["D"] // cfg["P"]
+    want = 0
+    for p in range(cfg["P"]):
+        c = int(order[p, 0])
+        d = ((q[p * S:(p + 1) * S][None] - f.cb2[p, c]) ** 2).sum(1)
+        want = (want + (c * cfg["C2"] + int(d.argmin())) * powers[p]) % 2 ** 32
+    assert f.oracle.bin_id(q) == want
+
+
+def test_tree_and_bins_file_formats(tmp_path):
+    """.tree: 5 x u32 (D,C1,C2,P,W) + cb1 + cb2 (treequantizer.hpp:699-737); .bins: nbins, {id,n,members}, nvec, LP, codes (:745-774)."""
+    f = fixture("odd")
+    o = f.oracle
+    tp, bp = str(tmp_path / "t.tree"), str(tmp_path / "t.bins")
+    o.save_tree(tp)
+    o.save_bins(bp)
+    raw = open(tp, "rb").read()
+    c = f.cfg
+    assert struct.unpack("<5I", raw[:20]) == (c["D"], c["C1"], c["C2"], c["P"], c["W"])
+    assert len(raw) == 20 + 4 * (c["C1"] * c["D"] + c["C1"] * c["C2"] * c["D"])
+    assert np.array_equal(np.frombuffer(raw[20:20 + 4 * c["C1"] * c["D"]], np.float32), f.cb1.ravel())
+    assert np.array_equal(np.frombuffer(raw[20 + 4 * c["C1"] * c["D"]:], np.float32), f.cb2.ravel())
+    rawb = open(bp, "rb").read()
+    nb = struct.unpack("<I", rawb[:4])[0]
+    assert nb == o.num_bins
+    assert len(rawb) == 4 + 8 * nb + 4 * o.num_vectors + 8 + 4 * o.num_vectors * c["LP"]
+    o2 = Oracle(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], heur_keep=f.heur_rows)
+    o2.load_tree(tp)
+    o2.load_bins(bp)
+    assert np.array_equal(o2.export_codes(), f.codes)
+    for q in f.queries[:8]:
+        i1, d1 = o.query(q, 300, 100)
+        i2, d2 = o2.query(q, 300, 100)
+        assert np.array_equal(i1, i2) and np.array_equal(bits(d1), bits(d2))
+    o3 = Oracle(c["D"], c["P"], c["C1"] , c["C2"], c["W"], c["LP"] , heur_keep=4)
+    with pytest.raises(RuntimeError):
+        o3.load_tree(str(tmp_path / "missing.tree"))
+
+
+def test_cut_rule_finish_the_bin_then_stop():
+    """rerankVectors (treequantizer.hpp:450-477): whole bins are taken; stop after the bin in which count > Bv."""
+    f = fixture("tools_default")
+    o = f.oracle
+    size_of = dict(zip(f.bin_ids.tolist(), f.bin_sizes.tolist()))
+    for q in f.queries[:12]:
+        for bv in (0, 1, 100, 1500):
+            bin_ids, dist, seq = o.stage_bins(q, 500)
+            n = 0
+            for s in seq:
+                n += size_of.get(int(bin_ids[s]), 0)
+                if n > bv:
+                    break
+            ids, _ = o.query_unsorted(q, bv, 500)
+            assert len(ids) == n
+
+
+@pytest.mark.parametrize("name", ["tools_default", "cfg2_small", "wrap", "odd"])
+def test_std_sort_and_stable_sort_agree_without_ties(name):
+    """The reference's std::sort order is unique unless keys tie; fixtures are tie-free -> both oracle modes agree."""
+    f = fixture(name)
+    for q in f.queries[:8]:
+        f.oracle.set_sort_mode(0)
+        a = f.oracle.query(q, 500, min(500, len(f.heur)))
+        f.oracle.set_sort_mode(1)
+        b = f.oracle.query(q, 500, min(500, len(f.heur)))
+        f.oracle.set_sort_mode(0)
+        uniq = len(np.unique(a[1])) == len(a[1])
+        assert np.array_equal(bits(a[1]), bits(b[1]))
+        if uniq:
+            assert np.array_equal(a[0], b[0])
+
+
+def test_query_batch_matches_single_queries():
+    f = fixture("odd")
+    ids, dist, cnt = f.oracle.query_batch(f.queries, 200, 100, 16, nthreads=2)
+    for qi, q in enumerate(f.queries):
+        i, d = f.oracle.query(q, 200, 100)
+        k = min(16, len(i))
+        assert cnt[qi] == len(i)
+        assert np.array_equal(ids[qi, :k], i[:k]) and np.array_equal(bits(dist[qi, :k]), bits(d[:k]))
+
+
+def test_train_restatement_smoke():
+    """generate() (treequantizer.hpp:155-177): k-means by splitting produces a usable tree (self-retrieval)."""
+    rng = np.random.default_rng(3)
+    data = np.rint(rng.uniform(0, 255, (600, 16))).astype(np.float32)
+    o = Oracle(16, 2, 4, 2, 2, 4, heur_keep=16)
+    o.train(data)
+    cb1, cb2 = o.codebooks()
+    assert np.isfinite(cb1).all() and np.isfinite(cb2).all()
+    o.insert(data)
+    hit = 0
+    for i in range(20):
+        ids, _ = o.query(data[i], 600, 16)
+        hit += int(i in ids[:50])
+    assert hit >= 15
+
+
+def test_invalid_parameters_rejected():
+    with pytest.raises(ValueError):
+        Oracle(128, 3, 16, 8, 4, 32)  # D % P != 0 (static_assert treequantizer.hpp:23)
+    with pytest.raises(ValueError):
+        Oracle(128, 2, 4, 8, 5, 32)   # W > C1 (:25)
