@@ -1,0 +1,246 @@
+// pqt/PerturbationProTree.cpp -- the reference's class surface implemented over the C-ABI (see the header).
+#include "PerturbationProTree.hh"
+
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+#include <algorithm>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+
+namespace pqt {
+
+ProQuantization::ProQuantization(uint _dim, uint _p) : d_dim(_dim), d_p(_p), d_vl(_p ? _dim / _p : 0), d_nClusters(0) {}
+ProQuantization::~ProQuantization() {}
+
+ProTree::ProTree(uint _dim, uint _p, uint _p2) : ProQuantization(_dim, _p), d_p2(_p2), d_nClusters2(0) {}
+
+void ProTree::prepareDistSequence(uint _rows) {
+  if (pqt_index_build_heuristic(handle(), _rows) != PQT_OK) throw std::runtime_error(pqt_last_error());
+}
+
+PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
+      d_boundBins(500), d_heurRows(0), d_N(0) {}
+
+PerturbationProTree::~PerturbationProTree() { if (d_idx) pqt_index_destroy(d_idx); }
+
+void PerturbationProTree::check(int rc, const char* what) {
+  if (rc != PQT_OK) throw std::runtime_error(std::string(what) + ": " + pqt_last_error());
+}
+
+pqt_index* PerturbationProTree::handle() {
+  if (!d_idx) throw std::runtime_error("no tree loaded (readTreeFromFile / loadTree / setTree first)");
+  return d_idx;
+}
+
+void PerturbationProTree::setTree(uint _c1, uint _c2, const float* _cb1, const float* _cb2) {
+  d_nClusters = _c1; d_nClusters2 = _c2;
+  h_codeBook.assign(_cb1, _cb1 + (size_t)_c1 * d_dim);
+  h_codeBook2.assign(_cb2, _cb2 + (size_t)_c1 * _c2 * d_dim);
+  if (d_idx) { pqt_index_destroy(d_idx); d_idx = nullptr; }
+  pqt_params prm = {d_dim, d_p, _c1, _c2, std::min(d_w, _c1), d_lineParts};
+  check(pqt_index_create(&prm, d_device, &d_idx), "pqt_index_create");
+  check(pqt_index_set_codebooks(d_idx, h_codeBook.data(), h_codeBook2.data()), "pqt_index_set_codebooks");
+  d_heurRows = 0;
+}
+
+void PerturbationProTree::readTreeFromFile(const std::string& _name) {
+  std::ifstream f(_name.c_str(), std::ifstream::in | std::ifstream::binary);
+  if (!f.good()) throw std::runtime_error("cannot open file " + _name);
+  uint dim, p, p2, c1, c2, ndbs;
+  f >> dim >> p >> p2 >> c1 >> c2 >> ndbs;
+  f.ignore(1);
+  if (!f.good() || ndbs < 1) throw std::runtime_error("bad .ppqt header in " + _name);
+  if (dim != d_dim || p != d_p) throw std::runtime_error("tree file does not match the constructor's dim/p");
+  std::vector<float> cb1((size_t)ndbs * c1 * dim), cb2((size_t)ndbs * c1 * c2 * dim);
+  f.read((char*)cb1.data(), cb1.size() * 4);
+  f.read((char*)cb2.data(), cb2.size() * 4);
+  if (!f.good()) throw std::runtime_error("short read in " + _name);
+  d_p2 = p2;
+  setTree(c1, c2, cb1.data(), cb2.data());  // perturbation 0 only (nDBs is hard-wired to 1, PerturbationProTree.cu:33)
+}
+
+void PerturbationProTree::writeTreeToFile(const std::string& _name) {
+  handle();
+  std::ofstream f(_name.c_str(), std::ofstream::out | std::ofstream::binary);
+  if (!f.good()) throw std::runtime_error("cannot open file " + _name);
+  f << d_dim << std::endl << d_p << std::endl << d_p2 << std::endl << d_nClusters << std::endl << d_nClusters2 << std::endl
+    << 1 << std::endl;
+  f.write((const char*)h_codeBook.data(), h_codeBook.size() * 4);
+  f.write((const char*)h_codeBook2.data(), h_codeBook2.size() * 4);
+}
+
+void PerturbationProTree::loadTree(const std::string& _name) {
+  std::ifstream f(_name.c_str(), std::ios_base::in | std::ios_base::binary);
+  if (!f.good()) throw std::runtime_error("read error: cannot open file" + _name);
+  uint hdr[5];
+  f.read((char*)hdr, sizeof(hdr));
+  if (hdr[0] != d_dim) throw std::runtime_error("D missmatch");
+  if (hdr[3] != d_p) throw std::runtime_error("P missmatch");
+  const uint c1 = hdr[1], c2 = hdr[2];
+  std::vector<float> cb1((size_t)c1 * d_dim), cb2((size_t)c1 * c2 * d_dim);
+  f.read((char*)cb1.data(), cb1.size() * 4);
+  f.read((char*)cb2.data(), cb2.size() * 4);
+  if (!f.good()) throw std::runtime_error("short read in " + _name);
+  setTree(c1, c2, cb1.data(), cb2.data());
+}
+
+void PerturbationProTree::saveTree(const std::string& _name) {
+  handle();
+  std::ofstream f(_name.c_str(), std::ios_base::out | std::ios_base::binary);
+  if (!f.good()) throw std::runtime_error("write error: cannot open file " + _name);
+  const uint hdr[5] = {d_dim, d_nClusters, d_nClusters2, d_p, d_w};
+  f.write((const char*)hdr, sizeof(hdr));
+  f.write((const char*)h_codeBook.data(), h_codeBook.size() * 4);
+  f.write((const char*)h_codeBook2.data(), h_codeBook2.size() * 4);
+}
+
+void PerturbationProTree::setBins(size_t _nbins, const uint* _ids, const uint* _sizes, const uint* _members) {
+  size_t n = 0;
+  for (size_t b = 0; b < _nbins; ++b) n += _sizes[b];
+  h_binIds.assign(_ids, _ids + _nbins); h_binSizes.assign(_sizes, _sizes + _nbins); h_members.assign(_members, _members + n);
+  d_N = n;
+  check(pqt_index_set_bins(handle(), _nbins, _ids, _sizes, _members), "pqt_index_set_bins");
+}
+
+void PerturbationProTree::setDB(uint _N, const uint* _prefix, const uint* _counts, const uint* _dbIdx, uint _hashSize) {
+  d_N = _N;
+  check(pqt_index_set_db_hashed(handle(), _N, _prefix, _counts, _dbIdx, _hashSize), "pqt_index_set_db_hashed");
+}
+
+void PerturbationProTree::prepareEmptyLambda(uint _N, uint _lParts) {
+  if (d_idx && _lParts != d_lineParts) throw std::runtime_error("line parts must be fixed before the tree is read");
+  d_lineParts = _lParts;
+  h_lines.assign((size_t)_N * _lParts, lineDescr{0, 0, 0});
+}
+
+void PerturbationProTree::setLines(const lineDescr* _lines, size_t _N) {
+  h_lines.assign(_lines, _lines + _N * d_lineParts);
+  check(pqt_index_set_lines_host(handle(), reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
+}
+
+void PerturbationProTree::loadBins(const std::string& _name) {
+  std::ifstream f(_name.c_str(), std::ios_base::in | std::ios_base::binary);
+  if (!f.good()) throw std::runtime_error("read error: cannot open file " + _name);
+  uint nb = 0;
+  f.read((char*)&nb, 4);
+  std::vector<uint> ids(nb), sizes(nb), members;
+  for (uint i = 0; i < nb; ++i) {
+    f.read((char*)&ids[i], 4);
+    f.read((char*)&sizes[i], 4);
+    const size_t o = members.size();
+    members.resize(o + sizes[i]);
+    f.read((char*)(members.data() + o), (size_t)sizes[i] * 4);
+  }
+  uint len = 0, lp = 0;
+  f.read((char*)&len, 4);
+  f.read((char*)&lp, 4);
+  if (!f.good()) throw std::runtime_error("short read in " + _name);
+  if (lp != d_lineParts) throw std::runtime_error("LP missmatch");
+  if (len != members.size()) throw std::runtime_error("#vectors missmatch ");
+  std::vector<lineDescr> lines((size_t)len * lp);
+  f.read((char*)lines.data(), lines.size() * 4);
+  if (!f.good()) throw std::runtime_error("short read in " + _name);
+  setBins(nb, ids.data(), sizes.data(), members.data());
+  setLines(lines.data(), len);
+}
+
+void PerturbationProTree::saveBins(const std::string& _name) {
+  std::ofstream f(_name.c_str(), std::ios_base::out | std::ios_base::binary);
+  if (!f.good()) throw std::runtime_error("write error: cannot open file " + _name);
+  // std::map order of the reference = ascending bin id
+  std::vector<size_t> order(h_binIds.size()), start(h_binIds.size());
+  size_t o = 0;
+  for (size_t b = 0; b < order.size(); ++b) { order[b] = b; start[b] = o; o += h_binSizes[b]; }
+  std::sort(order.begin(), order.end(), [&](size_t l, size_t r) { return h_binIds[l] < h_binIds[r]; });
+  const uint nb = (uint)order.size();
+  f.write((const char*)&nb, 4);
+  for (size_t b : order) {
+    f.write((const char*)&h_binIds[b], 4);
+    f.write((const char*)&h_binSizes[b], 4);
+    f.write((const char*)(h_members.data() + start[b]), (size_t)h_binSizes[b] * 4);
+  }
+  const uint len = (uint)d_N, lp = d_lineParts;
+  f.write((const char*)&len, 4);
+  f.write((const char*)&lp, 4);
+  f.write((const char*)h_lines.data(), h_lines.size() * 4);
+}
+
+void PerturbationProTree::buildKBestDB(const float* _A, uint _N) {
+  pqt_index* h = handle();
+  if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+  float* dA = nullptr; uint32_t* dBin = nullptr; uint32_t* dCodes = nullptr;
+  auto cleanup = [&]() { if (dA) (void)hipFree(dA); if (dBin) (void)hipFree(dBin); if (dCodes) (void)hipFree(dCodes); };
+  if (hipMalloc((void**)&dA, (size_t)_N * d_dim * 4) != hipSuccess || hipMalloc((void**)&dBin, (size_t)_N * 4) != hipSuccess ||
+      hipMalloc((void**)&dCodes, (size_t)_N * d_lineParts * 4) != hipSuccess) { cleanup(); throw std::runtime_error("device allocation failed"); }
+  std::vector<uint> bin(_N);
+  h_lines.resize((size_t)_N * d_lineParts);
+  bool ok = hipMemcpy(dA, _A, (size_t)_N * d_dim * 4, hipMemcpyHostToDevice) == hipSuccess;
+  int rc = ok ? pqt_build_assign_encode(h, dA, _N, dBin, dCodes, nullptr) : PQT_ERR_DEVICE;
+  ok = ok && rc == PQT_OK && hipMemcpy(bin.data(), dBin, (size_t)_N * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(h_lines.data(), dCodes, h_lines.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  cleanup();
+  if (!ok) throw std::runtime_error(std::string("buildKBestDB failed: ") + pqt_last_error());
+  // bins in ascending id order, members in insertion (= id) order: exactly what the reference's std::map holds
+  std::map<uint, std::vector<uint> > bins;
+  for (uint i = 0; i < _N; ++i) bins[bin[i]].push_back(i);
+  std::vector<uint> ids, sizes, members;
+  for (auto& kv : bins) { ids.push_back(kv.first); sizes.push_back((uint)kv.second.size()); members.insert(members.end(), kv.second.begin(), kv.second.end()); }
+  setBins(ids.size(), ids.data(), sizes.data(), members.data());
+  check(pqt_index_set_lines_host(h, reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
+}
+
+void PerturbationProTree::ensureHeuristic(uint rows) {
+  if (rows > d_heurRows) { prepareDistSequence(rows); d_heurRows = rows; }
+}
+
+void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec) {
+  pqt_index* h = handle();
+  ensureHeuristic(d_boundBins);
+  _resIdx.resize((size_t)_QN * _nVec);
+  _resDist.resize((size_t)_QN * _nVec);
+  if (!_QN) return;
+  if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+  uint32_t* dI = nullptr; float* dD = nullptr;
+  if (hipMalloc((void**)&dI, _resIdx.size() * 4) != hipSuccess || hipMalloc((void**)&dD, _resDist.size() * 4) != hipSuccess) {
+    if (dI) (void)hipFree(dI);
+    throw std::runtime_error("device allocation failed");
+  }
+  int rc = pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, dI, dD, nullptr, nullptr, 1);
+  bool ok = rc == PQT_OK && hipMemcpy(_resIdx.data(), dI, _resIdx.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(_resDist.data(), dD, _resDist.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipFree(dI); (void)hipFree(dD);
+  if (!ok) throw std::runtime_error(std::string("queryKNN failed: ") + pqt_last_error());
+}
+
+void PerturbationProTree::queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,
+                                             uint _nVec, const float* /*_hlines*/) {
+  queryKNN(_resIdx, _resDist, _Q, _QN, _nVec);
+}
+
+void PerturbationProTree::query(uint _boundVectors, uint _boundBins, const float* _vecHost, std::vector<std::pair<uint, float> >& _out) {
+  pqt_index* h = handle();
+  ensureHeuristic(_boundBins);
+  // the whole sorted candidate list: k = upper bound of the list length
+  pqt_stats st;
+  uint k = 8192;
+  std::vector<uint> idx; std::vector<float> dist; uint cnt = 0;
+  for (;;) {
+    idx.resize(k); dist.resize(k);
+    check(pqt_query_host(h, _vecHost, 1, _boundVectors, _boundBins, k, idx.data(), dist.data(), &cnt), "pqt_query_host");
+    if (cnt <= k) break;
+    k = cnt;
+  }
+  (void)st;
+  _out.clear();
+  for (uint i = 0; i < cnt; ++i) _out.push_back(std::make_pair(idx[i], dist[i]));
+}
+
+pqt_stats PerturbationProTree::lastStats() {
+  pqt_stats s;
+  check(pqt_get_stats(handle(), &s), "pqt_get_stats");
+  return s;
+}
+
+}  // namespace pqt

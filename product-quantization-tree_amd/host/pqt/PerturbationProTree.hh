@@ -1,0 +1,130 @@
+// pqt/PerturbationProTree.hh -- host-side mirror of the reference's class surface for the query path, over the
+// C-ABI of include/pqt_hip.h.  Same class names, method names, argument meaning and ownership rules as
+//   pqt::ProQuantization      (pqt/ProQuantization.hh:21-94)
+//   pqt::ProTree              (pqt/ProTree.hh:38-243)
+//   pqt::PerturbationProTree  (pqt/PerturbationProTree.hh:28-235)
+// restricted to what tool_query / tool_createdb / test1B call on the hot path; training and the
+// dead experimental methods are not mirrored.  Results follow cpu_version semantics.
+//
+// Error behaviour mirrors the reference: file readers throw std::runtime_error (utils/filereader.hpp:52-56,
+// treequantizer.hpp:702-705); device failures throw std::runtime_error carrying pqt_last_error() instead of the
+// reference's exit(1)/abort (PerturbationProTree.cu:8229-8232).
+#ifndef PQT_HOST_PERTURBATIONPROTREE_HH
+#define PQT_HOST_PERTURBATIONPROTREE_HH
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../../include/pqt_hip.h"
+
+typedef unsigned int uint;
+
+namespace pqt {
+
+/** 4-byte line code, layout of the reference's lineDescr (PerturbationProTree.hh:21-25) / code_t (helper.hpp:39-90) */
+typedef struct {
+  unsigned char p1;
+  unsigned char p2;
+  unsigned short lambda;
+} lineDescr;
+
+class ProQuantization {
+ public:
+  ProQuantization(uint _dim, uint _p);
+  virtual ~ProQuantization();
+  /** first-level codebook, HOST copy (the reference returns its device copy; the device copy here is owned by the handle) */
+  const float* getCodeBook() const { return h_codeBook.data(); }
+  uint getDim() const { return d_dim; }
+  uint getP() const { return d_p; }
+
+ protected:
+  uint d_dim, d_p, d_vl, d_nClusters;
+  std::vector<float> h_codeBook;
+};
+
+class ProTree : public ProQuantization {
+ public:
+  ProTree(uint _dim, uint _p, uint _p2);
+  uint getClusters2() const { return d_nClusters2; }
+  uint getNClusters() const { return d_nClusters; }
+  const float* getCodebook1() const { return h_codeBook.data(); }
+  /** traversal heuristic: the first _rows tuples of prepareHeuristic (treequantizer.hpp:75-127); the CUDA
+   *  prepareDistSequence(int,int) (ProTree.hh:66) is its counterpart */
+  void prepareDistSequence(uint _rows);
+
+ protected:
+  virtual pqt_index* handle() = 0;
+  uint d_p2, d_nClusters2;
+  std::vector<float> h_codeBook2;
+};
+
+class PerturbationProTree : public ProTree {
+ public:
+  PerturbationProTree(uint _dim, uint _p, uint _p2);
+  ~PerturbationProTree();
+
+  /** device selection (reference: cudaSetDevice(FLAGS_device), tool_query.cpp:74); call before reading a tree */
+  void setDevice(int _device) { d_device = _device; }
+  /** W of treequantizer<..,W,..> / k1 of queryKNN (PerturbationProTree.cu:8187); call before reading a tree */
+  void setW(uint _w) { d_w = _w; }
+  /** query bounds of treequantizer::query(boundVectors, boundBins, ..) (cpu_version/tools/query.cpp:42) */
+  void setBounds(uint _boundVectors, uint _boundBins) { d_boundVectors = _boundVectors; d_boundBins = _boundBins; }
+
+  /** GPU .ppqt (ASCII header dim,p,p2,C1,C2,nDBs + cb1 + cb2; PerturbationProTree.cu:60-220) */
+  void writeTreeToFile(const std::string& _name);
+  void readTreeFromFile(const std::string& _name);
+  /** CPU .tree (5 x u32 D,C1,C2,P,W + cb1 + cb2; treequantizer.hpp:699-737 / 782-837) */
+  void saveTree(const std::string& _name);
+  void loadTree(const std::string& _name);
+  /** CPU .bins (treequantizer.hpp:745-774 / 845-893): bins + line codes */
+  void loadBins(const std::string& _name);
+  void saveBins(const std::string& _name);
+  /** set the tree from host arrays cb1[C1][dim], cb2[p][C1][C2][dim/p] */
+  void setTree(uint _c1, uint _c2, const float* _cb1, const float* _cb2);
+
+  /** upload a previously stored db; host pointers, copied, caller keeps ownership (PerturbationProTree.hh:66).
+   *  slot = bin id % hashSize like the CUDA library (HASH_SIZE, PerturbationProTree.hh:12). */
+  void setDB(uint _N, const uint* _prefix, const uint* _counts, const uint* _dbIdx, uint _hashSize = 400000000u);
+  /** exact (un-hashed) bins: ids[nbins], sizes[nbins], members[N] */
+  void setBins(size_t _nbins, const uint* _ids, const uint* _sizes, const uint* _members);
+
+  /** line store: the reference exposes only prepareEmptyLambda/getLine (PerturbationProTree.hh:101-103) and
+   *  passes `_hlines` per call; here the codes are uploaded once. */
+  void prepareEmptyLambda(uint _N, uint _lParts = 16);
+  void setLines(const lineDescr* _lines, size_t _N);
+  uint getLineParts() const { return d_lineParts; }
+
+  /** insert = id() + prepareReranking for _N host vectors (treequantizer.hpp:212-217; CUDA buildKBestDB + lineDist):
+   *  fills the bin store and the line store of this object */
+  void buildKBestDB(const float* _A /* host */, uint _N);
+  void lineDist(const float* /*_DB*/, uint /*_N*/) {}  // line codes are produced by buildKBestDB in one pass
+
+  /** _Q is a DEVICE pointer (like the reference), results are resized to _QN*_nVec (PerturbationProTree.cu:8182-8183).
+   *  Unused slots: id 0xffffffff, distance +inf (the reference pads with 1e7). */
+  void queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec);
+  /** same with line codes "in host memory": the codes live in HBM here, _hlines is ignored (kept for signature parity) */
+  void queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,
+                          uint _nVec, const float* _hlines);
+  /** host-pointer variant of treequantizer::query for one vector: sorted (id, distance) pairs */
+  void query(uint _boundVectors, uint _boundBins, const float* _vecHost, std::vector<std::pair<uint, float> >& _out);
+
+  uint getNPerturbations() const { return 1; }
+  pqt_stats lastStats();
+  const std::vector<uint>& binIds() const { return h_binIds; }
+
+ protected:
+  pqt_index* handle();
+  void ensureHeuristic(uint rows);
+  void check(int rc, const char* what);
+
+  pqt_index* d_idx;
+  int d_device;
+  uint d_w, d_lineParts, d_boundVectors, d_boundBins, d_heurRows;
+  std::vector<uint> h_binIds, h_binSizes, h_members;
+  std::vector<lineDescr> h_lines;
+  size_t d_N;
+};
+
+}  // namespace pqt
+#endif

@@ -1,0 +1,74 @@
+"""End-to-end through the kept front-end: files in the reference's formats -> tool_createdb -> tool_query.
+
+tool_createdb's .bins dump must be byte-identical to the oracle's saveBins (treequantizer.hpp:745-774) for the
+same tree and dataset; tool_query's recall lines must equal the recall computed from the oracle's result lists.
+"""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import ROOT, fixture
+
+pytestmark = pytest.mark.gpu
+HOST = os.path.join(ROOT, "product-quantization-tree_amd", "host")
+
+
+def write_umem(path, arr, dtype):
+    arr = np.ascontiguousarray(arr, dtype)
+    hdr = ("%d\n%d\n" % arr.shape).encode().ljust(20, b"\0")
+    with open(path, "wb") as f:
+        f.write(hdr)
+        f.write(arr.tobytes())
+
+
+def test_createdb_then_query_roundtrip(tmp_path):
+    if not os.path.exists(os.path.join(HOST, "tool_query")):
+        subprocess.check_call(["make", "-C", HOST])
+    f = fixture("tools_default")
+    c = f.cfg
+    os.chdir(tmp_path)
+    pre = "t_%d_%d_%d_%d" % (c["D"], c["P"], c["C1"], c["C2"])
+    # .ppqt: ASCII header dim,p,p2,C1,C2,nDBs + 1 separator byte + cb1 + cb2 (PerturbationProTree.cu:60-116)
+    with open(pre + ".ppqt", "wb") as fh:
+        fh.write(("%d\n%d\n%d\n%d\n%d\n%d\n" % (c["D"], c["P"], c["P"], c["C1"], c["C2"], 1)).encode())
+        fh.write(f.cb1.tobytes())
+        fh.write(f.cb2.tobytes())
+    write_umem("base.umem", f.base, np.uint8)
+    write_umem("query.umem", f.queries, np.uint8)
+    args = ["--c1", str(c["C1"]), "--c2", str(c["C2"]), "--p", str(c["P"]), "--dim", str(c["D"]), "--lineparts", str(c["LP"]),
+            "--basename", "t", "--w", str(c["W"])]
+    out = subprocess.run([os.path.join(HOST, "tool_createdb")] + args + ["--dataset", "base.umem"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    f.oracle.save_bins("oracle.bins")
+    assert open(pre + ".bins", "rb").read() == open("oracle.bins", "rb").read(), ".bins dump differs from the oracle's saveBins"
+    # ground truth for recall = oracle's own top-1 (any fixed id list works: both sides are scored the same way)
+    bv, bb, nvec = 2000, 500, 128
+    lists = []
+    f.oracle.set_sort_mode(1)
+    for q in f.queries:
+        ids, _ = f.oracle.query(q, bv, bb)
+        lists.append(ids)
+    f.oracle.set_sort_mode(0)
+    rng = np.random.default_rng(0)
+    gt = np.array([l[min(len(l) - 1, int(rng.integers(0, 40)))] for l in lists], np.int32).reshape(-1, 1)
+    write_umem("gt.imem", gt, np.int32)
+    out = subprocess.run([os.path.join(HOST, "tool_query")] + args + ["--queryset", "query.umem", "--groundtruth", "gt.imem",
+                         "--boundvectors", str(bv), "--boundbins", str(bb), "--nvec", str(nvec)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    got = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"@R(\d+): ([0-9.eE+-]+)", out.stdout)}
+    for R in (1, 10, 100):
+        want = np.mean([gt[i, 0] in lists[i][:min(R, nvec)] for i in range(len(lists))])
+        assert abs(got[R] - want) < 1e-9, (R, got[R], want)
+    assert "avg. query time" in out.stdout
+
+
+def test_tool_reports_missing_codebook(tmp_path):
+    if not os.path.exists(os.path.join(HOST, "tool_query")):
+        subprocess.check_call(["make", "-C", HOST])
+    os.chdir(tmp_path)
+    write_umem("q.umem", np.zeros((2, 128)), np.uint8)
+    out = subprocess.run([os.path.join(HOST, "tool_query"), "--queryset", "q.umem", "--basename", "nope"], capture_output=True, text=True)
+    assert out.returncode == 1 and "you need to generate a codebook first" in out.stdout
