@@ -259,6 +259,15 @@ def main():
         step()
         torch.cuda.synchronize(dev)
         rerank_ms.extend(idx.rerank_launch_ms().tolist())
+    if os.environ.get("PQT_TSTAMP"):
+        import ctypes
+        ts = np.zeros((qn, 16), np.uint64)
+        L = pkg.lib()
+        L.pqt_debug_tstamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        if L.pqt_debug_tstamps(idx.h, ts.ctypes.data, qn) == 0:
+            d = np.diff(ts[:, :9].astype(np.int64), axis=1)
+            log("[tstamp] phase cycles median:", np.median(d, axis=0).astype(int).tolist(), " total median", int(np.median(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64))),
+                " p90", int(np.percentile(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64), 90)))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -82,6 +82,10 @@ int pqt_device_count(void);
 int pqt_index_create(const pqt_params* prm, int device, pqt_index** out);
 void pqt_index_destroy(pqt_index* idx);
 int pqt_index_params(const pqt_index* idx, pqt_params* out);
+/* tuning/debug options: "fused" = 1 (default) use the wave-per-query fused kernels (traversal; rerank+select) when
+ * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
+ * intermediates readable by pqt_debug_read). Results are identical either way. */
+int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);
 
 /* ---- tree ---------------------------------------------------------------------------
  * replaces: loadTree payload (treequantizer.hpp:782-837) / readTreeFromFile payload
@@ -169,6 +173,9 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bo
  *   cand_idx[QN][stride], cand_dist[...]    = candidates in visiting order (rerankVectors before its sort)
  * Each pointer may be NULL.  Host pointers.  stride is returned by pqt_debug_stride(). */
 uint64_t pqt_debug_stride(const pqt_index* idx);
+/* per-query phase timestamps of the fused traversal kernel (only when the process runs with PQT_TSTAMP=1):
+ * out[qn][16] shader-clock ticks */
+int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out_host, uint32_t qn);
 int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt_host, float* seg_d2_host,
                    uint32_t* seg_bin_host, uint32_t* cand_idx_host, float* cand_dist_host,
                    uint32_t* ncand_host);

@@ -42,6 +42,7 @@ class pqt_stats(C.Structure):
 # every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
+    "pqt_index_set_option", "pqt_debug_tstamps",
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
@@ -73,6 +74,8 @@ def lib():
     L.pqt_index_destroy.argtypes = [C.c_void_p]
     L.pqt_index_destroy.restype = None
     L.pqt_index_params.argtypes = [C.c_void_p, C.POINTER(pqt_params)]
+    L.pqt_index_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.pqt_debug_tstamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.pqt_index_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqt_index_get_coarse.argtypes = [C.c_void_p, f32p]
     L.pqt_index_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
@@ -137,6 +140,9 @@ class PqtIndex:
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        _chk(self.L.pqt_index_set_option(self.h, name.encode(), int(value)))
 
     # ---- population ---------------------------------------------------------------------------
     def set_codebooks(self, cb1, cb2):

@@ -13,10 +13,11 @@ struct PqtDevParams {
   uint32_t R;    // LP / P  : line parts per part
   uint32_t WC;   // W * C2  : second-level entries per part
   uint32_t hashMod;           // 0, or the CUDA library's HASH_SIZE modulo (PerturbationProTree.hh:12)
+  uint32_t tableSeed;         // seed of the second hash of the bin table
   uint32_t powers[PQT_MAXP];  // (C1*C2)^p mod 2^32  (treequantizer.hpp:45-49)
 };
 
-// open-addressing table of the non-empty bins; gcount == 0 marks a free slot
+// two-choice hash table of the non-empty bins; gcount == 0 marks a free slot
 struct __attribute__((aligned(16))) PqtBinEntry {
   uint32_t key;     // bin id (uint32, wrapped exactly like the reference's globIdx)
   uint32_t gcount;  // population of the bin in the WHOLE database (drives the cut)
@@ -24,8 +25,28 @@ struct __attribute__((aligned(16))) PqtBinEntry {
   uint32_t lcount;  // members held by this device (== gcount when unsharded)
 };
 
-__device__ __forceinline__ uint32_t pqt_hash_slot(uint32_t key, uint32_t bits) {
+// Two-choice (cuckoo) table: a key lives in slot h1(key) or h2(key), so a look-up is ONE round trip of two
+// independent 16-byte reads -- no probe chains, no divergence.  The host builds the table (pqt_hip.hip: uploadBins).
+__host__ __device__ __forceinline__ uint32_t pqt_hash1(uint32_t key, uint32_t bits) {
   return (key * 0x9E3779B1u) >> (32u - bits);
+}
+__host__ __device__ __forceinline__ uint32_t pqt_hash2(uint32_t key, uint32_t bits, uint32_t seed) {
+  uint32_t x = key ^ seed;
+  x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+  return (x * 0xC2B2AE35u) >> (32u - bits);
+}
+// returns {key, gcount, lstart, lcount}; gcount == 0 when the bin does not exist.  *slotOut = slot of the hit.
+__device__ __forceinline__ uint4 pqt_table_lookup(const uint4* __restrict__ table4, uint32_t key, uint32_t bits, uint32_t seed,
+                                                  uint32_t* slotOut) {
+  const uint32_t s1 = pqt_hash1(key, bits), s2 = pqt_hash2(key, bits, seed);
+  const uint4 e1 = table4[s1];
+  const uint4 e2 = table4[s2];
+  const bool h1 = e1.y != 0 && e1.x == key;
+  const bool h2 = e2.y != 0 && e2.x == key;
+  uint4 r = h1 ? e1 : e2;
+  if (!h1 && !h2) r = make_uint4(key, 0u, 0u, 0u);
+  *slotOut = h1 ? s1 : s2;
+  return r;
 }
 
 // total order on f32 matching operator< (with -0 == +0): key(a) < key(b)  <=>  a < b

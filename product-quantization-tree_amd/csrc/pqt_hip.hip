@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <string>
@@ -28,6 +29,8 @@ uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
 
 enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_RERANK, EV_SELECT, EV_COUNT };
 constexpr int kMaxChunks = 64;
+constexpr int kFusedWaves = 12;
+constexpr int kTravWaves = 4;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
 }  // namespace
 
@@ -40,7 +43,7 @@ struct pqt_index {
   float* d_cb1 = nullptr; float* d_cb2 = nullptr; float* d_coarse = nullptr;
   bool haveTree = false;
   // heuristic prefix (a3)
-  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr;
+  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr;
   uint64_t maxMultiIndex = 0;
   // bin store (a5)
   PqtBinEntry* d_table = nullptr; uint32_t* d_lower = nullptr; uint32_t tableBits = 0;
@@ -54,12 +57,14 @@ struct pqt_index {
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // 8
+  unsigned long long* d_tstamp = nullptr;    // optional per-query phase timestamps (debug)
   uint64_t stride = 0;
   // results of the last call
   pqt_stats stats{};
   uint32_t lastQn = 0; uint32_t lastHe = 0;
   hipEvent_t ev[kMaxChunks][EV_COUNT]{}; int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
+  int numCUs = 256; bool forceUnfused = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -106,28 +111,48 @@ struct BinDesc { uint32_t key, gcount, lstart, lcount, lower; };
 int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vector<uint32_t>& localIds, bool sharded) {
   int rc = setDevice(idx);
   if (rc) return rc;
+  // two-choice (cuckoo) table at load factor <= 0.4: every look-up is two independent reads
   uint32_t bits = 4;
-  while (((uint64_t)1 << bits) < 2 * (uint64_t)bins.size() && bits < 31) ++bits;
-  if (((uint64_t)1 << bits) < bins.size() + 1) return fail(PQT_ERR_LIMIT, "too many bins for the table");
+  while (((uint64_t)1 << bits) * 2 < 5 * (uint64_t)bins.size() && bits < 31) ++bits;
+  if (((uint64_t)1 << bits) < 2 * (uint64_t)bins.size() + 1) return fail(PQT_ERR_LIMIT, "too many bins for the table");
   const size_t tsz = (size_t)1 << bits;
-  std::vector<PqtBinEntry> table(tsz);
-  memset(table.data(), 0, tsz * sizeof(PqtBinEntry));
+  std::vector<PqtBinEntry> table;
   std::vector<uint32_t> lower;
-  if (sharded) lower.assign(tsz, 0);
   uint32_t maxBin = 0;
-  const uint32_t mask = (uint32_t)(tsz - 1);
-  for (const BinDesc& b : bins) {
-    if (b.gcount == 0) continue;
-    uint32_t slot = (b.key * 0x9E3779B1u) >> (32u - bits);
-    for (;;) {
-      if (table[slot].gcount == 0) break;
-      if (table[slot].key == b.key) return fail(PQT_ERR_INVALID, "duplicate bin id in bin list");
-      slot = (slot + 1) & mask;
+  uint32_t seed = 0x5bd1e995u, usedSeed = 0;
+  bool built = false;
+  for (int attempt = 0; attempt < 16 && !built; ++attempt, seed = seed * 1664525u + 1013904223u) {
+    usedSeed = seed;
+    table.assign(tsz, PqtBinEntry{0, 0, 0, 0});
+    if (sharded) lower.assign(tsz, 0);
+    built = true;
+    maxBin = 0;
+    for (const BinDesc& b0 : bins) {
+      if (b0.gcount == 0) continue;
+      maxBin = std::max(maxBin, b0.gcount);
+      PqtBinEntry cur{b0.key, b0.gcount, b0.lstart, b0.lcount};
+      uint32_t curLower = b0.lower;
+      // duplicate check against both homes of the new key
+      {
+        const uint32_t a = pqt_hash1(cur.key, bits), c = pqt_hash2(cur.key, bits, seed);
+        if ((table[a].gcount && table[a].key == cur.key) || (table[c].gcount && table[c].key == cur.key))
+          return fail(PQT_ERR_INVALID, "duplicate bin id in bin list");
+      }
+      uint32_t slot = pqt_hash1(cur.key, bits);
+      bool placed = false;
+      for (int kick = 0; kick < 512; ++kick) {
+        if (table[slot].gcount == 0) { table[slot] = cur; if (sharded) lower[slot] = curLower; placed = true; break; }
+        // evict the resident, move it to its other home
+        std::swap(cur, table[slot]);
+        if (sharded) std::swap(curLower, lower[slot]);
+        const uint32_t a = pqt_hash1(cur.key, bits), c = pqt_hash2(cur.key, bits, seed);
+        slot = (slot == a) ? c : a;
+      }
+      if (!placed) { built = false; break; }
     }
-    table[slot].key = b.key; table[slot].gcount = b.gcount; table[slot].lstart = b.lstart; table[slot].lcount = b.lcount;
-    if (sharded) lower[slot] = b.lower;
-    maxBin = std::max(maxBin, b.gcount);
   }
+  if (!built) return fail(PQT_ERR_LIMIT, "could not build the bin table (cuckoo insertion failed for 16 seeds)");
+  idx->dp.tableSeed = usedSeed;
   if ((rc = devAlloc(&idx->d_table, tsz))) return rc;
   HIPCHK(hipMemcpy(idx->d_table, table.data(), tsz * sizeof(PqtBinEntry), hipMemcpyHostToDevice));
   if (idx->d_lower) { (void)hipFree(idx->d_lower); idx->d_lower = nullptr; }
@@ -209,11 +234,46 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t lSel = ldsSelect(kP2);
   if (!fullSort) { if (idx->sharded) { if ((rc = allowLds(pqt_k_select<true>, lSel))) return rc; } else { if ((rc = allowLds(pqt_k_select<false>, lSel))) return rc; } }
 
+  // fused traversal (wave per query) when the bin list fits the in-register sorter
+  const bool travFused = (He <= 512) && (d.WC <= 256) && !idx->sharded && !idx->forceUnfused;
+  const uint32_t travPerWave = (uint32_t)((512 * 8 + 4 * (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P * d.W + 3 * d.P * d.WC) + 15) & ~(size_t)15);
+  const size_t lTrav = (size_t)kTravWaves * travPerWave;
+  if (travFused) {
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false>, lTrav))) return rc;
+  }
+  // fused rerank+select (wave per query) whenever the result list fits the in-register selector
+  const bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
+  const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
+  const bool coarseLds = coarseBytes <= 64 * 1024;
+  const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4);
+  if (fused) {
+#define PQT_ALLOW_RS(LPV)                                                                                          \
+    do { if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, true, true>, lFused))) return rc;               \
+         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, true, false>, lFused))) return rc;              \
+         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, false, true>, lFused))) return rc;              \
+         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, false, false>, lFused))) return rc; } while (0)
+    switch (d.LP / 4) { case 1: PQT_ALLOW_RS(1); break; case 2: PQT_ALLOW_RS(2); break; case 4: PQT_ALLOW_RS(4); break; default: PQT_ALLOW_RS(8); break; }
+#undef PQT_ALLOW_RS
+  }
   idx->nChunks = nChunks;
   for (int c = 0; c < nChunks; ++c) {
     const uint32_t q0 = (uint32_t)c * qChunk;
     const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
     HIPCHK(hipEventRecord(idx->ev[c][EV_BEGIN], st));
+    if (travFused) {
+      // a1..a6 in one launch, one wavefront per query
+      HIPCHK(hipEventRecord(idx->ev[c][EV_TABLES], st));
+      const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
+#define PQT_LAUNCH_TR(WCR)                                                                                              \
+      hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, false>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
+                         q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
+                         idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
+                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->d_counters, idx->d_tstamp)
+      if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
+#undef PQT_LAUNCH_TR
+    } else {
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
                        idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_counters);
@@ -228,7 +288,30 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                          idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                          idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
                          stride, idx->d_counters);
+    }
     HIPCHK(hipEventRecord(idx->ev[c][EV_BINS], st));
+    uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
+    uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
+    if (fused) {
+      // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
+      const uint32_t grid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
+#define PQT_LAUNCH_RS(LPV, CL, SH)                                                                                         \
+      hipLaunchKernelGGL((pqt_k_rerank_select<kFusedWaves, LPV, CL, SH>), dim3(grid), dim3(kFusedWaves * 64), lFused, st, \
+                         idx->d_codes, idx->idBase, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, \
+                         idx->d_candPos, idx->d_nLocal + q0, stride, k, nq, d, oI, oD, oP, idx->d_counters, idx->dbg)
+#define PQT_LAUNCH_RS2(LPV)                                                                                                \
+      do { if (coarseLds) { if (idx->sharded) PQT_LAUNCH_RS(LPV, true, true); else PQT_LAUNCH_RS(LPV, true, false); }     \
+           else { if (idx->sharded) PQT_LAUNCH_RS(LPV, false, true); else PQT_LAUNCH_RS(LPV, false, false); } } while (0)
+      switch (d.LP / 4) {
+        case 1: PQT_LAUNCH_RS2(1); break;
+        case 2: PQT_LAUNCH_RS2(2); break;
+        case 4: PQT_LAUNCH_RS2(4); break;
+        default: PQT_LAUNCH_RS2(8); break;
+      }
+#undef PQT_LAUNCH_RS2
+#undef PQT_LAUNCH_RS
+      HIPCHK(hipEventRecord(idx->ev[c][EV_RERANK], st));
+    } else {
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
@@ -238,8 +321,6 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
                          idx->d_nLocal + q0, stride, d);
     HIPCHK(hipEventRecord(idx->ev[c][EV_RERANK], st));
-    uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
-    uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fullSort) {
       if (idx->sharded)
         hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
@@ -254,6 +335,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       else
         hipLaunchKernelGGL(pqt_k_select<false>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
                            idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
+    }
     }
     HIPCHK(hipEventRecord(idx->ev[c][EV_SELECT], st));
   }
@@ -308,6 +390,10 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
     return fail(PQT_ERR_DEVICE, "stream/counter allocation failed");
   }
   size_t freeB = 0, totalB = 0;
+  idx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
+  if (getenv("PQT_DBG")) idx->dbg = (uint32_t)atoi(getenv("PQT_DBG"));
+  if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * 16 * 8) != hipSuccess) idx->d_tstamp = nullptr; }
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
   *out = idx;
   return PQT_OK;
@@ -317,7 +403,7 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_coarse, idx->d_heur, idx->d_table, idx->d_lower, idx->d_ids,
+  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -330,6 +416,12 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out) {
   if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
   *out = idx->prm;
   return PQT_OK;
+}
+
+int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
+  if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
+  if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
+  return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }
 
 int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) {
@@ -370,6 +462,11 @@ static int uploadHeuristic(pqt_index* idx) {
   }
   if ((rc = devAlloc(&idx->d_heur, h16.size()))) return rc;
   if (!h16.empty()) HIPCHK(hipMemcpy(idx->d_heur, h16.data(), h16.size() * 2, hipMemcpyHostToDevice));
+  // 16-byte rows (8 x u16, zero padded) for the one-read-per-row traversal kernel
+  std::vector<uint16_t> h8(idx->heurRows * 8, 0);
+  for (uint64_t r = 0; r < idx->heurRows; ++r) for (uint32_t pp = 0; pp < P; ++pp) h8[r * 8 + pp] = h16[r * P + pp];
+  if ((rc = devAlloc(&idx->d_heur8, h8.size()))) return rc;
+  if (!h8.empty()) HIPCHK(hipMemcpy(idx->d_heur8, h8.data(), h8.size() * 2, hipMemcpyHostToDevice));
   return PQT_OK;
 }
 
@@ -588,6 +685,13 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd
   if (candIdx) HIPCHK(hipMemcpy(candIdx, idx->d_cand, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
   if (candDist) HIPCHK(hipMemcpy(candDist, idx->d_candDist, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
   if (ncand) HIPCHK(hipMemcpy(ncand, idx->d_nLocal, (size_t)qn * 4, hipMemcpyDeviceToHost));
+  return PQT_OK;
+}
+
+int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out, uint32_t qn) {
+  if (!idx || !idx->d_tstamp || qn > (1u << 16)) return fail(PQT_ERR_STATE, "timestamps not enabled (PQT_TSTAMP=1)");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, idx->d_tstamp, (size_t)qn * 16 * 8, hipMemcpyDeviceToHost));
   return PQT_OK;
 }
 

@@ -166,16 +166,12 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
       glob += sSegB[p * WC + idx] * prm.powers[p];
     }
     if (prm.hashMod) glob %= prm.hashMod;
-    // probe (linear probing; gcount == 0 terminates)
-    uint32_t slot = pqt_hash_slot(glob, tableBits);
-    const uint32_t mask = (1u << tableBits) - 1u;
-    uint32_t g = 0, ls = 0, lc = 0, lo = 0;
-    for (;;) {
-      const PqtBinEntry e = table[slot];
-      if (e.gcount == 0) break;
-      if (e.key == glob) { g = e.gcount; ls = e.lstart; lc = e.lcount; if (SHARDED) lo = lower[slot]; break; }
-      slot = (slot + 1) & mask;
-    }
+    // one round trip: both candidate slots of the two-choice table
+    uint32_t slot;
+    const uint4 e = pqt_table_lookup(reinterpret_cast<const uint4*>(table), glob, tableBits, prm.tableSeed, &slot);
+    const uint32_t g = e.y, ls = e.z, lc = e.w;
+    uint32_t lo = 0;
+    if (SHARDED && g) lo = lower[slot];
     sG[h] = g; sLs[h] = ls;
     if (SHARDED) { sLc[h] = lc; sLo[h] = lo; }
     sKey[h] = ((uint64_t)pqt_f2key(fine) << 32) | h;
@@ -615,4 +611,377 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
   const uint32_t u = pqt_lambda_encode(l[i]);
   outU16[i] = (uint16_t)u;
   outRound[i] = pqt_lambda_decode(u);
+}
+
+// ===================================================================================================
+// Fused stage a7 + a8 (k <= 128): ADC line rerank + exact top-k, one WAVEFRONT per query.
+//
+//   * workgroup = NW independent wavefronts that share one LDS copy of coarse[LP][C1][C1] (when it fits:
+//     <= 64 KB, i.e. cfg1/cfg2); each wavefront walks queries q = wg*NW + w, += grid*NW.
+//   * lane = one candidate: reads its id, streams the 4*LP-byte code row as 16-byte vectors, accumulates the LP
+//     terms in p order (bit-exact, see pqt_k_rerank); the three table look-ups per term are LDS reads
+//     (L1virt of the query + coarse), not TA gathers.
+//   * selection: keys (f32 key << 32 | visiting position) are unique, so "the k smallest keys" is exact.
+//     A candidate enters the wave's pending buffer only if its key beats tau, the current k-th best;
+//     when the buffer fills (or at the end) [best 128 | pending] is sorted by the in-register bitonic network
+//     (pqt_wave_sort_u64<8>, 512 keys) and the first 128 become the new best.  Distances never touch HBM.
+// LDS: coarse (optional) + NW * (LP*C1*4 + 384*8) bytes.
+// ===================================================================================================
+#include "pqt_wave.h"
+
+#define PQT_RS_BEST 128
+#define PQT_RS_PEND 384
+
+template <int NW, int LPV, bool COARSE_LDS, bool SHARDED>
+__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
+    const uint32_t* __restrict__ codes, uint64_t idBase, const float* __restrict__ qL1virt,
+    const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
+    unsigned long long* __restrict__ counters, uint32_t dbg) {
+  // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
+  // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
+  constexpr int U = (16 / LPV) > 8 ? 8 : (16 / LPV);
+  constexpr uint32_t LP = LPV * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t C1 = prm.C1;
+  const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
+  float* sCoarse = (float*)smem_raw;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
+  if (COARSE_LDS) {
+    if (!(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
+    __syncthreads();
+  }
+  const float* cz = COARSE_LDS ? sCoarse : coarse;
+
+  for (uint32_t q = blockIdx.x * NW + wave; q < qn; q += gridDim.x * NW) {
+    const uint32_t n = (dbg & 2) ? 0u : nLocal[q];
+    const uint32_t* cid = cand + (size_t)q * stride;
+    const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
+    for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
+    __builtin_amdgcn_wave_barrier();
+    uint64_t tau = ~0ull;
+    uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = 128 once a best list exists
+    uint32_t off0 = 0;
+
+    auto flush = [&]() {
+      uint64_t key[8];  // [best 128 (after the first flush) | pending npend | padding], 8 keys per lane, blocked
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t e = lane * 8 + r;
+        key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
+      }
+      if (!(dbg & 1)) pqt_wave_sort_u64<8>(key);
+      if (lane < PQT_RS_BEST / 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      tau = sKeys[k - 1];  // k-th best so far (~0 while fewer than k seen)
+      npend = 0;
+      off0 = PQT_RS_BEST;
+    };
+
+    for (uint32_t base = 0;; base += 64 * U) {
+      if (base < n) {
+        uint32_t id[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = base + u * 64 + lane;
+          id[u] = cid[j < n ? j : n - 1];
+        }
+        uint4 rows[U][LPV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint4* row4 = reinterpret_cast<const uint4*>(codes + ((size_t)id[u] - idBase) * LP);
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = base + u * 64 + lane;
+          const bool valid = j < n;
+          float acc = 0.f;
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) {
+            const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const uint32_t p = v * 4 + x;
+              const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
+              const float lam = pqt_lambda_decode(w[x] >> 16);
+              const float sb = sVirt[p * C1 + A];
+              const float sa = sVirt[p * C1 + B];
+              const float sc = cz[(p * C1 + A) * C1 + B];
+              acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+            }
+          }
+          // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
+          const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
+          const bool pass = valid && key < tau;
+          uint32_t tot;
+          const uint32_t rk = pqt_ballot_rank(pass, &tot);
+          if (pass) sKeys[off0 + npend + rk] = key;
+          npend += tot;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // single flush site: when the pending buffer could overflow on the next batch, and once at the end
+      const bool last = base + 64 * U >= n;
+      if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) flush();
+      if (last) break;
+    }
+    // results: first min(k, n) entries of the best list
+    const uint32_t kk = n < k ? n : k;
+    uint32_t ties = 0;
+    for (uint32_t i = lane; i < k; i += 64) {
+      const size_t o = (size_t)q * k + i;
+      if (i < kk) {
+        const uint64_t key = sKeys[i];
+        const uint32_t j = (uint32_t)key;
+        outIdx[o] = cid[j];
+        outDist[o] = pqt_key2f((uint32_t)(key >> 32));
+        if (SHARDED) outPos[o] = cpos[j];
+        if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
+      } else {
+        outIdx[o] = 0xffffffffu;
+        outDist[o] = __uint_as_float(0x7f800000u);
+        if (SHARDED) outPos[o] = 0xffffffffu;
+      }
+    }
+    if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ===================================================================================================
+// Fused stage a1 + a2 + a4 + a5 + a6 (bound_bins <= 512): the whole traversal of one query by ONE WAVEFRONT.
+//
+//   workgroup = NW independent wavefronts (no __syncthreads anywhere), each owns a private LDS slice.
+//   a1  lane = (centroid, line part) accumulators, sequential over SS dims; W-best by rank counting.
+//   a2  lane = one second-level entry (row of cb2), sorted per part by the in-register network (pqt_wave_sort_u64<WCR>).
+//   a4  8 heuristic rows per lane: two LDS look-ups per part, uint32 wrap-around bin id, bin-table probe
+//       (8 independent 16-byte random reads in flight per lane), keys (f32 key << 32 | row) sorted in registers (512).
+//   a6  exclusive scan of the populations in visiting order (wave scan), cut, compact list of the non-empty
+//       included bins in LDS, candidates gathered by binary search over that list.
+// LDS per wavefront: D + LP*C1 + P*C1 + P*W + 3*P*WC words + 512 * 8 bytes.
+// ===================================================================================================
+template <int NW, int WCR, bool SHARDED>
+__global__ __launch_bounds__(NW * 64) void pqt_k_traverse(
+    const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2, PqtDevParams prm,
+    const uint4* __restrict__ heur8 /* rows of 8 x u16 */, uint32_t He, uint32_t Bv, const PqtBinEntry* __restrict__ table,
+    const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids, uint32_t qn,
+    float* __restrict__ qL1virt, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
+    uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
+    uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp) {
+#define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, W = prm.W, LP = prm.LP, S = prm.S, SS = prm.SS,
+                 R = prm.R, WC = prm.WC;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * NW + wave;
+  if (q >= qn) return;
+  unsigned char* base = smem_raw + (size_t)wave * perWaveBytes;
+  uint64_t* sBin = (uint64_t*)base;                 // 512 : (gcount | lstart<<32) by row, later the compact bin list
+  float* sQ = (float*)(sBin + 512);                 // D
+  float* sVirt = sQ + D;                            // LP*C1
+  float* sL1 = sVirt + LP * C1;                     // P*C1
+  uint32_t* sOrd = (uint32_t*)(sL1 + P * C1);       // P*W
+  float* sSegD = (float*)(sOrd + P * W);            // P*WC (first unsorted d2, then sorted)
+  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);    // P*WC
+  float* sD2 = (float*)(sSegB + P * WC);            // P*WC unsorted staging
+
+  PQT_TS(0);
+  for (uint32_t i = lane; i < D; i += 64) sQ[i] = Q[(size_t)q * D + i];
+  __builtin_amdgcn_wave_barrier();
+  // ---- a1 (4 accumulators per lane in flight: their cb1 reads overlap)
+  for (uint32_t t0 = lane; t0 < C1 * LP; t0 += 64 * 4) {
+    float acc[4];
+    uint32_t dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t t = t0 + 64 * u;
+      const uint32_t tt = t < C1 * LP ? t : t0;
+      const uint32_t c = tt / LP, lp = tt % LP;
+      const float* cen = cb1 + (size_t)c * D + lp * SS;
+      const float* qq = sQ + lp * SS;
+      float s = 0.f;
+      for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      acc[u] = s;
+      dst[u] = t < C1 * LP ? lp * C1 + c : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (dst[u] != 0xffffffffu) sVirt[dst[u]] = acc[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  PQT_TS(1);
+  for (uint32_t t = lane; t < LP * C1; t += 64) qL1virt[(size_t)q * LP * C1 + t] = sVirt[t];
+  for (uint32_t t = lane; t < P * C1; t += 64) {
+    const uint32_t p = t / C1, c = t % C1;
+    float d = 0.f;
+    for (uint32_t pp = 0; pp < R; ++pp) d = d + sVirt[(p * R + pp) * C1 + c];
+    sL1[t] = d;
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t ties = 0;
+  for (uint32_t t = lane; t < P * C1; t += 64) {
+    const uint32_t p = t / C1, c = t % C1;
+    const float my = sL1[t];
+    uint32_t rank = 0;
+    for (uint32_t o = 0; o < C1; ++o) {
+      const float v = sL1[p * C1 + o];
+      rank += (v < my) || (v == my && o < c);
+      ties += (v == my && o < c);
+    }
+    if (rank < W) sOrd[p * W + rank] = c;
+  }
+  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[0], (unsigned long long)ties); }
+  __builtin_amdgcn_wave_barrier();
+  PQT_TS(2);
+  // ---- a2 (2 entries per lane in flight)
+  for (uint32_t t0 = lane; t0 < P * WC; t0 += 64 * 2) {
+    float acc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t t = t0 + 64 * u;
+      const uint32_t tt = t < P * WC ? t : t0;
+      const uint32_t p = tt / WC, pos = tt % WC, h1 = pos / C2, h2 = pos % C2;
+      const uint32_t c1 = sOrd[p * W + h1];
+      const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
+      const float* qq = sQ + p * S;
+      float s = 0.f;
+      for (uint32_t d = 0; d < S; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      acc[u] = s;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (t0 + 64 * u < P * WC) sD2[t0 + 64 * u] = acc[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  PQT_TS(3);
+  ties = 0;
+  for (uint32_t p = 0; p < P; ++p) {
+    uint64_t key[WCR];
+#pragma unroll
+    for (int r = 0; r < WCR; ++r) {
+      const uint32_t pos = lane + 64 * r;
+      key[r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[p * WC + pos]) << 32) | pos) : ~0ull;
+    }
+    pqt_wave_sort_u64<WCR>(key);
+#pragma unroll
+    for (int r = 0; r < WCR; ++r) {
+      const uint32_t e = lane * WCR + r;
+      if (e < WC) {
+        const uint32_t pos = (uint32_t)key[r];
+        sSegD[p * WC + e] = sD2[p * WC + pos];
+        sSegB[p * WC + e] = (sOrd[p * W + pos / C2] * C2 + pos % C2) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
+      }
+      // exact ties between neighbours of the sorted list (statistics only)
+      const uint32_t hi = (uint32_t)(key[r] >> 32);
+      const uint32_t nx = (r + 1 < WCR) ? (uint32_t)(key[(r + 1) % WCR] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
+      if (e + 1 < WC && hi == nx && !(r + 1 == WCR && lane == 63)) ++ties;
+    }
+  }
+  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[1], (unsigned long long)ties); }
+  __builtin_amdgcn_wave_barrier();
+  PQT_TS(4);
+  // ---- a4 + a5: 8 rows per lane, row h = lane + 64*r
+  uint64_t key[8];
+  {
+    uint32_t glob[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t h = lane + 64 * r;
+      key[r] = ~0ull;
+      glob[r] = 0;
+      if (h < He) {
+        const uint4 hv = heur8[h];  // one 16-byte read: the row's P digits
+        const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
+        float fine = 0.f;
+        uint32_t g = 0;
+#pragma unroll
+        for (int p = 0; p < PQT_MAXP; ++p) {
+          if ((uint32_t)p < P) {
+            fine = fine + sSegD[p * WC + dg[p]];
+            g += sSegB[p * WC + dg[p]];
+          }
+        }
+        if (prm.hashMod) g %= prm.hashMod;
+        glob[r] = g;
+        key[r] = ((uint64_t)pqt_f2key(fine) << 32) | h;
+      }
+    }
+    // probes: first touch of all 8 slots is issued before any is consumed
+    const uint4* table4 = reinterpret_cast<const uint4*>(table);  // {key, gcount, lstart, lcount}
+    // 16 independent 16-byte reads per lane in flight, then resolved: exactly one memory round trip
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t h = lane + 64 * r;
+      uint32_t slot;
+      const uint4 x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
+      if (h < He) sBin[h] = (uint64_t)x.y | ((uint64_t)x.z << 32);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  PQT_TS(5);
+  pqt_wave_sort_u64<8>(key);
+  PQT_TS(6);
+  // ---- a6: scan populations in visiting order (element i = lane*8 + r)
+  uint32_t g8[8], ls8[8];
+  uint32_t sum = 0;
+  ties = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t i = lane * 8 + r;
+    g8[r] = 0; ls8[r] = 0;
+    if (i < He) {
+      const uint64_t b = sBin[(uint32_t)key[r]];
+      g8[r] = (uint32_t)b; ls8[r] = (uint32_t)(b >> 32);
+      const uint32_t hi = (uint32_t)(key[r] >> 32);
+      const uint32_t nx = (r < 7) ? (uint32_t)(key[(r + 1) & 7] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
+      if (i + 1 < He && hi == nx && !(r == 7 && lane == 63)) ++ties;
+    }
+    sum += g8[r];
+  }
+  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[2], (unsigned long long)ties); }
+  const uint32_t incl = pqt_wave_incl_scan(sum);
+  uint32_t run = incl - sum;  // exclusive prefix of this lane's first element
+  uint32_t myIncl = 0, myCand = 0, myNonEmpty = 0;
+  uint32_t ex8[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t i = lane * 8 + r;
+    const uint32_t g = g8[r];  // 0 beyond He
+    ex8[r] = run;
+    if (i < He && run <= Bv) { ++myIncl; myCand += g; if (g) ++myNonEmpty; } else { g8[r] = 0; }
+    run += g;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // wave totals
+  uint32_t totCand = myCand, totIncl = myIncl;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { totCand += __shfl_xor(totCand, d, 64); totIncl += __shfl_xor(totIncl, d, 64); }
+  const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
+  const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
+  uint32_t wpos = neIncl - myNonEmpty;
+  // compact list (start in candidate list | lstart<<32), ordered by start; overwrites sBin (all reads done)
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; nIncl[q] = totIncl; }
+  PQT_TS(7);
+  for (uint32_t j = lane; j < totCand; j += 64) {
+    uint32_t lo = 0, hi = m;  // last entry with start <= j
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+    }
+    const uint64_t b = sBin[lo];
+    cand[(size_t)q * stride + j] = ids[(uint32_t)(b >> 32) + (j - (uint32_t)b)];
+  }
+  PQT_TS(8);
+#undef PQT_TS
 }

@@ -1,0 +1,83 @@
+// pqt_wave.h -- wave64 register-level primitives for gfx950: a bitonic sorting network over 64*R u64 keys held
+// R per lane (blocked layout: element e = lane*R + r), cross-lane exchanges by lane-xor shuffles.
+// No LDS traffic, no barriers: one wavefront sorts 512 keys in ~1.5k VALU/shuffle instructions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// value of lane (lane ^ LM).  LM = 1, 2, 8 are single DPP moves (VALU latency), LM = 4 two DPP moves and a select;
+// LM = 16, 32 go through ds_bpermute (LDS crossbar).
+template <int LM>
+__device__ __forceinline__ uint32_t pqt_lane_xor_u32(uint32_t v) {
+  if (LM == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  if (LM == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  if (LM == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+  if (LM == 4) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x104, 0xf, 0xf, true);  // row_shl:4  lane i <- i+4
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x114, 0xf, 0xf, true);  // row_shr:4  lane i <- i-4
+    return (threadIdx.x & 4) ? dn : up;
+  }
+  return __shfl_xor(v, LM, 64);
+}
+template <int LM>
+__device__ __forceinline__ uint64_t pqt_lane_xor_u64(uint64_t v) {
+  const uint32_t lo = pqt_lane_xor_u32<LM>((uint32_t)v);
+  const uint32_t hi = pqt_lane_xor_u32<LM>((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// one compare-exchange stage (K = bitonic block size, J = partner distance) of the network
+template <int R, int K, int J>
+__device__ __forceinline__ void pqt_sort_stage(uint64_t (&key)[R], const int lane) {
+  if constexpr (J < R) {
+    // partner inside the lane
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const int r2 = r | J;
+        // direction of the pair: ascending iff bit K of the element index (lane*R + r) is clear
+        const bool desc = (K < R) ? ((r & K) != 0) : (((lane * R) & K) != 0);
+        const uint64_t a = key[r], b = key[r2];
+        const bool sw = (a > b) != desc;  // branch-free: compare mask XOR direction mask, then selects
+        key[r] = sw ? b : a;
+        key[r2] = sw ? a : b;
+      }
+    }
+  } else {
+    constexpr int LM = J / R;  // partner lane = lane ^ LM, same register slot
+    const bool isLow = (lane & LM) == 0;
+    const bool asc = ((lane * R) & K) == 0;
+    const bool keepMax = (isLow != asc);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint64_t o = pqt_lane_xor_u64<LM>(key[r]);
+      const uint64_t a = key[r];
+      // keys are unique (position in the low word) except for ~0 padding, where either choice is the same
+      const bool takeO = (o < a) != keepMax;
+      key[r] = takeO ? o : a;
+    }
+  }
+}
+template <int R, int K, int J>
+__device__ __forceinline__ void pqt_sort_merge(uint64_t (&key)[R], const int lane) {
+  pqt_sort_stage<R, K, J>(key, lane);
+  if constexpr (J > 1) pqt_sort_merge<R, K, J / 2>(key, lane);
+}
+template <int R, int K>
+__device__ __forceinline__ void pqt_sort_level(uint64_t (&key)[R], const int lane) {
+  pqt_sort_merge<R, K, K / 2>(key, lane);
+  if constexpr (K < 64 * R) pqt_sort_level<R, K * 2>(key, lane);
+}
+// ascending sort of the 64*R keys of one wavefront; on return lane L holds sorted elements [L*R, L*R+R)
+template <int R>
+__device__ __forceinline__ void pqt_wave_sort_u64(uint64_t (&key)[R]) {
+  pqt_sort_level<R, 2>(key, (int)(threadIdx.x & 63));
+}
+
+// rank of this lane among the set lanes of a predicate, and the total
+__device__ __forceinline__ uint32_t pqt_ballot_rank(bool pred, uint32_t* total) {
+  const unsigned long long m = __ballot(pred);
+  const int lane = threadIdx.x & 63;
+  *total = (uint32_t)__popcll(m);
+  return (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}

@@ -1,0 +1,8 @@
+for d in 0 1 2 3 4 7; do
+  echo -n "dbg $d: "
+  PQT_DBG=$d python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['config']
+print(c['stage_ms'])
+"
+done

@@ -19,11 +19,14 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.fixture(scope="module", params=list(CONFIGS))
+@pytest.fixture(scope="module", params=[(c, m) for c in CONFIGS for m in ("fused", "staged")], ids=lambda p: "%s-%s" % p)
 def pair(request):
-    f = fixture(request.param)
+    """Every test runs on both launch structures: the wave-per-query fused kernels and the staged kernels."""
+    name, mode = request.param
+    f = fixture(name)
     idx = f.hip_index()
-    yield request.param, f, idx
+    idx.set_option("fused", 1 if mode == "fused" else 0)
+    yield name, f, idx
     idx.close()
 
 
@@ -62,6 +65,7 @@ def test_coarse_table_bit_exact(pair):
 def test_stage_tables_bit_exact(pair):
     name, f, idx = pair
     Bv, Bb = BV_BB[name]
+    idx.set_option("fused", 0)  # the fused traversal keeps the segment lists on chip; the staged kernels expose them
     idx.query(f.queries, Bv, Bb, 10)
     st = idx.stats()
     dbg = idx.debug_read(len(f.queries), cands=False)

@@ -61,7 +61,7 @@ def test_createdb_then_query_roundtrip(tmp_path):
     got = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"@R(\d+): ([0-9.eE+-]+)", out.stdout)}
     for R in (1, 10, 100):
         want = np.mean([gt[i, 0] in lists[i][:min(R, nvec)] for i in range(len(lists))])
-        assert abs(got[R] - want) < 1e-9, (R, got[R], want)
+        assert abs(got[R] - want) < 1e-5, (R, got[R], want)  # the tool prints 6 significant digits
     assert "avg. query time" in out.stdout
 
 
