@@ -243,22 +243,16 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage = dict(tables=0.0, bins=0.0, rerank=0.0, select=0.0)
-    rerank_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-stage device times of the last timed step (HIP events on the stream the kernels ran on)
+    # per-stage device times of the timed steps themselves: the library records HIP events around every kernel on the
+    # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
+    hist = idx.stage_ms_history(min(args.steps, 32))
     st = idx.stats()
-    for kname in stage:
-        stage[kname] = st["ms_" + kname]
-    # live per-launch duration of the dominant kernel: re-run K steps reading the events each time (untimed region)
-    for _ in range(min(args.steps, 10)):
-        step()
-        torch.cuda.synchronize(dev)
-        rerank_ms.extend(idx.rerank_launch_ms().tolist())
+    stage = dict(zip(("tables", "traverse", "rerank_select", "select"), hist.mean(0).tolist()))
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
         ts = np.zeros((qn, 16), np.uint64)
@@ -282,16 +276,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     qps = qn * args.steps / elapsed
 
-    # ---- roofline of the dominant kernel (ADC line rerank, stage a7) ------------------------------------
-    # algorithmic bytes per launch = sum over queries of: LP*4 B code row + 4 B id read + 4 B distance write per
-    # candidate, + the query's L1virt table (LP*C1*4 B) staged to LDS.  (DESIGN.md "bytes")
+    # ---- roofline of the dominant kernel (largest mean launch duration over the timed steps) ---------------------
+    # algorithmic bytes per launch (SURVEY.md 8d per-unit figures x the units one launch processes):
+    #   traversal  (a1-a6): query 4D + L1virt out 4*LP*C1 + heuristic rows 16*Bb + bin probes 2*16*Bb
+    #                       + candidate ids in/out 8*nCand                                   per query
+    #   rerank+sel (a7-a8): code rows 4*LP*nCand + candidate ids 4*nCand + L1virt in 4*LP*C1 + results 8*k per query
     LP, C1 = w["LP"], w["C1"]
-    rr_bytes = cand_local * (4 * LP + 8) + qn * LP * C1 * 4
-    rr_ms = float(np.mean(rerank_ms)) if rerank_ms else float("nan")
+    fused_rs = args.k <= 128
+    bytes_trav = qn * (4 * w["D"] + 4 * LP * C1 + 48 * bins_visited) + 8 * cand_local
+    bytes_rs = cand_local * (4 * LP + 4 + (0 if fused_rs else 4)) + qn * (4 * LP * C1 + 8 * k)
+    kern = {"traverse": ("pqt_k_traverse", bytes_trav), "rerank_select": ("pqt_k_rerank_select" if fused_rs else "pqt_k_rerank", bytes_rs)}
+    dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
+    rr_name, rr_bytes = kern[dominant]
+    rr_ms = float(stage[dominant])
     rr_gbs = rr_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
     # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k
     path_bytes_q = 4 * w["D"] + 8 * bins_visited + 4 * ncand_mean + 4 * LP * ncand_mean + 8 * k
-    dominant = max(stage, key=stage.get)
 
     out = {
         "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
@@ -306,10 +306,13 @@ def main():
                    "mean_bins_visited": bins_visited, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
                    "algorithmic_bytes_per_query": path_bytes_q,
                    "path_GBps": path_bytes_q * qps / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qps / 1e9 / HBM_PEAK_GBS,
-                   "stage_ms": stage, "dominant_stage_by_time": dominant},
-        "roofline": {"bound": "hbm", "kernel": "pqt_k_rerank", "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "stage_ms": stage, "dominant_kernel_by_time": rr_name},
+        "roofline": {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": rr_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": rr_ms,
-                     "algorithmic_bytes_per_launch": rr_bytes},
+                     "algorithmic_bytes_per_launch": rr_bytes,
+                     "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
+                                                      "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}
+                                       for n_ in kern if n_ != dominant}},
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------

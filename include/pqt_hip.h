@@ -184,6 +184,9 @@ int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* duration (ms) of each launch of the dominant kernel (rerank) in the last call, via HIP events on the
  * stream it ran on; returns the number of launches written (<= cap). */
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
+/* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][4] = {tables, traversal/bins,
+ * rerank(+select when fused), select} in ms, from HIP events recorded on the launch stream; returns n (<= cap). */
+int pqt_get_stage_ms_history(const pqt_index* idx, float* out_ms, int cap);
 
 /* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------
  * computed ON THE DEVICE by a one-thread kernel, so they pin the kernels' arithmetic, not the host's. */

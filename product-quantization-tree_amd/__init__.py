@@ -47,7 +47,7 @@ EXPORTS = [
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
-    "pqt_get_rerank_launch_ms", "pqt_dev_triangle",
+    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
     L.pqt_debug_read.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, u32p, u32p, f32p, u32p]
     L.pqt_get_stats.argtypes = [C.c_void_p, C.POINTER(pqt_stats)]
     L.pqt_get_rerank_launch_ms.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.pqt_get_stage_ms_history.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_dev_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_uint16), f32p, C.c_int]
     _LIB = L
     return L
@@ -223,6 +224,12 @@ class PqtIndex:
         s = pqt_stats()
         _chk(self.L.pqt_get_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def stage_ms_history(self, cap=32):
+        """[n][4] per-call device ms of {tables, traversal, rerank(+select), select}, oldest first."""
+        out = np.zeros((cap, 4), np.float32)
+        n = _chk(self.L.pqt_get_stage_ms_history(self.h, _p(out, f32p), cap))
+        return out[:n].copy()
 
     def rerank_launch_ms(self, cap=64):
         out = np.zeros(cap, np.float32)

@@ -28,7 +28,8 @@ uint32_t upow(uint32_t x, uint32_t n) { uint32_t r = 1; for (uint32_t i = 0; i <
 uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
 
 enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_RERANK, EV_SELECT, EV_COUNT };
-constexpr int kMaxChunks = 64;
+constexpr int kMaxChunks = 16;
+constexpr int kRing = 32;        // per-stage event sets of the last kRing query calls
 constexpr int kFusedWaves = 12;
 constexpr int kTravWaves = 4;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
@@ -62,7 +63,8 @@ struct pqt_index {
   // results of the last call
   pqt_stats stats{};
   uint32_t lastQn = 0; uint32_t lastHe = 0;
-  hipEvent_t ev[kMaxChunks][EV_COUNT]{}; int nChunks = 0; bool evCreated = false;
+  hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
+  int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
   int numCUs = 256; bool forceUnfused = false; uint32_t dbg = 0;
 };
@@ -222,7 +224,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     idx->sortCap = (uint64_t)qChunk * sortP2;
   }
   if (!idx->evCreated) {
-    for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) HIPCHK(hipEventCreate(&idx->ev[c][e]));
+    for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) HIPCHK(hipEventCreate(&idx->evRing[r][c][e]));
     idx->evCreated = true;
   }
   HIPCHK(hipMemsetAsync(idx->d_counters, 0, 8 * sizeof(unsigned long long), st));
@@ -258,13 +260,16 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 #undef PQT_ALLOW_RS
   }
   idx->nChunks = nChunks;
+  idx->ringPos = (int)(idx->calls % kRing);
+  idx->ringChunks[idx->ringPos] = nChunks;
+  idx->calls++;
   for (int c = 0; c < nChunks; ++c) {
     const uint32_t q0 = (uint32_t)c * qChunk;
     const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
-    HIPCHK(hipEventRecord(idx->ev[c][EV_BEGIN], st));
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BEGIN], st));
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
-      HIPCHK(hipEventRecord(idx->ev[c][EV_TABLES], st));
+      HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
 #define PQT_LAUNCH_TR(WCR)                                                                                              \
       hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, false>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
@@ -277,7 +282,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
                        idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_counters);
-    HIPCHK(hipEventRecord(idx->ev[c][EV_TABLES], st));
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
     if (idx->sharded)
       hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                          idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
@@ -289,7 +294,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                          idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
                          stride, idx->d_counters);
     }
-    HIPCHK(hipEventRecord(idx->ev[c][EV_BINS], st));
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BINS], st));
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {
@@ -310,7 +315,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       }
 #undef PQT_LAUNCH_RS2
 #undef PQT_LAUNCH_RS
-      HIPCHK(hipEventRecord(idx->ev[c][EV_RERANK], st));
+      HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     } else {
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
@@ -320,7 +325,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       hipLaunchKernelGGL(pqt_k_rerank<1>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
                          idx->d_nLocal + q0, stride, d);
-    HIPCHK(hipEventRecord(idx->ev[c][EV_RERANK], st));
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     if (fullSort) {
       if (idx->sharded)
         hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
@@ -337,7 +342,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                            idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
     }
     }
-    HIPCHK(hipEventRecord(idx->ev[c][EV_SELECT], st));
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_SELECT], st));
   }
   if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
@@ -407,7 +412,7 @@ void pqt_index_destroy(pqt_index* idx) {
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (idx->evCreated) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->ev[c][e]);
+  if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
   delete idx;
 }
@@ -718,18 +723,37 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   }
   for (int ch = 0; ch < idx->nChunks; ++ch) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BEGIN], idx->ev[ch][EV_TABLES]) == hipSuccess) s.ms_tables += ms;
-    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_TABLES], idx->ev[ch][EV_BINS]) == hipSuccess) s.ms_bins += ms;
-    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BINS], idx->ev[ch][EV_RERANK]) == hipSuccess) s.ms_rerank += ms;
-    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_RERANK], idx->ev[ch][EV_SELECT]) == hipSuccess) s.ms_select += ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BEGIN], idx->evRing[idx->ringPos][ch][EV_TABLES]) == hipSuccess) s.ms_tables += ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_TABLES], idx->evRing[idx->ringPos][ch][EV_BINS]) == hipSuccess) s.ms_bins += ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BINS], idx->evRing[idx->ringPos][ch][EV_RERANK]) == hipSuccess) s.ms_rerank += ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_RERANK], idx->evRing[idx->ringPos][ch][EV_SELECT]) == hipSuccess) s.ms_select += ms;
   }
   if (idx->nChunks > 0) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->ev[0][EV_BEGIN], idx->ev[idx->nChunks - 1][EV_SELECT]) == hipSuccess) s.ms_total = ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][0][EV_BEGIN], idx->evRing[idx->ringPos][idx->nChunks - 1][EV_SELECT]) == hipSuccess) s.ms_total = ms;
   }
   idx->stats = s;
   *out = s;
   return PQT_OK;
+}
+
+int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
+  if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
+  if (hipSetDevice(idx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(PQT_ERR_DEVICE, "sync failed");
+  const int have = (int)std::min<unsigned long long>(idx->calls, (unsigned long long)kRing);
+  const int n = std::min(have, cap);
+  for (int i = 0; i < n; ++i) {
+    // oldest of the n most recent calls first
+    const int slot = (int)((idx->calls - n + i) % kRing);
+    float st[4] = {0, 0, 0, 0};
+    for (int ch = 0; ch < idx->ringChunks[slot]; ++ch) {
+      float ms = 0;
+      for (int e = 0; e < 4; ++e)
+        if (hipEventElapsedTime(&ms, idx->evRing[slot][ch][e], idx->evRing[slot][ch][e + 1]) == hipSuccess) st[e] += ms;
+    }
+    for (int e = 0; e < 4; ++e) out[i * 4 + e] = st[e];
+  }
+  return n;
 }
 
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
@@ -738,7 +762,7 @@ int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
   int n = 0;
   for (int ch = 0; ch < idx->nChunks && n < cap; ++ch) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->ev[ch][EV_BINS], idx->ev[ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BINS], idx->evRing[idx->ringPos][ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
     out[n++] = ms;
   }
   return n;
