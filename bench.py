@@ -9,10 +9,14 @@ rerank -> top-k) over one batch of QN synthetic SIFT-shaped queries, inputs and 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU (--gpus N > 1): the database is range-sharded by vector id over the N ranks (each rank owns
-a slice of the bin/line store), every rank runs the traversal for the whole batch, reranks its own slice and the
-per-shard top-k lists are merged after ONE RCCL all-gather (SURVEY.md 8e / BASELINE.json north_star).  The
-database size is fixed as N grows => "scaling": "strong".
+Multi-GPU (--gpus N > 1), one process per GPU.  Two ways the path shards:
+  * default for this workload (the 1 M-vector index is 70 MB, it fits every GPU): queries are the units -- every rank
+    holds the whole index and answers its own batch of QN queries; no data-path collective; per-GPU work is fixed
+    as N grows => "scaling": "weak", value = N*QN*steps / time.
+  * --shard-db (the north-star layout for databases that do not fit one GPU, SIFT1B): the database is range-sharded
+    by vector id, every rank runs the traversal for the whole batch, reranks its own slice, and the per-shard top-k
+    lists are merged after ONE RCCL all-gather => "scaling": "strong", value = QN*steps / time.  A short leg in this
+    layout also runs after the default one and is reported as config.db_sharded (never as `value`).
 """
 import argparse
 import importlib
@@ -168,6 +172,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard-db", action="store_true", help="multi-GPU: range-shard the database instead of the queries")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
     ap.add_argument("--centers", type=int, default=GEN["n_centers"])
@@ -183,8 +188,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("PQT_BENCH_BACKEND", "nccl")  # "gloo" + PQT_BENCH_SAME_DEVICE=1: functional check on a 1-GPU box
+        if os.environ.get("PQT_BENCH_SAME_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -193,9 +204,9 @@ def main():
     pkg.lib()  # fails loudly if the HIP library is missing
     w = WORKLOADS[args.workload]
     n = w["n_base"]
-    shard = None
-    if world > 1:
-        shard = importlib.import_module("product-quantization-tree_amd.sharding").shard_range(rank, world, n)
+    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
+    mode = "single" if world == 1 else ("shard_db" if args.shard_db else "replica")
+    shard = sharding.shard_range(rank, world, n) if mode == "shard_db" else None
     idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
     t0 = time.time()
     idx.build_heuristic(max(args.bb, 1))
@@ -210,7 +221,7 @@ def main():
         pick = torch.randint(0, n, (qn,), generator=g, device=dev)
         queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
     else:  # fresh draws from the same mixture (like SIFT's separate query set)
-        queries = sift_like(qn, w["D"], 0xC0DE03, dev)
+        queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
     gt = brute_force_gt(base, queries, 1)[:, 0]
     del base
     torch.cuda.empty_cache()
@@ -220,13 +231,12 @@ def main():
     out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
     out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
-    if world > 1:
+    if mode == "shard_db":
         sbuf = sharding.ShardBuffers(world, qn, k, dev)
         engine = sharding.PqtShardEngine(idx)
 
     def step():
-        if world == 1:
+        if mode != "shard_db":
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
         else:
             # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
@@ -274,7 +284,12 @@ def main():
     bins_visited = st["bins_visited"] / max(1, st["queries"])
 
     ms_per_step = elapsed / args.steps * 1e3
-    qps = qn * args.steps / elapsed
+    units = qn * (world if mode == "replica" else 1)  # queries answered by the whole job per step
+    qps = units * args.steps / elapsed
+    if world > 1:  # job-wide recall / candidate statistics (outside the timed region)
+        agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        r1, r10, r100, ncand_mean = (agg / world).tolist()
 
     # ---- roofline of the dominant kernel (largest mean launch duration over the timed steps) ---------------------
     # algorithmic bytes per launch (SURVEY.md 8d per-unit figures x the units one launch processes):
@@ -296,12 +311,14 @@ def main():
     out = {
         "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
         "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if mode == "shard_db" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "SIFT1M-shape synthetic: N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
                                "query(boundVectors=%d, boundBins=%d), k=%d" %
                                (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
-                   "parallelism": "1 GPU" if world == 1 else "db range-sharded x%d + RCCL all-gather top-k" % world,
+                   "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
+                                   "shard_db": "%d GPUs: db range-sharded + one RCCL all-gather of per-shard top-k" % world}[mode],
+                   "global_batch": units,
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
                    "mean_bins_visited": bins_visited, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
                    "algorithmic_bytes_per_query": path_bytes_q,
@@ -316,7 +333,7 @@ def main():
     }
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
-    if world == 1 and not args.no_cpu:
+    if mode == "single" and not args.no_cpu:
         from oracle import Oracle
         o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=1)
         o.set_heuristic(idx.heuristic(max(args.bb, 1)))
@@ -346,6 +363,38 @@ def main():
                                          % (sample, qn),
                                "single_thread_qps": s1 / cpu1_t, "single_thread_ms_per_query": cpu1_t / s1 * 1e3,
                                "topk_sets_identical_frac": same}
+    # ---- north-star layout on the same job (short leg, never the headline value) ----------------------------------
+    if mode == "replica":
+        try:
+            idx.close()
+            del idx
+            torch.cuda.empty_cache()
+            sidx, sbase, smeta = build_index(pkg, w, local_rank, shard=sharding.shard_range(rank, world, n))
+            del sbase
+            sidx.build_heuristic(max(args.bb, 1))
+            squeries = sift_like(qn, w["D"], 0xC0DE03, dev)  # the SAME batch on every rank
+            sbuf = sharding.ShardBuffers(world, qn, k, dev)
+            engine = sharding.PqtShardEngine(sidx)
+            for _ in range(2):
+                sharding.sharded_query(engine, dist, world, squeries, args.bv, args.bb, k, sbuf)
+            barrier()
+            ts = time.perf_counter()
+            nstep = max(3, min(args.steps, 10))
+            for _ in range(nstep):
+                sharding.sharded_query(engine, dist, world, squeries, args.bv, args.bb, k, sbuf)
+            barrier()
+            tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+            # every rank must hold the same merged result
+            chk = sbuf.out_idx.to(torch.int64).sum().reshape(1)
+            lo, hi = chk.clone(), chk.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            out["config"]["db_sharded"] = {"queries_per_sec": qn * nstep / float(tsh.item()), "ms_per_step": float(tsh.item()) / nstep * 1e3,
+                                           "scaling": "strong", "ranks_agree": bool(lo.item() == hi.item()),
+                                           "layout": "db range-sharded x%d, replicated traversal, one RCCL all-gather of [3][QN][k] words, exact merge" % world}
+        except Exception as e:  # the headline measurement above stands on its own
+            out["config"]["db_sharded"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
