@@ -280,6 +280,8 @@ def main():
     ids_t = out_idx.to(torch.int64) & 0xffffffff
     r1, r10, r100 = recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100)
     ncand_mean = float(out_cnt.to(torch.int64).float().mean())
+    cq = torch.quantile(out_cnt.to(torch.float32), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
+    log("[bench] candidates per query: median %.0f p90 %.0f p99 %.0f max %.0f" % tuple(cq))
     cand_local = st["candidates"]  # local candidates reranked on this rank in the last step
     bins_visited = st["bins_visited"] / max(1, st["queries"])
 

@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libpqt_hip.so")
+LIB_PATH = os.environ.get("PQT_LIB") or os.path.join(CSRC, "libpqt_hip.so")  # PQT_LIB: tuning builds only
 _LIB = None
 
 u32p = C.POINTER(C.c_uint32)

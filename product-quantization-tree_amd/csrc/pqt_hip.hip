@@ -30,7 +30,10 @@ uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
 enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_RERANK, EV_SELECT, EV_COUNT };
 constexpr int kMaxChunks = 16;
 constexpr int kRing = 32;        // per-stage event sets of the last kRing query calls
-constexpr int kFusedWaves = 12;
+#ifndef PQT_RS_NW
+#define PQT_RS_NW 8
+#endif
+constexpr int kFusedWaves = PQT_RS_NW;
 constexpr int kTravWaves = 4;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
 }  // namespace
@@ -188,6 +191,42 @@ int allowLds(K kernel, size_t bytes) {
   return PQT_OK;
 }
 
+// ---- fused rerank+select launcher: picks the instantiation for (LP, coarse-in-LDS, sharded) -------------------
+#ifndef PQT_RS_U16
+#define PQT_RS_U16 4   // candidates per lane in flight when LP = 16 (scaled so that U * LP/4 stays 16 code vectors)
+#endif
+template <int LPV, bool CL, bool SH>
+int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
+             uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  constexpr int U0 = (PQT_RS_U16 * 4) / LPV;
+  constexpr int UV = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
+  const uint32_t c1 = idx->dp.C1;
+  const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
+  auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, true> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, false>;
+  int rc = allowLds(kern, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codes, idx->idBase, qL1virt, idx->d_coarse,
+                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg);
+  return PQT_OK;
+}
+template <int LPV>
+int launchRS1(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
+              uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  if (cl) return idx->sharded ? launchRS<LPV, true, true>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP)
+                              : launchRS<LPV, true, false>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+  return idx->sharded ? launchRS<LPV, false, true>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP)
+                      : launchRS<LPV, false, false>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+}
+int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
+                       uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  switch (idx->dp.LP / 4) {
+    case 1: return launchRS1<1>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+    case 2: return launchRS1<2>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+    case 4: return launchRS1<4>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+    default: return launchRS1<8>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
+  }
+}
+
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
               uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
   if (!idx) return fail(PQT_ERR_INVALID, "null index");
@@ -238,7 +277,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 
   // fused traversal (wave per query) when the bin list fits the in-register sorter
   const bool travFused = (He <= 512) && (d.WC <= 256) && !idx->sharded && !idx->forceUnfused;
-  const uint32_t travPerWave = (uint32_t)((512 * 8 + 4 * (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P * d.W + 3 * d.P * d.WC) + 15) & ~(size_t)15);
+  const size_t travR0 = (std::max<size_t>(512 * 8, 4 * (size_t)(d.LP * d.C1 + d.P * d.WC)) + 15) & ~(size_t)15;
+  const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.D + d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
   const size_t lTrav = (size_t)kTravWaves * travPerWave;
   if (travFused) {
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false>, lTrav))) return rc;
@@ -250,15 +290,6 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
   const bool coarseLds = coarseBytes <= 64 * 1024;
   const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4);
-  if (fused) {
-#define PQT_ALLOW_RS(LPV)                                                                                          \
-    do { if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, true, true>, lFused))) return rc;               \
-         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, true, false>, lFused))) return rc;              \
-         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, false, true>, lFused))) return rc;              \
-         if ((rc = allowLds(pqt_k_rerank_select<kFusedWaves, LPV, false, false>, lFused))) return rc; } while (0)
-    switch (d.LP / 4) { case 1: PQT_ALLOW_RS(1); break; case 2: PQT_ALLOW_RS(2); break; case 4: PQT_ALLOW_RS(4); break; default: PQT_ALLOW_RS(8); break; }
-#undef PQT_ALLOW_RS
-  }
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -300,21 +331,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (fused) {
       // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
       const uint32_t grid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
-#define PQT_LAUNCH_RS(LPV, CL, SH)                                                                                         \
-      hipLaunchKernelGGL((pqt_k_rerank_select<kFusedWaves, LPV, CL, SH>), dim3(grid), dim3(kFusedWaves * 64), lFused, st, \
-                         idx->d_codes, idx->idBase, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, \
-                         idx->d_candPos, idx->d_nLocal + q0, stride, k, nq, d, oI, oD, oP, idx->d_counters, idx->dbg)
-#define PQT_LAUNCH_RS2(LPV)                                                                                                \
-      do { if (coarseLds) { if (idx->sharded) PQT_LAUNCH_RS(LPV, true, true); else PQT_LAUNCH_RS(LPV, true, false); }     \
-           else { if (idx->sharded) PQT_LAUNCH_RS(LPV, false, true); else PQT_LAUNCH_RS(LPV, false, false); } } while (0)
-      switch (d.LP / 4) {
-        case 1: PQT_LAUNCH_RS2(1); break;
-        case 2: PQT_LAUNCH_RS2(2); break;
-        case 4: PQT_LAUNCH_RS2(4); break;
-        default: PQT_LAUNCH_RS2(8); break;
-      }
-#undef PQT_LAUNCH_RS2
-#undef PQT_LAUNCH_RS
+      if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
+                                   stride, k, nq, oI, oD, oP))) return rc;
       HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     } else {
     if (d.LP % 4 == 0)

@@ -632,7 +632,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #define PQT_RS_BEST 128
 #define PQT_RS_PEND 384
 
-template <int NW, int LPV, bool COARSE_LDS, bool SHARDED>
+template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, bool C1P2>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     const uint32_t* __restrict__ codes, uint64_t idBase, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
@@ -641,10 +641,11 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     unsigned long long* __restrict__ counters, uint32_t dbg) {
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
-  constexpr int U = (16 / LPV) > 8 ? 8 : (16 / LPV);
+  constexpr int U = UREQ;
   constexpr uint32_t LP = LPV * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t C1 = prm.C1;
+  const uint32_t c1sh = C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u;  // power-of-two C1: shifts instead of quarter-rate multiplies
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -691,6 +692,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + u * 64 + lane;
           id[u] = cid[j < n ? j : n - 1];
+          if (dbg & 8) id[u] = (uint32_t)idBase + ((q * 977u + j) & 0xfffffu) % 1000000u;  // debug: sequential rows (results wrong)
+          if (dbg & 16) id[u] = (uint32_t)idBase + (j & 1023u);                           // debug: L1/L2-resident rows
         }
         uint4 rows[U][LPV];
 #pragma unroll
@@ -711,10 +714,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
             for (int x = 0; x < 4; ++x) {
               const uint32_t p = v * 4 + x;
               const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
-              const float lam = pqt_lambda_decode(w[x] >> 16);
-              const float sb = sVirt[p * C1 + A];
-              const float sa = sVirt[p * C1 + B];
-              const float sc = cz[(p * C1 + A) * C1 + B];
+              const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
+              const float sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
+              const float sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
+              const float sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
               acc = acc + pqt_extract_distance(sa, sb, sc, lam);
             }
           }
@@ -769,7 +772,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 // LDS per wavefront: D + LP*C1 + P*C1 + P*W + 3*P*WC words + 512 * 8 bytes.
 // ===================================================================================================
 template <int NW, int WCR, bool SHARDED>
-__global__ __launch_bounds__(NW * 64) void pqt_k_traverse(
+#ifndef PQT_TR_WPS
+#define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for (66 VGPRs, no spills)
+#endif
+__global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2, PqtDevParams prm,
     const uint4* __restrict__ heur8 /* rows of 8 x u16 */, uint32_t He, uint32_t Bv, const PqtBinEntry* __restrict__ table,
     const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids, uint32_t qn,
@@ -784,14 +790,16 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_traverse(
   const uint32_t q = blockIdx.x * NW + wave;
   if (q >= qn) return;
   unsigned char* base = smem_raw + (size_t)wave * perWaveBytes;
+  // region0 is time-shared: L1virt + unsorted d2 (a1/a2), then the per-row bin records and the compact bin list (a4-a6)
+  const uint32_t r0Bytes = perWaveBytes - 4 * (D + P * C1 + P * W + 2 * P * WC);
   uint64_t* sBin = (uint64_t*)base;                 // 512 : (gcount | lstart<<32) by row, later the compact bin list
-  float* sQ = (float*)(sBin + 512);                 // D
-  float* sVirt = sQ + D;                            // LP*C1
-  float* sL1 = sVirt + LP * C1;                     // P*C1
+  float* sVirt = (float*)base;                      // LP*C1     (dead before sBin is written)
+  float* sD2 = sVirt + LP * C1;                     // P*WC unsorted staging (dead before sBin is written)
+  float* sQ = (float*)(base + r0Bytes);             // D
+  float* sL1 = sQ + D;                              // P*C1
   uint32_t* sOrd = (uint32_t*)(sL1 + P * C1);       // P*W
-  float* sSegD = (float*)(sOrd + P * W);            // P*WC (first unsorted d2, then sorted)
-  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);    // P*WC
-  float* sD2 = (float*)(sSegB + P * WC);            // P*WC unsorted staging
+  float* sSegD = (float*)(sOrd + P * W);            // P*WC sorted d2
+  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);    // P*WC sorted bin parts (pre-multiplied)
 
   PQT_TS(0);
   for (uint32_t i = lane; i < D; i += 64) sQ[i] = Q[(size_t)q * D + i];

@@ -1,4 +1,4 @@
-for d in 0 1 2 3 4 7; do
+for d in 0 8 16 1 17; do
   echo -n "dbg $d: "
   PQT_DBG=$d python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import json,sys
