@@ -138,6 +138,14 @@ int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t 
 int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n,
                             uint32_t* out_bin_dev, uint32_t* out_codes_dev, void* hip_stream);
 
+/* E step of the reference's k-means (productquantizer.hpp:40-66 getAssignment, vectorquantizer.hpp:33-53): nearest of
+ * `ncen` centroids (rows of cen_dev, stride cen_ld) for n rows of x_dev (stride ld, optionally gathered through
+ * rows_dev[n]) over `dim` dims; squared distances summed left to right, first minimum wins.  The M step (sequential
+ * sums) stays on the host, which makes the whole training bit-reproducible (host/pqt/PerturbationProTree.cpp createTree). */
+int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, uint32_t ld, const uint32_t* rows_dev,
+                      const float* cen_dev, uint32_t ncen, uint32_t cen_ld, uint32_t* out_assign_dev, float* out_dist_dev,
+                      void* hip_stream);
+
 /* ---- query ----------------------------------------------------------------------------------------
  * replaces: treequantizer::query(boundVectors, boundBins, vec, out) (treequantizer.hpp:323-350) for a
  * batch, / PerturbationProTree::queryKNN(resIdx,resDist,Q,QN,nVec) (PerturbationProTree.hh:72).

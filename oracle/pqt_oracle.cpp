@@ -364,9 +364,9 @@ struct Oracle {
 // k-means by centroid splitting (offline; "next" row of SURVEY §8f).  Restates
 // productquantizer.hpp:40-158 and vectorquantizer.hpp:33-146.
 // ------------------------------------------------------------------------------------------
-static void pq_generate(uint D, uint P, uint C, const float* const* vecs, size_t n, float* cen /*C*D*/) {
+static void pq_generate(uint D, uint P, uint C, const float* const* vecs, size_t n, float* cen /*C*D*/, std::vector<uint8_t>& mapping) {
   const uint S = D / P;
-  std::vector<uint8_t> mapping(n * P, 0);
+  mapping.assign(n * P, 0);
   std::vector<float> dist(n * P, 0.f);
   std::fill(cen, cen + (size_t)C * D, 0.f);
   // iterator::center() (iterator/iterator.hpp:41-53)
@@ -513,19 +513,9 @@ void pqo_train(void* h, const float* data, unsigned long long n) {
   std::vector<const float*> vecs(n);
   for (size_t i = 0; i < n; ++i) vecs[i] = data + i * D;
   o->cb1.assign((size_t)C1 * D, 0.f);
-  pq_generate(D, P, C1, vecs.data(), n, o->cb1.data());
-  // final assignment = the mapping left by the last E step; recompute it (same rule) for grouping (:140-147)
-  std::vector<uint8_t> mapping(n * P);
-#pragma omp parallel for schedule(static)
-  for (long long i = 0; i < (long long)n; ++i)
-    for (uint p = 0; p < P; ++p) {
-      uint best = 0; float bd = HUGE_VALF;
-      for (uint c = 0; c < C1; ++c) {
-        const float d = sqdist_seq(vecs[i] + p * S, &o->cb1[(size_t)c * D + p * S], S);
-        if (d < bd) { bd = d; best = c; }
-      }
-      mapping[i * P + p] = (uint8_t)best;
-    }
+  // grouping uses _PQ->_mapping, i.e. the assignment left by the LAST E step (treequantizer.hpp:140-147)
+  std::vector<uint8_t> mapping;
+  pq_generate(D, P, C1, vecs.data(), n, o->cb1.data(), mapping);
   o->cb2.assign((size_t)P * C1 * C2 * S, 0.f);
 #pragma omp parallel for schedule(dynamic) collapse(2)
   for (uint p = 0; p < P; ++p)

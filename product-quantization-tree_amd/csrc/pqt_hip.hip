@@ -639,6 +639,21 @@ int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n, u
   return PQT_OK;
 }
 
+int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, uint32_t ld, const uint32_t* rows_dev,
+                       const float* cen_dev, uint32_t ncen, uint32_t cen_ld, uint32_t* out_assign_dev, float* out_dist_dev,
+                       void* stream) {
+  if (!x_dev || !cen_dev || !out_assign_dev || !out_dist_dev || !dim || !ncen) return fail(PQT_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(device));
+  const size_t lds = (size_t)ncen * dim * 4;
+  int rc = allowLds(pqt_k_kmeans_assign, lds);
+  if (rc) return rc;
+  if (n) hipLaunchKernelGGL(pqt_k_kmeans_assign, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, (hipStream_t)stream, x_dev, n, dim, ld,
+                            rows_dev, cen_dev, ncen, cen_ld, out_assign_dev, out_dist_dev);
+  HIPCHK(hipGetLastError());
+  if (!stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return PQT_OK;
+}
+
 int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
               float* outDist, uint32_t* outCount, void* stream, int sync) {
   if (idx && idx->sharded) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard + pqt_merge_topk");

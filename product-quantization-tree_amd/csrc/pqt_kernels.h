@@ -993,3 +993,30 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   PQT_TS(8);
 #undef PQT_TS
 }
+
+// ---------------------------------------------------------------------------------------------------
+// offline ("next" row 8f-3): E step of the reference's Lloyd iterations (productquantizer.hpp:40-66,
+// vectorquantizer.hpp:33-53): for every row the nearest of ncen centroids over `dim` dims, squared distance
+// summed left to right, first minimum wins (strict '<').  lane = one row; centroids staged in LDS.
+// rows (optional) selects/gathers the rows (group(), treequantizer.hpp:140-147).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pqt_k_kmeans_assign(
+    const float* __restrict__ x, uint64_t n, uint32_t dim, uint32_t ld, const uint32_t* __restrict__ rows,
+    const float* __restrict__ cen, uint32_t ncen, uint32_t cenLd, uint32_t* __restrict__ outAssign,
+    float* __restrict__ outDist) {
+  extern __shared__ __attribute__((aligned(16))) float sCen[];  // ncen * dim
+  for (uint32_t t = threadIdx.x; t < ncen * dim; t += 256) sCen[t] = cen[(size_t)(t / dim) * cenLd + t % dim];
+  __syncthreads();
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* xr = x + (size_t)(rows ? rows[i] : i) * ld;
+  uint32_t best = 0;
+  float bd = __uint_as_float(0x7f800000u);  // HUGE_VAL
+  for (uint32_t c = 0; c < ncen; ++c) {
+    float s = 0.f;
+    for (uint32_t d = 0; d < dim; ++d) { const float df = xr[d] - sCen[c * dim + d]; s = s + df * df; }
+    if (s < bd) { bd = s; best = c; }
+  }
+  outAssign[i] = best;
+  outDist[i] = bd;
+}

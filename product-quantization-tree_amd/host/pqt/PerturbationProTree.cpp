@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <fstream>
 #include <map>
 #include <stdexcept>
@@ -43,6 +44,143 @@ void PerturbationProTree::setTree(uint _c1, uint _c2, const float* _cb1, const f
   check(pqt_index_create(&prm, d_device, &d_idx), "pqt_index_create");
   check(pqt_index_set_codebooks(d_idx, h_codeBook.data(), h_codeBook2.data()), "pqt_index_set_codebooks");
   d_heurRows = 0;
+}
+
+namespace {
+// device buffer with RAII
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  explicit DevBuf(size_t n) { if (hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) throw std::runtime_error("device allocation failed"); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf(const DevBuf&) = delete;
+};
+void h2d(void* d, const void* h, size_t b) { if (b && hipMemcpy(d, h, b, hipMemcpyHostToDevice) != hipSuccess) throw std::runtime_error("H2D copy failed"); }
+void d2h(void* h, const void* d, size_t b) { if (b && hipMemcpy(h, d, b, hipMemcpyDeviceToHost) != hipSuccess) throw std::runtime_error("D2H copy failed"); }
+
+// Lloyd iterations with centroid splitting on `dim` dims of the rows selected by `rows` (all rows if empty):
+// restates productquantizer::generate for ONE part / vectorquantizer::generate (same schedule, see callers).
+struct SplitKMeans {
+  int device; const float* xDev; const float* xHost; uint32_t ld; uint32_t dim; uint32_t off;  // column window [off, off+dim)
+  std::vector<uint32_t> rows; const uint32_t* rowsDev; size_t n;
+  // E step on the device: assignment + distance of every selected row to the first `step` centroids
+  void estep(const std::vector<float>& cen, uint32_t step, std::vector<uint32_t>& asg, std::vector<float>& dist,
+             DevBuf<float>& dCen, DevBuf<uint32_t>& dAsg, DevBuf<float>& dDist) const {
+    if (!n) return;
+    h2d(dCen.p, cen.data(), (size_t)step * dim * 4);
+    if (pqt_kmeans_assign(device, xDev + off, n, dim, ld, rowsDev, dCen.p, step, dim, dAsg.p, dDist.p, nullptr) != PQT_OK)
+      throw std::runtime_error(std::string("pqt_kmeans_assign: ") + pqt_last_error());
+    d2h(asg.data(), dAsg.p, n * 4);
+    d2h(dist.data(), dDist.p, n * 4);
+  }
+  const float* row(size_t i) const { return xHost + (size_t)(rows.empty() ? i : rows[i]) * ld + off; }
+};
+}  // namespace
+
+void PerturbationProTree::createTree(uint _k, uint _k2, const float* _A, uint _N) {
+  if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+  const uint D = d_dim, P = d_p, S = D / P, C1 = _k, C2 = _k2;
+  if (!C1 || (C1 & 1) || C1 > 256 || !C2 || (C2 > 1 && (C2 & 1)) || C2 > 256) throw std::runtime_error("createTree: cluster counts must be even (or C2 == 1) and <= 256");
+  DevBuf<float> dX((size_t)_N * D);
+  h2d(dX.p, _A, (size_t)_N * D * 4);
+  DevBuf<float> dCen((size_t)256 * std::max(S, 1u));
+  DevBuf<uint32_t> dAsg(_N); DevBuf<float> dDist(_N); DevBuf<uint32_t> dRows(_N);
+  std::vector<float> cb1((size_t)C1 * D, 0.f), cb2((size_t)P * C1 * C2 * S, 0.f);
+  std::vector<uint32_t> asg(_N); std::vector<float> dist(_N);
+  std::vector<std::vector<uint32_t> > assign1(P, std::vector<uint32_t>(_N, 0));
+
+  // ---- level 1: productquantizer::generate (productquantizer.hpp:131-158).  The reference runs all parts inside one
+  // loop with a COMMON loss (sum over parts); the parts only interact through that stopping test, so they are iterated
+  // together here as well.
+  {
+    std::vector<std::vector<float> > cen(P, std::vector<float>((size_t)C1 * S, 0.f));
+    std::vector<std::vector<uint32_t> > a(P, std::vector<uint32_t>(_N, 0));
+    std::vector<std::vector<float> > dd(P, std::vector<float>(_N, 0.f));
+    // iterator::center(): mean of all vectors (iterator/iterator.hpp:41-53), sequential sums
+    for (uint p = 0; p < P; ++p) {
+      std::vector<float> avg(S, 0.f);
+      for (uint i = 0; i < _N; ++i) for (uint d = 0; d < S; ++d) avg[d] += _A[(size_t)i * D + p * S + d];
+      for (uint d = 0; d < S; ++d) cen[p][d] = avg[d] / (float)_N;
+    }
+    uint step = 1;
+    float cur = 0.f, last = 0.f;
+    do {
+      uint run = 1000;
+      for (uint p = 0; p < P; ++p)  // augmentCentroids (:97-103)
+        for (uint i = 0; i < step; ++i) for (uint d = 0; d < S; ++d) {
+          cen[p][(size_t)(i + step) * S + d] = cen[p][(size_t)i * S + d] + 0.001f;
+          cen[p][(size_t)i * S + d] = cen[p][(size_t)i * S + d] - 0.001f;
+        }
+      step *= 2;
+      do {
+        last = cur;
+        for (uint p = 0; p < P; ++p) {
+          SplitKMeans km{d_device, dX.p, _A, D, S, p * S, {}, nullptr, _N};
+          km.estep(cen[p], step, a[p], dd[p], dCen, dAsg, dDist);  // getAssignment (:40-66)
+          // updateCentroids (:74-91): zero everything, sequential sums in vector order, divide non-empty
+          std::fill(cen[p].begin(), cen[p].end(), 0.f);
+          std::vector<float> cnt(C1, 0.f);
+          for (uint i = 0; i < _N; ++i) {
+            const uint c = a[p][i];
+            for (uint d = 0; d < S; ++d) cen[p][(size_t)c * S + d] += _A[(size_t)i * D + p * S + d];
+            cnt[c] += 1.f;
+          }
+          for (uint c = 0; c < C1; ++c) if (cnt[c] != 0) for (uint d = 0; d < S; ++d) cen[p][(size_t)c * S + d] /= cnt[c];
+        }
+        float sum = 0.f;  // loss (:113-124) over _distances[n*P + p] in index order
+        for (uint i = 0; i < _N; ++i) for (uint p = 0; p < P; ++p) sum += dd[p][i];
+        cur = sum;
+        run--;
+      } while ((std::fabs(last - cur) > 0.005f) && (run > 0));
+    } while (step < C1);
+    for (uint p = 0; p < P; ++p) {
+      for (uint c = 0; c < C1; ++c) for (uint d = 0; d < S; ++d) cb1[(size_t)c * D + p * S + d] = cen[p][(size_t)c * S + d];
+      // grouping uses the mapping of the LAST E step (treequantizer.hpp:140-147 reads _PQ->_mapping)
+      assign1[p] = a[p];
+    }
+  }
+  // ---- level 2: one vectorquantizer per (part, cell) on the segments grouped into that cell (treequantizer.hpp:163-172)
+  for (uint p = 0; p < P; ++p)
+    for (uint c = 0; c < C1; ++c) {
+      SplitKMeans km{d_device, dX.p, _A, D, S, p * S, {}, nullptr, 0};
+      for (uint i = 0; i < _N; ++i) if (assign1[p][i] == c) km.rows.push_back(i);
+      km.n = km.rows.size();
+      h2d(dRows.p, km.rows.data(), km.n * 4);
+      km.rowsDev = dRows.p;
+      std::vector<float> cen((size_t)C2 * S, 0.f);
+      std::vector<uint32_t> a(km.n, 0); std::vector<float> dd(km.n, 0.f);
+      {
+        std::vector<float> avg(S, 0.f);
+        for (size_t i = 0; i < km.n; ++i) for (uint d = 0; d < S; ++d) avg[d] += km.row(i)[d];
+        for (uint d = 0; d < S; ++d) cen[d] = avg[d] / (float)km.n;  // empty cell: NaN, zeroed by the first M step
+      }
+      auto mstep = [&](uint) {
+        std::fill(cen.begin(), cen.end(), 0.f);
+        std::vector<float> cnt(C2, 0.f);
+        for (size_t i = 0; i < km.n; ++i) { const uint cc = a[i]; for (uint d = 0; d < S; ++d) cen[(size_t)cc * S + d] += km.row(i)[d]; cnt[cc] += 1.f; }
+        for (uint cc = 0; cc < C2; ++cc) if (cnt[cc] != 0) for (uint d = 0; d < S; ++d) cen[(size_t)cc * S + d] /= cnt[cc];
+      };
+      uint step = 1;
+      float cur = 0.f, last = 0.f;
+      if (C2 == 1) { km.estep(cen, 1, a, dd, dCen, dAsg, dDist); mstep(1); }
+      else do {
+        for (uint i = 0; i < step; ++i) for (uint d = 0; d < S; ++d) {
+          cen[(size_t)(i + step) * S + d] = cen[(size_t)i * S + d] + 0.001f;
+          cen[(size_t)i * S + d] = cen[(size_t)i * S + d] - 0.001f;
+        }
+        step *= 2;
+        uint guard = 100000;  // the reference has no cap here (vectorquantizer.hpp:137-143)
+        do {
+          last = cur;
+          km.estep(cen, step, a, dd, dCen, dAsg, dDist);
+          mstep(step);
+          float sum = 0.f;
+          for (size_t i = 0; i < km.n; ++i) sum += dd[i];
+          cur = sum;
+        } while ((std::fabs(last - cur) > 0.005f) && --guard);
+      } while (step < C2);
+      std::copy(cen.begin(), cen.end(), cb2.begin() + ((size_t)p * C1 + c) * C2 * S);
+    }
+  setTree(C1, C2, cb1.data(), cb2.data());
 }
 
 void PerturbationProTree::readTreeFromFile(const std::string& _name) {

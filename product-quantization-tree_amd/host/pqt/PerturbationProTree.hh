@@ -80,6 +80,13 @@ class PerturbationProTree : public ProTree {
   /** CPU .bins (treequantizer.hpp:745-774 / 845-893): bins + line codes */
   void loadBins(const std::string& _name);
   void saveBins(const std::string& _name);
+  /** produces a two-layer product quantization tree with _k / _k2 centroids per level from _N training vectors
+   *  (ProTree.hh:82 createTree; algorithm = cpu_version: productquantizer::generate productquantizer.hpp:131-158,
+   *  vectorquantizer::generate vectorquantizer.hpp:117-146, treequantizer::generate treequantizer.hpp:155-177:
+   *  k-means by centroid splitting).  _A is a HOST pointer here.  The E step (nearest centroid of every vector) runs on
+   *  the GPU (pqt_kmeans_assign), the M step (sequential sums) on the host, so the result does not depend on any
+   *  parallel reduction order. */
+  void createTree(uint _k, uint _k2, const float* _A, uint _N);
   /** set the tree from host arrays cb1[C1][dim], cb2[p][C1][C2][dim/p] */
   void setTree(uint _c1, uint _c2, const float* _cb1, const float* _cb2);
 

@@ -28,6 +28,7 @@ int main(int argc, char* argv[]) {
   F.def("basename", "tmp", "prefix for generated data");
   F.def("dataset", "base.umem", "path to vector dataset");
   F.def("w", "2", "first-level cells expanded per part (treequantizer W)");
+  F.def("train", "0", "if > 0 and no codebook exists: createTree on the first <train> vectors (the reference trains on 20000, tool_createdb.cpp:76)");
   if (!F.parse(argc, argv)) return 1;
   try {
     const uint dim = F.num("dim"), p = F.num("p"), c1 = F.num("c1"), c2 = F.num("c2"), lp = F.num("lineparts");
@@ -39,9 +40,18 @@ int main(int argc, char* argv[]) {
     ppt.setW((uint)F.num("w"));
     ppt.prepareEmptyLambda(0, lp);
     const std::string cb = pre + ".ppqt";
-    if (!file_exists(cb)) { std::cout << "you need to generate a codebook first. No codebook found in " << cb << std::endl; return 1; }
-    std::cout << "codebook exists, reading from " << cb << std::endl;
-    ppt.readTreeFromFile(cb);
+    if (!file_exists(cb)) {
+      const size_t nt = std::min<size_t>((size_t)F.num("train"), reader.num());
+      if (nt == 0) { std::cout << "you need to generate a codebook first. No codebook found in " << cb << std::endl; return 1; }
+      std::cout << "building the codebook from " << nt << " vectors" << std::endl;
+      std::vector<float> tr = reader.data(nt);
+      ppt.createTree(c1, c2, tr.data(), (uint)nt);
+      ppt.writeTreeToFile(cb);
+      std::cout << "written " << cb << std::endl;
+    } else {
+      std::cout << "codebook exists, reading from " << cb << std::endl;
+      ppt.readTreeFromFile(cb);
+    }
     if (ppt.getNClusters() != c1 || ppt.getClusters2() != c2) { std::cerr << "codebook c1/c2 differ from flags" << std::endl; return 1; }
     const size_t n = std::min<size_t>(reader.num(), (size_t)F.num("chunksize"));
     std::vector<float> data = reader.data(n);

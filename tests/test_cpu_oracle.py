@@ -223,3 +223,39 @@ def test_invalid_parameters_rejected():
         Oracle(128, 3, 16, 8, 4, 32)  # D % P != 0 (static_assert treequantizer.hpp:23)
     with pytest.raises(ValueError):
         Oracle(128, 2, 4, 8, 5, 32)   # W > C1 (:25)
+
+
+def test_converters_roundtrip(tmp_path):
+    """fvecs / bvecs / ivecs -> .umem / .imem (convert/*.cpp of the reference): header text + payload at byte 20."""
+    import subprocess
+    host = os.path.join(os.path.dirname(G), "..", "product-quantization-tree_amd", "host")
+    for t in ("convert_fvecs", "convert_bvecs", "convert_ivecs"):
+        subprocess.check_call(["make", "-C", host, t], stdout=subprocess.DEVNULL)
+    rng = np.random.default_rng(1)
+    n, d = 37, 24
+
+    def write_vecs(path, arr, dt):
+        with open(path, "wb") as f:
+            for r in arr:
+                f.write(np.int32(d).tobytes())
+                f.write(np.asarray(r, dt).tobytes())
+
+    vals = rng.integers(0, 256, (n, d))
+    write_vecs(tmp_path / "a.fvecs", vals, np.float32)
+    write_vecs(tmp_path / "a.bvecs", vals, np.uint8)
+    ivals = rng.integers(-5, 10 ** 6, (n, d))
+    write_vecs(tmp_path / "a.ivecs", ivals, np.int32)
+    for tool, flag, outflag, ext, dt, want in (("convert_fvecs", "fvecs", "umem", "fu", np.uint8, vals),
+                                               ("convert_bvecs", "bvecs", "umem", "bu", np.uint8, vals),
+                                               ("convert_ivecs", "ivecs", "imem", "ii", np.int32, ivals)):
+        out = str(tmp_path / ("o." + ext))
+        subprocess.check_call([os.path.join(host, tool), "--" + flag, str(tmp_path / ("a." + flag)), "--" + outflag, out,
+                               "--chunkSize", "10"], stdout=subprocess.DEVNULL)
+        raw = open(out, "rb").read()
+        assert raw[:20].rstrip(b"\0") == ("%d\n%d\n" % (n, d)).encode()
+        assert np.array_equal(np.frombuffer(raw[20:], dt).reshape(n, d), want.astype(dt))
+    # a float file that is not uint8-valued must be refused, not silently truncated
+    write_vecs(tmp_path / "b.fvecs", vals + 0.5, np.float32)
+    r = subprocess.run([os.path.join(host, "convert_fvecs"), "--fvecs", str(tmp_path / "b.fvecs"), "--umem", str(tmp_path / "b.umem")],
+                       capture_output=True)
+    assert r.returncode != 0

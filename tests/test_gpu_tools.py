@@ -72,3 +72,33 @@ def test_tool_reports_missing_codebook(tmp_path):
     write_umem("q.umem", np.zeros((2, 128)), np.uint8)
     out = subprocess.run([os.path.join(HOST, "tool_query"), "--queryset", "q.umem", "--basename", "nope"], capture_output=True, text=True)
     assert out.returncode == 1 and "you need to generate a codebook first" in out.stdout
+
+
+def test_createdb_trains_tree_identical_to_oracle(tmp_path):
+    """tool_createdb --train: k-means by centroid splitting (GPU E step, host M step) == the oracle's restatement of
+    productquantizer/vectorquantizer::generate, bit for bit (codebook dump compared as bytes)."""
+    if not os.path.exists(os.path.join(HOST, "tool_createdb")):
+        subprocess.check_call(["make", "-C", HOST])
+    from common import sift_like
+    from oracle import Oracle
+    D, P, C1, C2, LP = 32, 2, 8, 4, 4
+    data = sift_like(3000, D, 123)
+    os.chdir(tmp_path)
+    write_umem("base.umem", data, np.uint8)
+    args = ["--c1", str(C1), "--c2", str(C2), "--p", str(P), "--dim", str(D), "--lineparts", str(LP), "--basename", "tr",
+            "--dataset", "base.umem", "--train", "2000"]
+    out = subprocess.run([os.path.join(HOST, "tool_createdb")] + args, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    raw = open("tr_%d_%d_%d_%d.ppqt" % (D, P, C1, C2), "rb").read()
+    hdr = ("%d\n%d\n%d\n%d\n%d\n%d\n" % (D, P, P, C1, C2, 1)).encode()
+    assert raw.startswith(hdr)
+    body = np.frombuffer(raw[len(hdr):], np.float32)
+    o = Oracle(D, P, C1, C2, 2, LP, heur_keep=16)
+    o.train(data[:2000])
+    cb1, cb2 = o.codebooks()
+    assert np.array_equal(body[:C1 * D].view(np.uint32), cb1.ravel().view(np.uint32))
+    assert np.array_equal(body[C1 * D:].view(np.uint32), cb2.ravel().view(np.uint32))
+    # and the database built with that tree equals the oracle's
+    o.insert(data)
+    o.save_bins("oracle.bins")
+    assert open("tr_%d_%d_%d_%d.bins" % (D, P, C1, C2), "rb").read() == open("oracle.bins", "rb").read()
