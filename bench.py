@@ -310,6 +310,19 @@ def main():
     # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k
     path_bytes_q = 4 * w["D"] + 8 * bins_visited + 4 * ncand_mean + 4 * LP * ncand_mean + 8 * k
 
+    # HBM traffic of the dominant kernel from the committed PMC profile of this very command (profiles/pmc_latest.json,
+    # produced by scripts/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor from the
+    # calibration in profiles/r01_pmc_calibration.json: 1.0 for 64-B code rows, 2.0 for 128-B rows)
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        if pm.get("workload") == args.workload and pm.get("bv") == args.bv and pm.get("bb") == args.bb and pm.get("k") == args.k and world == 1:
+            ent = pm["kernels"].get(rr_name)
+            if ent:
+                traffic = (ent["FETCH_SIZE_KiB"] * pm["fetch_factor"] + ent["WRITE_SIZE_KiB"]) * 1024.0
+    except Exception:
+        traffic = None
+
     out = {
         "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
         "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -327,7 +340,7 @@ def main():
                    "path_GBps": path_bytes_q * qps / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qps / 1e9 / HBM_PEAK_GBS,
                    "stage_ms": stage, "dominant_kernel_by_time": rr_name},
         "roofline": {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": rr_ms,
+                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": rr_ms,
                      "algorithmic_bytes_per_launch": rr_bytes,
                      "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
                                                       "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}

@@ -188,6 +188,10 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt_host, float*
                    uint32_t* seg_bin_host, uint32_t* cand_idx_host, float* cand_dist_host,
                    uint32_t* ncand_host);
 
+/* PMC calibration probe: `gathers` random reads of row_bytes (64|128) rows, one lane per row, 16 bytes per load, from a
+ * table of 2^log2_rows rows (choose it far above the 256 MiB Infinity Cache); known bytes = gathers*row_bytes.  Run it
+ * under `rocprofv3 --pmc FETCH_SIZE` (scripts/pmc_calibrate.sh) to get the counter-to-bytes ratio of this access shape. */
+int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_bytes, uint64_t gathers, float* out_ms);
 int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* duration (ms) of each launch of the dominant kernel (rerank) in the last call, via HIP events on the
  * stream it ran on; returns the number of launches written (<= cap). */

@@ -42,7 +42,7 @@ class pqt_stats(C.Structure):
 # every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
-    "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign",
+    "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather",
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",

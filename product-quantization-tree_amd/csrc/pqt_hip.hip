@@ -733,6 +733,33 @@ int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out, uint32_t qn
   return PQT_OK;
 }
 
+int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_bytes, uint64_t gathers, float* out_ms) {
+  if ((row_bytes != 64 && row_bytes != 128) || log2_rows < 10 || log2_rows > 34) return fail(PQT_ERR_INVALID, "row_bytes 64|128, 10 <= log2_rows <= 34");
+  HIPCHK(hipSetDevice(device));
+  const uint64_t rows = 1ull << log2_rows;
+  if (gathers > rows) gathers = rows;
+  void* table = nullptr; unsigned long long* sink = nullptr;
+  HIPCHK(hipMalloc(&table, rows * row_bytes));
+  HIPCHK(hipMalloc((void**)&sink, 8));
+  HIPCHK(hipMemset(table, 1, rows * row_bytes));
+  HIPCHK(hipMemset(sink, 0, 8));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(e0, 0));
+  const unsigned grid = (unsigned)((gathers + 255) / 256);
+  if (row_bytes == 64) hipLaunchKernelGGL(pqt_k_calib_gather<4>, dim3(grid), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
+  else hipLaunchKernelGGL(pqt_k_calib_gather<8>, dim3(grid), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
+  HIPCHK(hipEventRecord(e1, 0));
+  HIPCHK(hipDeviceSynchronize());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  if (out_ms) *out_ms = ms;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(table); (void)hipFree(sink);
+  return PQT_OK;
+}
+
 int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   if (!cidx || !out) return fail(PQT_ERR_INVALID, "null argument");
   pqt_index* idx = const_cast<pqt_index*>(cidx);

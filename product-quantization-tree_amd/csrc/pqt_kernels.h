@@ -1020,3 +1020,21 @@ __global__ __launch_bounds__(256) void pqt_k_kmeans_assign(
   outAssign[i] = best;
   outDist[i] = bd;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// PMC calibration probe (MI355X_MICROARCH.md HBM: "calibrate on a known byte count in your own access pattern"):
+// `gathers` random row reads of ROWV 16-byte vectors each (lane = one row, exactly the access shape of the rerank
+// kernels) from a table far larger than the 256 MiB Infinity Cache.  Known bytes = gathers * ROWV * 16.
+// ---------------------------------------------------------------------------------------------------
+template <int ROWV>
+__global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restrict__ table, uint64_t tableRows, uint64_t gathers,
+                                                           unsigned long long* __restrict__ sink) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= gathers) return;
+  // bijective scramble of i over the table (odd multiplier modulo a power of two) -> every row at most once
+  const uint64_t row = (i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull) & (tableRows - 1);
+  uint32_t acc = 0;
+#pragma unroll
+  for (int v = 0; v < ROWV; ++v) { const uint4 x = table[row * ROWV + v]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+  if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
+}

@@ -25,5 +25,15 @@ with open('gpurun_out/prof/${tag}_pmc_$c.csv', 'w') as o:
 print(open('gpurun_out/prof/${tag}_pmc_$c.csv').read())
 PY
 done
+python - <<PY
+import csv, json
+k = {}
+for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for r in csv.DictReader(open('gpurun_out/prof/${tag}_pmc_%s.csv' % c)):
+        k.setdefault(r['kernel'].replace('void ', '').split('<')[0], {})[c + '_KiB'] = float(r['mean_' + c])
+json.dump({"workload": "sift1m", "bv": 20000, "bb": 500, "k": 100, "fetch_factor": 1.0,
+           "source": "scripts/profile.sh ${tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per dispatch", "kernels": k},
+          open('gpurun_out/prof/${tag}_pmc_latest.json', 'w'), indent=1)
+PY
 grep pqt_k gpurun_out/prof/${tag}_kernel_stats.csv | cut -c1-200
 cut -c1-1500 gpurun_out/prof/${tag}_bench.json
