@@ -66,7 +66,8 @@ def quick_codebooks(train, P, C1, C2, seed, iters=4):
 class Fixture:
     """An oracle holding a small index plus everything needed to load the same index elsewhere."""
 
-    def __init__(self, D, P, C1, C2, W, LP, n_base, n_query, seed, heur_rows=4096, train=4000, data=None):
+    def __init__(self, D, P, C1, C2, W, LP, n_base, n_query, seed, heur_rows=4096, train=4000, data=None, dup_base=0,
+                 dup_centroids=False):
         self.cfg = dict(D=D, P=P, C1=C1, C2=C2, W=W, LP=LP)
         self.heur_rows = heur_rows
         gen = data or sift_like
@@ -75,7 +76,13 @@ class Fixture:
         rng = np.random.default_rng(seed + 3)
         pick = rng.integers(0, n_base, n_query)
         self.queries = np.clip(np.rint(self.base[pick] + rng.normal(0, 6, (n_query, D))), 0, 255).astype(np.float32)
+        if dup_base:  # exact duplicates in the database -> identical line codes -> exact ties of the ADC distance
+            self.base[n_base - dup_base:] = self.base[:dup_base]
         self.cb1, self.cb2 = quick_codebooks(self.train, P, C1, C2, seed + 4)
+        if dup_centroids:  # duplicated centroids on both levels -> exact ties while ordering cells / entries / bins
+            self.cb2[:, :, C2 - 1] = self.cb2[:, :, 0]
+            S = D // P
+            self.cb1[C1 - 1, :S] = self.cb1[0, :S]
         self.oracle = Oracle(D, P, C1, C2, W, LP, heur_keep=heur_rows)
         self.oracle.set_codebooks(self.cb1, self.cb2)
         self.oracle.insert(self.base)
@@ -108,6 +115,9 @@ CONFIGS = {
     "wrap": dict(D=32, P=4, C1=32, C2=32, W=1, LP=8, n_base=30000, n_query=32, seed=33, heur_rows=2048),
     # odd sizes: LP not a multiple of 4 (scalar code reads), non-power-of-two everything
     "odd": dict(D=24, P=2, C1=6, C2=4, W=3, LP=6, n_base=3000, n_query=32, seed=44, heur_rows=144),
+    # exact ties everywhere: duplicated database vectors and duplicated centroids (canonical = stable order)
+    "ties": dict(D=32, P=2, C1=8, C2=8, W=4, LP=8, n_base=6000, n_query=32, seed=55, heur_rows=1024, dup_base=2500,
+                 dup_centroids=True),
 }
 
 

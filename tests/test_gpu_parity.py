@@ -12,7 +12,7 @@ from common import CONFIGS, fixture, pqt_pkg
 
 pytestmark = pytest.mark.gpu
 
-BV_BB = {"tools_default": (2000, 500), "cfg2_small": (300, 500), "wrap": (100, 1000), "odd": (400, 144)}
+BV_BB = {"tools_default": (2000, 500), "cfg2_small": (300, 500), "wrap": (100, 1000), "odd": (400, 144), "ties": (500, 400)}
 
 
 def bits(a):
@@ -246,3 +246,72 @@ def test_assign_encode_matches_oracle_insert(pair):
         off += s
     assert np.array_equal(got_bins, bin_of[:n])
     assert np.array_equal(got_codes, f.codes[:n])
+
+
+def test_tie_fixture_really_has_ties_and_matches_stable_order():
+    """The engine's tie order is the stable order: on a fixture with duplicated vectors and centroids
+    the counters are non-zero and every list equals the oracle in stable mode."""
+    f = fixture("ties")
+    for mode in (1, 0):
+        idx = f.hip_index()
+        idx.set_option("fused", mode)
+        try:
+            ids, dist, cnt = idx.query(f.queries, 500, 400, 100)
+            st = idx.stats()
+            assert st["ties_final"] > 0 and st["ties_l2"] > 0
+            f.oracle.set_sort_mode(1)
+            try:
+                for qi, q in enumerate(f.queries):
+                    s_ids, s_d = f.oracle.query(q, 500, 400)
+                    kk = min(100, len(s_ids))
+                    assert int(cnt[qi]) == len(s_ids)
+                    assert np.array_equal(ids[qi, :kk], s_ids[:kk])
+                    assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk]))
+            finally:
+                f.oracle.set_sort_mode(0)
+        finally:
+            idx.close()
+
+
+def test_empty_and_degenerate_inputs():
+    """Empty database, zero queries, k larger than anything, a bin list with one vector."""
+    pkg = pqt_pkg()
+    f = fixture("odd")
+    c = f.cfg
+    idx = pkg.PqtIndex(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"])
+    try:
+        idx.set_codebooks(f.cb1, f.cb2)
+        idx.set_heuristic(f.heur)
+        with pytest.raises(pkg.PqtError):  # no bins / codes yet: loud failure, no silent empty result
+            idx.query(f.queries[:2], 10, 10, 5)
+        idx.set_bins(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32))
+        idx.set_lines(np.zeros((0, c["LP"]), np.uint32))
+        ids, dist, cnt = idx.query(f.queries[:3], 10, 50, 7)
+        assert np.all(cnt == 0) and np.all(ids == 0xffffffff) and np.all(np.isinf(dist))
+        ids, dist, cnt = idx.query(np.zeros((0, c["D"]), np.float32), 10, 50, 7)
+        assert ids.shape == (0, 7)
+        # one vector
+        b = f.oracle.bin_id(f.base[0])
+        idx.set_bins(np.array([b], np.uint32), np.array([1], np.uint32), np.array([0], np.uint32))
+        idx.set_lines(f.codes[:1])
+        ids, dist, cnt = idx.query(f.base[:1], 0, len(f.heur), 3)
+        assert cnt[0] == 1 and ids[0, 0] == 0 and np.all(ids[0, 1:] == 0xffffffff)
+    finally:
+        idx.close()
+
+
+def test_invalid_arguments_are_rejected():
+    pkg = pqt_pkg()
+    with pytest.raises(pkg.PqtError):
+        pkg.PqtIndex(128, 3, 16, 8, 4, 32)      # dim % p != 0
+    with pytest.raises(pkg.PqtError):
+        pkg.PqtIndex(128, 2, 4, 8, 5, 32)       # w > c1
+    f = fixture("cfg2_small")
+    idx = f.hip_index()
+    try:
+        with pytest.raises(pkg.PqtError):
+            idx.query(f.queries[:2], 10, len(f.heur) + 1, 5)  # bound_bins beyond the heuristic prefix held
+        with pytest.raises(pkg.PqtError):
+            idx.set_bins(np.array([5, 5], np.uint32), np.array([1, 1], np.uint32), np.array([0, 1], np.uint32))  # duplicate bin id
+    finally:
+        idx.close()
