@@ -45,6 +45,7 @@ struct pqt_index {
   hipStream_t stream = nullptr;
   // tree
   float* d_cb1 = nullptr; float* d_cb2 = nullptr; float* d_coarse = nullptr;
+  float* d_cb2T = nullptr;  // cb2 re-tiled per cell as [S/4][C2] 16-byte vectors (coalesced row walks), when S % 4 == 0
   bool haveTree = false;
   // heuristic prefix (a3)
   std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr;
@@ -54,7 +55,8 @@ struct pqt_index {
   uint32_t* d_ids = nullptr; uint64_t nIds = 0; uint32_t maxBin = 0; bool sharded = false; bool haveBins = false;
   uint64_t nTotal = 0;  // database size (all shards)
   // line codes (a7)
-  uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;
+  uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
+  uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
@@ -169,6 +171,10 @@ int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vect
   if (!localIds.empty()) HIPCHK(hipMemcpy(idx->d_ids, localIds.data(), localIds.size() * 4, hipMemcpyHostToDevice));
   idx->nIds = localIds.size();
   idx->tableBits = bits; idx->maxBin = maxBin; idx->sharded = sharded; idx->haveBins = true;
+  // a new bin layout invalidates the bin-ordered line store; if the id-ordered copy was consumed by the reorder, the
+  // caller has to hand the line codes over again (the next query reports PQT_ERR_STATE otherwise)
+  if (idx->d_codesBin) { (void)hipFree(idx->d_codesBin); idx->d_codesBin = nullptr; }
+  idx->binOrdered = false;
   // candidate scratch layout depends on sharded-ness
   idx->candCap = 0;
   return PQT_OK;
@@ -205,7 +211,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, true> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, false>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codes, idx->idBase, qL1virt, idx->d_coarse,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
                      idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg);
   return PQT_OK;
 }
@@ -227,16 +233,40 @@ int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipSt
   }
 }
 
+// permute the line store into bin order (see pqt_k_reorder_lines); afterwards the id-ordered copy is dropped if owned
+int reorderLines(pqt_index* idx) {
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  const uint32_t LP = idx->dp.LP;
+  if ((rc = devAlloc(&idx->d_codesBin, (size_t)idx->nIds * LP))) return rc;
+  unsigned long long* bad = idx->d_counters + 7;
+  HIPCHK(hipMemsetAsync(bad, 0, 8, idx->stream));
+  const uint64_t pieces = idx->nIds * (uint64_t)(LP % 4 == 0 ? LP / 4 : LP);
+  const uint64_t maxGrid = 1ull << 30;
+  if (pieces > maxGrid * 256) return fail(PQT_ERR_LIMIT, "line store too large for one reorder launch");
+  if (pieces) hipLaunchKernelGGL(pqt_k_reorder_lines, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, idx->stream, idx->d_codes,
+                                 idx->idBase, idx->nCodes, idx->d_ids, idx->nIds, LP, idx->d_codesBin, bad);
+  HIPCHK(hipGetLastError());
+  unsigned long long nbad = 0;
+  HIPCHK(hipMemcpyAsync(&nbad, bad, 8, hipMemcpyDeviceToHost, idx->stream));
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  if (nbad) return fail(PQT_ERR_STATE, "bin members reference vector ids outside the line store [id_base, id_base + nvec)");
+  if (idx->codesOwned && idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; idx->codesOwned = false; idx->linesDropped = true; }
+  idx->binOrdered = true;
+  return PQT_OK;
+}
+
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
               uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
   if (!idx) return fail(PQT_ERR_INVALID, "null index");
-  if (!idx->haveTree || !idx->haveBins || !idx->d_codes || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic, bins and line codes before querying");
+  if (!idx->haveTree || !idx->haveBins || !(idx->d_codes || idx->binOrdered) || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic, bins and line codes before querying");
   if (qn == 0) return PQT_OK;
   if (k == 0 || !q_dev || !outIdx || !outDist) return fail(PQT_ERR_INVALID, "bad query arguments");
   if (idx->sharded && !outPos) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard");
   int rc = setDevice(idx);
   if (rc) return rc;
   if (!st) st = idx->stream;
+  if (!idx->binOrdered && (rc = reorderLines(idx))) return rc;
   const PqtDevParams& d = idx->dp;
   // number of heuristic rows enumerated (treequantizer.hpp:552)
   uint64_t He64 = std::min<uint64_t>(Bb, idx->maxMultiIndex);
@@ -304,7 +334,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
 #define PQT_LAUNCH_TR(WCR)                                                                                              \
       hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, false>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
-                         q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
+                         q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
                          idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->d_counters, idx->d_tstamp)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
@@ -336,27 +366,27 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     } else {
     if (d.LP % 4 == 0)
-      hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
+      hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
                          idx->d_nLocal + q0, stride, d);
     else
-      hipLaunchKernelGGL(pqt_k_rerank<1>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codes, idx->idBase,
+      hipLaunchKernelGGL(pqt_k_rerank<1>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
                          idx->d_nLocal + q0, stride, d);
     HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     if (fullSort) {
       if (idx->sharded)
-        hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+        hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
                            idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
       else
-        hipLaunchKernelGGL(pqt_k_fullsort<false>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+        hipLaunchKernelGGL(pqt_k_fullsort<false>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
                            idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
     } else {
       if (idx->sharded)
-        hipLaunchKernelGGL(pqt_k_select<true>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+        hipLaunchKernelGGL(pqt_k_select<true>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
                            idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
       else
-        hipLaunchKernelGGL(pqt_k_select<false>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_cand, idx->d_candDist, idx->d_candPos,
+        hipLaunchKernelGGL(pqt_k_select<false>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
                            idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
     }
     }
@@ -426,8 +456,8 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
-                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
+  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
+                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
@@ -458,6 +488,17 @@ int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) 
   if ((rc = devAlloc(&idx->d_coarse, nc))) return rc;
   HIPCHK(hipMemcpy(idx->d_cb1, cb1, n1 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(idx->d_cb2, cb2, n2 * 4, hipMemcpyHostToDevice));
+  if (idx->d_cb2T) { (void)hipFree(idx->d_cb2T); idx->d_cb2T = nullptr; }
+  if (d.S % 4 == 0) {
+    std::vector<float> t(n2);
+    const uint32_t V = d.S / 4;
+    for (size_t cell = 0; cell < (size_t)d.P * d.C1; ++cell)
+      for (uint32_t h = 0; h < d.C2; ++h)
+        for (uint32_t v = 0; v < V; ++v)
+          for (uint32_t e = 0; e < 4; ++e) t[(cell * V + v) * d.C2 * 4 + (size_t)h * 4 + e] = cb2[(cell * d.C2 + h) * d.S + v * 4 + e];
+    if ((rc = devAlloc(&idx->d_cb2T, n2))) return rc;
+    HIPCHK(hipMemcpy(idx->d_cb2T, t.data(), n2 * 4, hipMemcpyHostToDevice));
+  }
   hipLaunchKernelGGL(pqt_k_coarse, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, idx->stream, idx->d_cb1, idx->d_coarse, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(idx->stream));
@@ -606,7 +647,7 @@ int pqt_index_set_lines_host(pqt_index* idx, const uint32_t* codes, uint64_t nve
   if ((rc = devAlloc(&idx->d_codes, (size_t)nvec * idx->dp.LP))) return rc;
   idx->codesOwned = true;
   if (nvec) HIPCHK(hipMemcpy(idx->d_codes, codes, (size_t)nvec * idx->dp.LP * 4, hipMemcpyHostToDevice));
-  idx->nCodes = nvec; idx->idBase = id_base;
+  idx->nCodes = nvec; idx->idBase = id_base; idx->binOrdered = false; idx->linesDropped = false;
   return PQT_OK;
 }
 
@@ -615,7 +656,7 @@ int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t 
   if (((uintptr_t)codes_dev & 15) != 0) return fail(PQT_ERR_INVALID, "line-code buffer must be 16-byte aligned");
   if (idx->codesOwned && idx->d_codes) { (void)hipSetDevice(idx->device); (void)hipFree(idx->d_codes); }
   idx->d_codes = const_cast<uint32_t*>(codes_dev);
-  idx->codesOwned = false; idx->nCodes = nvec; idx->idBase = id_base;
+  idx->codesOwned = false; idx->nCodes = nvec; idx->idBase = id_base; idx->binOrdered = false; idx->linesDropped = false;
   return PQT_OK;
 }
 
@@ -720,7 +761,15 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd
   if (l1virt) HIPCHK(hipMemcpy(l1virt, idx->d_qL1virt, (size_t)qn * d.LP * d.C1 * 4, hipMemcpyDeviceToHost));
   if (segd) HIPCHK(hipMemcpy(segd, idx->d_segD, (size_t)qn * d.P * d.WC * 4, hipMemcpyDeviceToHost));
   if (segbin) HIPCHK(hipMemcpy(segbin, idx->d_segBin, (size_t)qn * d.P * d.WC * 4, hipMemcpyDeviceToHost));
-  if (candIdx) HIPCHK(hipMemcpy(candIdx, idx->d_cand, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
+  if (candIdx) {
+    HIPCHK(hipMemcpy(candIdx, idx->d_cand, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
+    // the device list holds positions in the bin-ordered store; report vector ids like the reference's list
+    std::vector<uint32_t> hid(idx->nIds), hn(qn);
+    if (idx->nIds) HIPCHK(hipMemcpy(hid.data(), idx->d_ids, idx->nIds * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hn.data(), idx->d_nLocal, (size_t)qn * 4, hipMemcpyDeviceToHost));
+    for (uint32_t q = 0; q < qn; ++q)
+      for (uint32_t j = 0; j < hn[q]; ++j) { uint32_t& v = candIdx[(size_t)q * idx->stride + j]; v = v < idx->nIds ? hid[v] : 0xffffffffu; }
+  }
   if (candDist) HIPCHK(hipMemcpy(candDist, idx->d_candDist, (size_t)qn * idx->stride * 4, hipMemcpyDeviceToHost));
   if (ncand) HIPCHK(hipMemcpy(ncand, idx->d_nLocal, (size_t)qn * 4, hipMemcpyDeviceToHost));
   return PQT_OK;

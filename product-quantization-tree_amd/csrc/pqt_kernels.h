@@ -250,7 +250,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     }
     const uint32_t h = (uint32_t)sKey[lo];
     const uint32_t off = j - (uint32_t)(sKey[lo] >> 32);
-    cand[(size_t)q * stride + j] = ids[sLs[h] + off];
+    cand[(size_t)q * stride + j] = sLs[h] + off;  // position in the bin-ordered line store (== index into ids[])
     if (SHARDED) candPos[(size_t)q * stride + j] = sG[h] + sLo[h] + off;
   }
 }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
 // ---------------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_rerank(
-    const uint32_t* __restrict__ codes, uint64_t idBase, const float* __restrict__ qL1virt,
+    const uint32_t* __restrict__ codes /* bin-ordered */, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, float* __restrict__ candDist,
     const uint32_t* __restrict__ nLocal, uint64_t stride, PqtDevParams prm) {
   extern __shared__ __attribute__((aligned(16))) float sVirt[];
@@ -275,8 +275,8 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_rerank(
   for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
   __syncthreads();
   for (uint32_t j = tid; j < n; j += PQT_BLOCK) {
-    const uint32_t id = cand[(size_t)q * stride + j];
-    const uint32_t* row = codes + ((size_t)id - idBase) * LP;
+    const uint32_t pos = cand[(size_t)q * stride + j];  // candidates are positions in the bin-ordered store
+    const uint32_t* row = codes + (size_t)pos * LP;
     float acc = 0.f;
     if (VEC == 4) {
       const uint4* row4 = reinterpret_cast<const uint4*>(row);
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_rerank(
 // ---------------------------------------------------------------------------------------------------
 template <bool SHARDED>
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_select(
-    const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t kP2,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
     unsigned long long* __restrict__ counters) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_select(
   for (uint32_t i = tid; i < k; i += PQT_BLOCK) {
     if (i < kk) {
       const uint32_t j = (uint32_t)sSel[i];
-      outIdx[(size_t)q * k + i] = cid[j];
+      outIdx[(size_t)q * k + i] = ids[cid[j]];
       outDist[(size_t)q * k + i] = dist[j];
       if (SHARDED) outPos[(size_t)q * k + i] = cpos[j];
       if (i + 1 < kk && (uint32_t)(sSel[i] >> 32) == (uint32_t)(sSel[i + 1] >> 32)) ++ties;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_select(
 // keys[q][nP2] u64, one workgroup per query.
 template <bool SHARDED>
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
-    const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ ids, const uint32_t* __restrict__ cand, const float* __restrict__ candDist, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint64_t* __restrict__ keys, uint32_t nP2max,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
     unsigned long long* __restrict__ counters) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
   for (uint32_t i = tid; i < k; i += PQT_BLOCK) {
     if (i < kk) {
       const uint32_t j = (uint32_t)a[i];
-      outIdx[(size_t)q * k + i] = cand[(size_t)q * stride + j];
+      outIdx[(size_t)q * k + i] = ids[cand[(size_t)q * stride + j]];
       outDist[(size_t)q * k + i] = dist[j];
       if (SHARDED) outPos[(size_t)q * k + i] = candPos[(size_t)q * stride + j];
       if (i + 1 < kk && (uint32_t)(a[i] >> 32) == (uint32_t)(a[i + 1] >> 32)) ++ties;
@@ -634,7 +634,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, bool C1P2>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
-    const uint32_t* __restrict__ codes, uint64_t idBase, const float* __restrict__ qL1virt,
+    const uint32_t* __restrict__ codes /* bin-ordered */, const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
@@ -691,14 +691,13 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + u * 64 + lane;
-          id[u] = cid[j < n ? j : n - 1];
-          if (dbg & 8) id[u] = (uint32_t)idBase + ((q * 977u + j) & 0xfffffu) % 1000000u;  // debug: sequential rows (results wrong)
-          if (dbg & 16) id[u] = (uint32_t)idBase + (j & 1023u);                           // debug: L1/L2-resident rows
+          id[u] = cid[j < n ? j : n - 1];  // position in the bin-ordered line store
+          if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
         }
         uint4 rows[U][LPV];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint4* row4 = reinterpret_cast<const uint4*>(codes + ((size_t)id[u] - idBase) * LP);
+          const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)id[u] * LP);
 #pragma unroll
           for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
         }
@@ -744,7 +743,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
       if (i < kk) {
         const uint64_t key = sKeys[i];
         const uint32_t j = (uint32_t)key;
-        outIdx[o] = cid[j];
+        outIdx[o] = ids[cid[j]];
         outDist[o] = pqt_key2f((uint32_t)(key >> 32));
         if (SHARDED) outPos[o] = cpos[j];
         if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
@@ -776,7 +775,8 @@ template <int NW, int WCR, bool SHARDED>
 #define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for (66 VGPRs, no spills)
 #endif
 __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
-    const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2, PqtDevParams prm,
+    const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2,
+    const float4* __restrict__ cb2T /* per (p,c1): [S/4][C2] 16-byte vectors, or null when S % 4 != 0 */, PqtDevParams prm,
     const uint4* __restrict__ heur8 /* rows of 8 x u16 */, uint32_t He, uint32_t Bv, const PqtBinEntry* __restrict__ table,
     const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids, uint32_t qn,
     float* __restrict__ qL1virt, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
@@ -838,10 +838,24 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     const uint32_t p = t / C1, c = t % C1;
     const float my = sL1[t];
     uint32_t rank = 0;
-    for (uint32_t o = 0; o < C1; ++o) {
-      const float v = sL1[p * C1 + o];
-      rank += (v < my) || (v == my && o < c);
-      ties += (v == my && o < c);
+    if ((C1 & 3) == 0) {  // 16-byte LDS reads: 4 cells per ds_read_b128
+      const float4* row4 = reinterpret_cast<const float4*>(sL1 + p * C1);
+      for (uint32_t o4 = 0; o4 < C1 / 4; ++o4) {
+        const float4 v4 = row4[o4];
+        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t o = o4 * 4 + e;
+          rank += (vv[e] < my) || (vv[e] == my && o < c);
+          ties += (vv[e] == my && o < c);
+        }
+      }
+    } else {
+      for (uint32_t o = 0; o < C1; ++o) {
+        const float v = sL1[p * C1 + o];
+        rank += (v < my) || (v == my && o < c);
+        ties += (v == my && o < c);
+      }
     }
     if (rank < W) sOrd[p * W + rank] = c;
   }
@@ -857,10 +871,24 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       const uint32_t tt = t < P * WC ? t : t0;
       const uint32_t p = tt / WC, pos = tt % WC, h1 = pos / C2, h2 = pos % C2;
       const uint32_t c1 = sOrd[p * W + h1];
-      const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
       const float* qq = sQ + p * S;
       float s = 0.f;
-      for (uint32_t d = 0; d < S; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      if (cb2T) {
+        // transposed tile: vector v of the C2 rows of a cell is contiguous, so the 32..64 lanes walking the rows of
+        // a cell read 512..1024 contiguous bytes per instruction (row-per-lane reads of the file layout touch one
+        // cache line per lane); same dims in the same order
+        const float4* cen4 = cb2T + ((size_t)p * C1 + c1) * (S / 4) * C2 + h2;
+        for (uint32_t v = 0; v < S / 4; ++v) {
+          const float4 c = cen4[(size_t)v * C2];
+          float df = qq[4 * v] - c.x; s = s + df * df;
+          df = qq[4 * v + 1] - c.y; s = s + df * df;
+          df = qq[4 * v + 2] - c.z; s = s + df * df;
+          df = qq[4 * v + 3] - c.w; s = s + df * df;
+        }
+      } else {
+        const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
+        for (uint32_t d = 0; d < S; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      }
       acc[u] = s;
     }
 #pragma unroll
@@ -869,26 +897,39 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   __builtin_amdgcn_wave_barrier();
   PQT_TS(3);
   ties = 0;
-  for (uint32_t p = 0; p < P; ++p) {
-    uint64_t key[WCR];
+  constexpr int PM = (4 / WCR) < 1 ? 1 : (4 / WCR);  // parts sorted together (register budget: PM * WCR keys)
+  for (uint32_t p0 = 0; p0 < P; p0 += PM) {
+    // several parts at once: their sorting networks are independent dependency chains the scheduler interleaves
+    uint64_t key[PM][WCR];
 #pragma unroll
-    for (int r = 0; r < WCR; ++r) {
-      const uint32_t pos = lane + 64 * r;
-      key[r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[p * WC + pos]) << 32) | pos) : ~0ull;
-    }
-    pqt_wave_sort_u64<WCR>(key);
+    for (int m = 0; m < PM; ++m) {
+      const uint32_t p = p0 + m < P ? p0 + m : p0;
 #pragma unroll
-    for (int r = 0; r < WCR; ++r) {
-      const uint32_t e = lane * WCR + r;
-      if (e < WC) {
-        const uint32_t pos = (uint32_t)key[r];
-        sSegD[p * WC + e] = sD2[p * WC + pos];
-        sSegB[p * WC + e] = (sOrd[p * W + pos / C2] * C2 + pos % C2) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
+      for (int r = 0; r < WCR; ++r) {
+        const uint32_t pos = lane + 64 * r;
+        key[m][r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[p * WC + pos]) << 32) | pos) : ~0ull;
       }
-      // exact ties between neighbours of the sorted list (statistics only)
-      const uint32_t hi = (uint32_t)(key[r] >> 32);
-      const uint32_t nx = (r + 1 < WCR) ? (uint32_t)(key[(r + 1) % WCR] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
-      if (e + 1 < WC && hi == nx && !(r + 1 == WCR && lane == 63)) ++ties;
+    }
+#pragma unroll
+    for (int m = 0; m < PM; ++m) pqt_wave_sort_u64<WCR>(key[m]);
+#pragma unroll
+    for (int m = 0; m < PM; ++m) {
+      const uint32_t p = p0 + m;
+      if (p < P) {
+#pragma unroll
+        for (int r = 0; r < WCR; ++r) {
+          const uint32_t e = lane * WCR + r;
+          if (e < WC) {
+            const uint32_t pos = (uint32_t)key[m][r];
+            sSegD[p * WC + e] = sD2[p * WC + pos];
+            sSegB[p * WC + e] = (sOrd[p * W + pos / C2] * C2 + pos % C2) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
+          }
+          // exact ties between neighbours of the sorted list (statistics only)
+          const uint32_t hi = (uint32_t)(key[m][r] >> 32);
+          const uint32_t nx = (r + 1 < WCR) ? (uint32_t)(key[m][(r + 1) % WCR] >> 32) : __shfl_down((uint32_t)(key[m][0] >> 32), 1, 64);
+          if (e + 1 < WC && hi == nx && !(r + 1 == WCR && lane == 63)) ++ties;
+        }
+      }
     }
   }
   if (__any(ties != 0)) { if (ties) atomicAdd(&counters[1], (unsigned long long)ties); }
@@ -988,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
     }
     const uint64_t b = sBin[lo];
-    cand[(size_t)q * stride + j] = ids[(uint32_t)(b >> 32) + (j - (uint32_t)b)];
+    cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
   }
   PQT_TS(8);
 #undef PQT_TS
@@ -1037,4 +1078,31 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restric
 #pragma unroll
   for (int v = 0; v < ROWV; ++v) { const uint4 x = table[row * ROWV + v]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
   if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// one-off at load time: the line store is permuted into BIN ORDER (row pos holds the code of vector ids[pos]), so
+// the candidates of a bin are consecutive rows: rerank reads become short sequential runs instead of one random
+// row per candidate, the id indirection disappears from the rerank chain, and the traversal emits positions
+// without touching ids[].  lane = one 16-byte (or 4-byte) piece of a row; writes coalesced, reads gathered.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pqt_k_reorder_lines(const uint32_t* __restrict__ codes, uint64_t idBase, uint64_t nCodes,
+                                                            const uint32_t* __restrict__ ids, uint64_t nIds, uint32_t LP,
+                                                            uint32_t* __restrict__ out, unsigned long long* __restrict__ bad) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (LP % 4 == 0) {
+    const uint32_t V = LP / 4;
+    if (t >= nIds * V) return;
+    const uint64_t pos = t / V, v = t % V;
+    const uint64_t r = (uint64_t)ids[pos] - idBase;
+    if (r >= nCodes) { atomicAdd(bad, 1ull); return; }
+    reinterpret_cast<uint4*>(out)[pos * V + v] = reinterpret_cast<const uint4*>(codes)[r * V + v];
+  } else {
+    if (t >= nIds * LP) return;
+    const uint64_t pos = t / LP, v = t % LP;
+    const uint64_t r = (uint64_t)ids[pos] - idBase;
+    if (r >= nCodes) { atomicAdd(bad, 1ull); return; }
+    out[pos * LP + v] = codes[r * LP + v];
+  }
 }
