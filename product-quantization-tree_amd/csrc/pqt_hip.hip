@@ -346,12 +346,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
     if (idx->sharded)
       hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                          idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
                          stride, idx->d_counters);
     else
       hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                          idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
                          stride, idx->d_counters);
     }
