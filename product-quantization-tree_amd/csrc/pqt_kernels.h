@@ -851,7 +851,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     const uint32_t p = t / C1, c = t % C1;
     const float my = sL1[t];
     uint32_t rank = 0;
-    if ((C1 & 3) == 0) {  // 16-byte LDS reads: 4 cells per ds_read_b128
+    if ((C1 & 3) == 0 && (((uint32_t)(uintptr_t)(sL1 + p * C1)) & 15u) == 0) {  // 16-byte LDS reads: 4 cells per ds_read_b128
       const float4* row4 = reinterpret_cast<const float4*>(sL1 + p * C1);
       for (uint32_t o4 = 0; o4 < C1 / 4; ++o4) {
         const float4 v4 = row4[o4];
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       const uint32_t h = lane + 64 * r;
       uint32_t slot;
       const uint4 x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
-      if (h < He) sBin[h] = (uint64_t)x.y | ((uint64_t)x.z << 32);
+      if (h < He) sBin[h] = (uint64_t)x.y | ((uint64_t)(SHARDED ? slot : x.z) << 32);  // sharded: keep the slot, resolve local fields after the cut
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -1024,25 +1024,70 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   uint32_t totCand = myCand, totIncl = myIncl;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { totCand += __shfl_xor(totCand, d, 64); totIncl += __shfl_xor(totIncl, d, 64); }
-  const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
-  const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
-  uint32_t wpos = neIncl - myNonEmpty;
-  // compact list (start in candidate list | lstart<<32), ordered by start; overwrites sBin (all reads done)
+  if constexpr (!SHARDED) {
+    const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
+    const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
+    uint32_t wpos = neIncl - myNonEmpty;
+    // compact list (start in candidate list | lstart<<32), ordered by start; overwrites sBin (all reads done)
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; nIncl[q] = totIncl; }
-  PQT_TS(7);
-  for (uint32_t j = lane; j < totCand; j += 64) {
-    uint32_t lo = 0, hi = m;  // last entry with start <= j
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+    for (int r = 0; r < 8; ++r) {
+      if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
     }
-    const uint64_t b = sBin[lo];
-    cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; nIncl[q] = totIncl; }
+    PQT_TS(7);
+    for (uint32_t j = lane; j < totCand; j += 64) {
+      uint32_t lo = 0, hi = m;  // last entry with start <= j
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+      }
+      const uint64_t b = sBin[lo];
+      cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
+    }
+  } else {
+    // range shard: the cut above used the GLOBAL populations; now resolve what this device holds of the included bins
+    // (one more round trip, only for included populated bins) and build the LOCAL candidate list together with each
+    // candidate's global visiting position = global start of its bin + members held by lower shards + offset.
+    const uint4* table4 = reinterpret_cast<const uint4*>(table);
+    uint32_t lc8[8], gp8[8];
+    uint32_t myLocal = 0, myLocalBins = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      lc8[r] = 0; gp8[r] = 0;
+      if (g8[r]) {
+        const uint32_t slot = ls8[r];
+        const uint4 e = table4[slot];
+        ls8[r] = e.z; lc8[r] = e.w; gp8[r] = ex8[r] + lower[slot];
+        myLocal += e.w;
+        if (e.w) ++myLocalBins;
+      }
+    }
+    const uint32_t locIncl = pqt_wave_incl_scan(myLocal);
+    const uint32_t totLocal = __shfl(locIncl, 63, 64);
+    uint32_t lrun = locIncl - myLocal;
+    const uint32_t nbIncl = pqt_wave_incl_scan(myLocalBins);
+    const uint32_t m = __shfl(nbIncl, 63, 64);
+    uint32_t wpos = nbIncl - myLocalBins;
+    uint32_t* sGpos = (uint32_t*)(sBin + 512);  // 512 words: global position of the first local member of a listed bin
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (lc8[r]) { sBin[wpos] = (uint64_t)lrun | ((uint64_t)ls8[r] << 32); sGpos[wpos] = gp8[r]; ++wpos; lrun += lc8[r]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; nIncl[q] = totIncl; }
+    PQT_TS(7);
+    for (uint32_t j = lane; j < totLocal; j += 64) {
+      uint32_t lo = 0, hi = m;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+      }
+      const uint64_t b = sBin[lo];
+      const uint32_t off = j - (uint32_t)b;
+      cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + off;
+      candPos[(size_t)q * stride + j] = sGpos[lo] + off;
+    }
   }
   PQT_TS(8);
 #undef PQT_TS
