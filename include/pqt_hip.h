@@ -138,6 +138,14 @@ int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t 
 int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n,
                             uint32_t* out_bin_dev, uint32_t* out_codes_dev, void* hip_stream);
 
+/* Exact re-rank of the first k results against the raw vectors ("next" row 8f-4; CUDA queryBIGKNNRerankPerfect
+ * PerturbationProTree.hh:84, rerankBIGKernelPerfect .cu:5532): in_idx_dev[QN][k] (0xffffffff = empty) -> the same ids
+ * ordered by exact squared L2 (f32, summed left to right; ties keep the previous order), with the distances.
+ * raw_dev: row (id - raw_id_base) holds the vector, f32 or uint8 (raw_is_u8); 1 <= k <= 512.  Device pointers. */
+int pqt_rerank_exact(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t k, const uint32_t* in_idx_dev,
+                     const void* raw_dev, int raw_is_u8, uint64_t raw_id_base, uint64_t raw_rows,
+                     uint32_t* out_idx_dev, float* out_dist_dev, void* hip_stream, int sync);
+
 /* E step of the reference's k-means (productquantizer.hpp:40-66 getAssignment, vectorquantizer.hpp:33-53): nearest of
  * `ncen` centroids (rows of cen_dev, stride cen_ld) for n rows of x_dev (stride ld, optionally gathered through
  * rows_dev[n]) over `dim` dims; squared distances summed left to right, first minimum wins.  The M step (sequential

@@ -42,7 +42,7 @@ class pqt_stats(C.Structure):
 # every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
-    "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather",
+    "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather", "pqt_rerank_exact",
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
@@ -94,6 +94,8 @@ def lib():
     L.pqt_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.pqt_merge_topk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_rerank_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
+                                   C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_debug_stride.argtypes = [C.c_void_p]
     L.pqt_debug_stride.restype = C.c_uint64
     L.pqt_debug_read.argtypes = [C.c_void_p, C.c_uint32, f32p, f32p, u32p, u32p, f32p, u32p]
@@ -205,6 +207,13 @@ class PqtIndex:
     def merge_topk_dev(self, nshards, qn, k, idx_all, dist_all, pos_all, out_idx, out_dist, stream=None, sync=False):
         _chk(self.L.pqt_merge_topk(self.h, nshards, qn, k, idx_all.data_ptr(), dist_all.data_ptr(), pos_all.data_ptr(),
                                    out_idx.data_ptr(), out_dist.data_ptr(), stream, int(sync)))
+
+    def rerank_exact_dev(self, q, k, in_idx, raw, out_idx, out_dist, raw_id_base=0, stream=None, sync=False):
+        """Exact re-rank of in_idx[QN][k] against raw vectors (torch CUDA tensor, float32 or uint8 rows)."""
+        import torch
+        _chk(self.L.pqt_rerank_exact(self.h, q.data_ptr(), q.shape[0], k, in_idx.data_ptr(), raw.data_ptr(),
+                                     int(raw.dtype == torch.uint8), raw_id_base, raw.shape[0], out_idx.data_ptr(),
+                                     out_dist.data_ptr(), stream, int(sync)))
 
     def assign_encode_dev(self, vecs, out_bin, out_codes, stream=None):
         _chk(self.L.pqt_build_assign_encode(self.h, vecs.data_ptr(), vecs.shape[0], out_bin.data_ptr(),

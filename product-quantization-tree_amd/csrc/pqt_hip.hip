@@ -685,6 +685,31 @@ int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n, u
   return PQT_OK;
 }
 
+int pqt_rerank_exact(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t k, const uint32_t* in_idx_dev, const void* raw_dev,
+                     int raw_is_u8, uint64_t raw_id_base, uint64_t raw_rows, uint32_t* out_idx_dev, float* out_dist_dev,
+                     void* stream, int sync) {
+  if (!idx || !q_dev || !in_idx_dev || !raw_dev || !out_idx_dev || !out_dist_dev) return fail(PQT_ERR_INVALID, "null argument");
+  if (k == 0 || k > 512) return fail(PQT_ERR_LIMIT, "exact re-rank supports 1 <= k <= 512");
+  if (in_idx_dev == out_idx_dev) return fail(PQT_ERR_INVALID, "in place re-rank is not supported");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
+  constexpr int NW = 4;
+  const uint32_t D = idx->dp.D;
+  const size_t lds = (size_t)NW * D * 4;
+  const dim3 grid((qn + NW - 1) / NW), block(NW * 64);
+#define PQT_LAUNCH_EX(RR)                                                                                              \
+  do { if (raw_is_u8) hipLaunchKernelGGL((pqt_k_rerank_exact<NW, RR, true>), grid, block, lds, st, q_dev, qn, D, k, in_idx_dev, raw_dev, \
+                                         raw_id_base, raw_rows, out_idx_dev, out_dist_dev);                            \
+       else hipLaunchKernelGGL((pqt_k_rerank_exact<NW, RR, false>), grid, block, lds, st, q_dev, qn, D, k, in_idx_dev, raw_dev,          \
+                               raw_id_base, raw_rows, out_idx_dev, out_dist_dev); } while (0)
+  if (qn) { if (k <= 64) PQT_LAUNCH_EX(1); else if (k <= 128) PQT_LAUNCH_EX(2); else if (k <= 256) PQT_LAUNCH_EX(4); else PQT_LAUNCH_EX(8); }
+#undef PQT_LAUNCH_EX
+  HIPCHK(hipGetLastError());
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
 int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, uint32_t ld, const uint32_t* rows_dev,
                        const float* cen_dev, uint32_t ncen, uint32_t cen_ld, uint32_t* out_assign_dev, float* out_dist_dev,
                        void* stream) {

@@ -1164,3 +1164,55 @@ __global__ __launch_bounds__(256) void pqt_k_reorder_lines(const uint32_t* __res
     out[pos * LP + v] = codes[r * LP + v];
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// "next" row 8f-4: exact re-rank of the first k results against the raw database vectors
+// (CUDA rerankBIGKernelPerfect PerturbationProTree.cu:5532 / queryBIGKNNRerankPerfect :8703; cpu_version/Readme.md:
+// "You may resort the k-th best vectors from this list exactly").
+//   one wavefront per query, lane = candidate(s): squared L2 over D dims summed left to right, then the
+//   (distance, previous rank) keys are sorted by the in-register network.  RAW_U8: rows are uint8 (.umem / bvecs).
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int RR, bool RAW_U8>
+__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_exact(
+    const float* __restrict__ Q, uint32_t qn, uint32_t D, uint32_t k, const uint32_t* __restrict__ inIdx,
+    const void* __restrict__ raw, uint64_t rawIdBase, uint64_t rawRows, uint32_t* __restrict__ outIdx,
+    float* __restrict__ outDist) {
+  extern __shared__ __attribute__((aligned(16))) float smemf[];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * NW + wave;
+  if (q >= qn) return;
+  float* sQ = smemf + (size_t)wave * D;
+  for (uint32_t i = lane; i < D; i += 64) sQ[i] = Q[(size_t)q * D + i];
+  __builtin_amdgcn_wave_barrier();
+  uint64_t key[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const uint32_t pos = lane + 64 * r;
+    key[r] = ~0ull;
+    if (pos < k) {
+      const uint32_t id = inIdx[(size_t)q * k + pos];
+      const uint64_t row = (uint64_t)id - rawIdBase;
+      if (id != 0xffffffffu && row < rawRows) {
+        float s = 0.f;
+        if (RAW_U8) {
+          const uint8_t* x = reinterpret_cast<const uint8_t*>(raw) + row * D;
+          for (uint32_t d = 0; d < D; ++d) { const float df = sQ[d] - (float)x[d]; s = s + df * df; }
+        } else {
+          const float* x = reinterpret_cast<const float*>(raw) + row * D;
+          for (uint32_t d = 0; d < D; ++d) { const float df = sQ[d] - x[d]; s = s + df * df; }
+        }
+        key[r] = ((uint64_t)pqt_f2key(s) << 32) | pos;
+      }
+    }
+  }
+  pqt_wave_sort_u64<RR>(key);
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    const uint32_t e = lane * RR + r;
+    if (e < k) {
+      const bool ok = key[r] != ~0ull;
+      outIdx[(size_t)q * k + e] = ok ? inIdx[(size_t)q * k + (uint32_t)key[r]] : 0xffffffffu;
+      outDist[(size_t)q * k + e] = ok ? pqt_key2f((uint32_t)(key[r] >> 32)) : __uint_as_float(0x7f800000u);
+    }
+  }
+}

@@ -315,3 +315,41 @@ def test_invalid_arguments_are_rejected():
             idx.set_bins(np.array([5, 5], np.uint32), np.array([1, 1], np.uint32), np.array([0, 1], np.uint32))  # duplicate bin id
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("raw_u8", [False, True])
+@pytest.mark.parametrize("k", [10, 100, 300])
+def test_exact_rerank_against_raw_vectors(k, raw_u8):
+    """Row 8f-4: the first k approximate results re-ordered by exact squared L2 (f32, summed left to right), ties keep
+    the previous order -- against a numpy restatement with the same summation order."""
+    import torch
+    f = fixture("tools_default")
+    idx = f.hip_index()
+    try:
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        oi = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        od = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        idx.query_dev(q, 2000, 500, k, oi, od, sync=True) if k <= 4096 else None
+        raw = torch.from_numpy(f.base.astype(np.uint8) if raw_u8 else f.base).cuda()
+        ri = torch.empty_like(oi)
+        rd = torch.empty_like(od)
+        idx.rerank_exact_dev(q, k, oi, raw, ri, rd, sync=True)
+        ids = oi.cpu().numpy().view(np.uint32)
+        got_i = ri.cpu().numpy().view(np.uint32)
+        got_d = rd.cpu().numpy()
+        for qi in range(qn):
+            valid = ids[qi] != 0xffffffff
+            cand = ids[qi][valid]
+            x = f.base[cand]
+            s = np.zeros(len(cand), np.float32)
+            for d in range(f.cfg["D"]):  # same left-to-right f32 accumulation as the kernel
+                df = (f.queries[qi, d] - x[:, d]).astype(np.float32)
+                s = (s + df * df).astype(np.float32)
+            order = np.lexsort((np.arange(len(cand)), s))
+            n = len(cand)
+            assert np.array_equal(got_i[qi, :n], cand[order])
+            assert np.array_equal(bits(got_d[qi, :n]), bits(s[order]))
+            assert np.all(got_i[qi, n:] == 0xffffffff)
+    finally:
+        idx.close()
