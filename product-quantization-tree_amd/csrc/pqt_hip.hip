@@ -61,6 +61,7 @@ struct pqt_index {
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
+  uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // 8
   unsigned long long* d_tstamp = nullptr;    // optional per-query phase timestamps (debug)
@@ -99,6 +100,8 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_nCand, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_nLocal, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
+  if ((rc = devAlloc(&idx->d_ovList, (size_t)qn))) return rc;
+  if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
   idx->qCap = qn;
   return PQT_OK;
 }
@@ -181,8 +184,8 @@ int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vect
 }
 
 size_t ldsTables(const PqtDevParams& d) { return (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P * d.W + d.P * d.WC) * 4; }
-size_t ldsBins(const PqtDevParams& d, uint32_t He, uint32_t HeP2, bool sharded) {
-  return (size_t)HeP2 * 8 + (size_t)He * 4 * (sharded ? 4 : 2) + (size_t)d.P * d.WC * 8 + (PQT_BLOCK / 64 + 1 + 4) * 4;
+size_t ldsBins(const PqtDevParams& d, uint32_t cap, uint32_t capP2, bool sharded) {
+  return (size_t)capP2 * 8 + (size_t)cap * 4 * (sharded ? 4 : 2) + (size_t)d.P * d.WC * 8 + (PQT_BLOCK / 64 + 1 + 4) * 4;
 }
 size_t ldsSelect(uint32_t kP2) { return (size_t)kP2 * 8 + (256 + 8 + PQT_BLOCK / 64 + 1) * 4; }
 size_t ldsEncode(const PqtDevParams& d) {
@@ -274,7 +277,9 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const uint32_t He = (uint32_t)He64;
   const uint32_t HeP2 = np2(std::max<uint32_t>(He, 2));
   const size_t lBins = ldsBins(d, He, HeP2, idx->sharded);
-  if (lBins > kMaxLds) return fail(PQT_ERR_LIMIT, "bound_bins too large for the LDS-resident bin sort");
+  if (lBins > kMaxLds || He > 8192) return fail(PQT_ERR_LIMIT, "bound_bins too large for the LDS-resident bin sort (limit 8192)");
+  const uint32_t cap1 = std::min<uint32_t>(He, 1024), cap1P2 = np2(std::max<uint32_t>(cap1, 2));
+  const size_t lBins1 = ldsBins(d, cap1, cap1P2, idx->sharded);
   // candidate list bound: the reference overshoots Bv by at most the bin that crosses it
   uint64_t stride = std::min<uint64_t>((uint64_t)Bv + idx->maxBin + 1, (uint64_t)He * idx->maxBin + 1);
   stride = (stride + 63) & ~(uint64_t)63;
@@ -349,16 +354,25 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
                        idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_counters);
     HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
-    if (idx->sharded)
-      hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
-                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                         stride, idx->d_counters);
-    else
-      hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                         idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
-                         idx->tableBits, idx->d_ids, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                         stride, idx->d_counters);
+    // pass 1: small LDS arena (high occupancy); queries with more populated bins than it holds queue themselves for
+    // pass 2, which runs the same kernel with a full-size arena on that (usually empty) list
+    HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t cap = pass == 0 ? cap1 : He, capP2 = pass == 0 ? cap1P2 : HeP2;
+      const size_t lds = pass == 0 ? lBins1 : lBins;
+      const uint32_t* ql = pass == 0 ? nullptr : idx->d_ovList;
+      if (pass == 1 && cap1 >= He) break;
+      if (idx->sharded)
+        hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                           idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
+                           idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->d_counters);
+      else
+        hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                           idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
+                           idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->d_counters);
+    }
     }
     HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BINS], st));
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
@@ -463,7 +477,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);

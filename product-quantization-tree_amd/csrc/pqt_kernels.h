@@ -117,75 +117,89 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// stage a4 + a5 + a6: bin enumeration, probe, exact ordering, cut and candidate gather.
+// stage a4 + a5 + a6 (staged structure): bin enumeration, probe, exact ordering, cut and candidate gather.
 //   one workgroup per query.
 //   a4  for h < He: dist_h = sum_p segD[p][heur[h][p]] ; glob_h = sum_p segBin[p][..]*powers[p] (uint32 wrap)
 //       then order the bins by dist_h                                                  (treequantizer.hpp:548-588)
 //   a5  probe the bin table for (start, population)                                    (:462-463, std::map lookup)
 //   a6  visit bins in order, take whole bins, stop after the bin during which the running count
 //       exceeded Bv (strict >)                                                         (:450-477)
-// outputs: cand[q*stride + j] = vector id of the j-th candidate in visiting order (local members only
-//          when sharded), candPos (sharded only) = global visiting position, nCand[q] = GLOBAL candidate
-//          count, nLocal[q] = local candidate count.
-// LDS: P*WC*2 words + NP2(He) u64 keys + He*3 words (gcount/lstart/lcount by h) + scan scratch.
+// Only POPULATED bins take part in the ordering: an empty bin adds nothing to the running count, to the candidate
+// list or to any visiting position, so dropping it before the sort leaves every result unchanged.  Populated bins
+// are collected as compact LDS entries {key = (f32 key << 32 | row << 13 | entry), rec = (gcount, lstart[, lcount,
+// lower])}.  The LDS arena holds `cap` entries: the first launch uses a small cap (high occupancy); a query with more
+// populated bins than that appends itself to `ovList` and is redone by a second launch of the same kernel with
+// cap = He (qlist = ovList), before the rerank stage runs.
+// outputs: cand[q*stride + j] = position in the bin-ordered line store of the j-th candidate in visiting order (local
+//          members only when sharded), candPos (sharded only) = global visiting position, nCand[q] = GLOBAL candidate
+//          count, nLocal[q] = local candidate count, nIncl[q] = included populated bins.
 // ---------------------------------------------------------------------------------------------------
 template <bool SHARDED>
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     const float* __restrict__ segD, const uint32_t* __restrict__ segBin, const uint16_t* __restrict__ heur,
-    uint32_t He, uint32_t HeP2, uint32_t Bv, PqtDevParams prm, const PqtBinEntry* __restrict__ table,
-    const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids,
-    uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos, uint32_t* __restrict__ nCand,
-    uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
-    unsigned long long* __restrict__ counters) {
+    uint32_t He, uint32_t cap, uint32_t capP2, uint32_t Bv, PqtDevParams prm, const PqtBinEntry* __restrict__ table,
+    const uint32_t* __restrict__ lower, uint32_t tableBits, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
+    uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
+    const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qcount, uint32_t* __restrict__ ovList,
+    uint32_t* __restrict__ ovCount, unsigned long long* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (qlist && blockIdx.x >= *qcount) return;
+  const uint32_t q = qlist ? qlist[blockIdx.x] : blockIdx.x;
   const uint32_t P = prm.P, WC = prm.WC;
-  uint64_t* sKey = (uint64_t*)smem_raw;                 // HeP2
-  uint32_t* sG = (uint32_t*)(sKey + HeP2);              // He : global population by h
-  uint32_t* sLs = sG + He;                              // He : local start by h
-  uint32_t* sLc = sLs + He;                             // He : local count by h   (SHARDED)
-  uint32_t* sLo = sLc + (SHARDED ? He : 0);             // He : lower count by h   (SHARDED)
-  float* sSegD = (float*)(sLo + (SHARDED ? He : 0));    // P*WC
-  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);        // P*WC
-  uint32_t* sPart = sSegB + P * WC;                     // PQT_BLOCK/64 + 1
-  uint32_t* sMisc = sPart + (PQT_BLOCK / 64 + 1);       // 4 : [0] included bins [1] candidates [2] local candidates [3] populated bins
-  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  constexpr uint32_t RW = SHARDED ? 4 : 2;               // words per record
+  uint64_t* sKey = (uint64_t*)smem_raw;                  // capP2
+  uint32_t* sRec = (uint32_t*)(sKey + capP2);            // cap * RW : gcount, lstart [, lcount, lower]
+  float* sSegD = (float*)(sRec + (size_t)cap * RW);      // P*WC
+  uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);         // P*WC
+  uint32_t* sPart = sSegB + P * WC;                      // PQT_BLOCK/64 + 1
+  uint32_t* sMisc = sPart + (PQT_BLOCK / 64 + 1);        // 4 : [0] included bins [1] candidates [2] local candidates [3] populated bins
+  const uint32_t tid = threadIdx.x;
 
   for (uint32_t t = tid; t < P * WC; t += PQT_BLOCK) {
     sSegD[t] = segD[(size_t)q * P * WC + t];
     sSegB[t] = segBin[(size_t)q * P * WC + t];
   }
+  if (tid == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; sMisc[3] = 0; }
   __syncthreads();
-
-  // Only NON-EMPTY bins take part in the ordering: an empty bin adds nothing to the running count, to the candidate
-  // list or to any visiting position, so dropping it before the sort leaves every result unchanged and shrinks the
-  // sort from boundBins to the (typically 5-30 %) populated ones.
-  if (tid == 0) sMisc[3] = 0;
-  __syncthreads();
-  for (uint32_t h = tid; h < He; h += PQT_BLOCK) {
-    uint32_t glob = 0;
-    float fine = 0.f;
-    const uint4 hv = reinterpret_cast<const uint4*>(heur)[h];  // 16-byte row of 8 x u16 digits
-    const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
+  // 4 rows per thread in flight: heuristic-row reads, then 8 table probes, overlap instead of chaining
+  for (uint32_t h0 = tid; h0 < He; h0 += PQT_BLOCK * 4) {
+    uint4 hv[4];
 #pragma unroll
-    for (int p = 0; p < PQT_MAXP; ++p) {
-      if ((uint32_t)p < P) {
-        fine = fine + sSegD[p * WC + dg[p]];
-        glob += sSegB[p * WC + dg[p]] * prm.powers[p];
+    for (int u = 0; u < 4; ++u) { const uint32_t h = h0 + u * PQT_BLOCK; hv[u] = reinterpret_cast<const uint4*>(heur)[h < He ? h : h0]; }
+    uint32_t glob[4]; float fine[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t dg[8] = {hv[u].x & 0xffffu, hv[u].x >> 16, hv[u].y & 0xffffu, hv[u].y >> 16, hv[u].z & 0xffffu, hv[u].z >> 16, hv[u].w & 0xffffu, hv[u].w >> 16};
+      float f = 0.f; uint32_t g = 0;
+#pragma unroll
+      for (int p = 0; p < PQT_MAXP; ++p) {
+        if ((uint32_t)p < P) { f = f + sSegD[p * WC + dg[p]]; g += sSegB[p * WC + dg[p]] * prm.powers[p]; }
       }
+      if (prm.hashMod) g %= prm.hashMod;
+      glob[u] = g; fine[u] = f;
     }
-    if (prm.hashMod) glob %= prm.hashMod;
-    // one round trip: both candidate slots of the two-choice table
-    uint32_t slot;
-    const uint4 e = pqt_table_lookup(reinterpret_cast<const uint4*>(table), glob, tableBits, prm.tableSeed, &slot);
-    const uint32_t g = e.y, ls = e.z, lc = e.w;
-    if (g) {
-      sG[h] = g; sLs[h] = ls;
-      if (SHARDED) { sLc[h] = lc; sLo[h] = lower[slot]; }
-      sKey[atomicAdd(&sMisc[3], 1u)] = ((uint64_t)pqt_f2key(fine) << 32) | h;  // h is unique: insertion order is irrelevant
+    uint4 e[4]; uint32_t slot[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) e[u] = pqt_table_lookup(reinterpret_cast<const uint4*>(table), glob[u], tableBits, prm.tableSeed, &slot[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t h = h0 + u * PQT_BLOCK;
+      if (h < He && e[u].y) {
+        const uint32_t ent = atomicAdd(&sMisc[3], 1u);
+        if (ent < cap) {
+          sRec[ent * RW] = e[u].y; sRec[ent * RW + 1] = e[u].z;
+          if (SHARDED) { sRec[ent * RW + 2] = e[u].w; sRec[ent * RW + 3] = lower[slot[u]]; }
+          sKey[ent] = ((uint64_t)pqt_f2key(fine[u]) << 32) | (h << 13) | ent;  // ordered by (distance, row); ent addresses the record
+        }
+      }
     }
   }
   __syncthreads();
   const uint32_t nEnt = sMisc[3];  // populated bins among the enumerated rows
+  if (nEnt > cap) {  // does not fit this launch's arena: hand the query to the full-size pass
+    if (tid == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; }
+    return;
+  }
   uint32_t entP2 = 2;
   while (entP2 < nEnt) entP2 <<= 1;
   for (uint32_t i = nEnt + tid; i < entP2; i += PQT_BLOCK) sKey[i] = ~0ull;
@@ -197,52 +211,46 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
   const uint32_t i0 = tid * per < nEnt ? tid * per : nEnt, i1 = (i0 + per < nEnt) ? i0 + per : nEnt;
   uint32_t loc = 0, ties = 0;
   for (uint32_t i = i0; i < i1; ++i) {
-    const uint32_t h = (uint32_t)sKey[i];
-    loc += sG[h];
+    loc += sRec[((uint32_t)sKey[i] & 0x1fffu) * RW];
     if (i + 1 < nEnt && (uint32_t)(sKey[i] >> 32) == (uint32_t)(sKey[i + 1] >> 32)) ++ties;
   }
   if (ties) atomicAdd(&counters[2], (unsigned long long)ties);
   uint32_t total;
-  uint32_t run = pqt_block_excl_scan<PQT_BLOCK>(loc, sPart, &total);
-  // number of included bins nb = #{i : excl[i] <= Bv}; excl is non-decreasing so this is a prefix
-  if (tid == 0) { sMisc[0] = 0; sMisc[1] = 0; sMisc[2] = 0; }
-  __syncthreads();
-  uint32_t myIncl = 0, myCand = 0;
+  const uint32_t run = pqt_block_excl_scan<PQT_BLOCK>(loc, sPart, &total);
+  // included bins = the prefix with exclusive count <= Bv (the count is non-decreasing)
+  uint32_t myIncl = 0, myCand = 0, locIncl = 0;
   {
     uint32_t r = run;
     for (uint32_t i = i0; i < i1; ++i) {
-      const uint32_t h = (uint32_t)sKey[i];
-      if (r <= Bv) { ++myIncl; myCand = r + sG[h]; }
-      r += sG[h];
+      const uint32_t ent = (uint32_t)sKey[i] & 0x1fffu;
+      const uint32_t g = sRec[ent * RW];
+      if (r <= Bv) { ++myIncl; myCand = r + g; if (SHARDED) locIncl += sRec[ent * RW + 2]; }
+      r += g;
     }
   }
   if (myIncl) { atomicAdd(&sMisc[0], myIncl); atomicMax(&sMisc[1], myCand); }
-  __syncthreads();
-  const uint32_t nb = sMisc[0];
-  const uint32_t nGlobal = sMisc[1];
-  // second pass: rewrite keys as (start of the bin in the candidate list << 32 | h) for the gather.
-  // unsharded: list position == global position.  sharded: local list position, from a scan of lcount.
   uint32_t runL = run;
   if (SHARDED) {
     uint32_t totalL;
-    // only included bins contribute local candidates
-    uint32_t locIncl = 0;
-    { uint32_t r = run; for (uint32_t i = i0; i < i1; ++i) { const uint32_t h = (uint32_t)sKey[i]; if (r <= Bv) locIncl += sLc[h]; r += sG[h]; } }
     runL = pqt_block_excl_scan<PQT_BLOCK>(locIncl, sPart, &totalL);
     if (tid == 0) sMisc[2] = totalL;
   }
+  __syncthreads();
+  const uint32_t nb = sMisc[0];
+  const uint32_t nGlobal = sMisc[1];
+  // rewrite the sorted keys as (start of the bin in the candidate list << 32 | entry) for the gather; the sharded
+  // variant lists local members only and stashes the bin's GLOBAL start in record word 0 (the count is spent)
   {
     uint32_t r = run, rl = runL;
     for (uint32_t i = i0; i < i1; ++i) {
-      const uint32_t h = (uint32_t)sKey[i];
-      const uint32_t g = sG[h];
+      const uint32_t ent = (uint32_t)sKey[i] & 0x1fffu;
+      const uint32_t g = sRec[ent * RW];
       if (SHARDED) {
-        // stash the global start of the bin in sG[h] (no longer needed as a count once lcount is separate)
-        sKey[i] = ((uint64_t)rl << 32) | h;
-        sG[h] = r;
-        if (r <= Bv) rl += sLc[h];
+        sKey[i] = ((uint64_t)rl << 32) | ent;
+        if (r <= Bv) rl += sRec[ent * RW + 2];
+        sRec[ent * RW] = r;
       } else {
-        sKey[i] = ((uint64_t)r << 32) | h;
+        sKey[i] = ((uint64_t)r << 32) | ent;
       }
       r += g;
     }
@@ -261,10 +269,10 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
       const uint32_t mid = (lo + hi) >> 1;
       if ((uint32_t)(sKey[mid] >> 32) <= j) lo = mid; else hi = mid;
     }
-    const uint32_t h = (uint32_t)sKey[lo];
+    const uint32_t ent = (uint32_t)sKey[lo];
     const uint32_t off = j - (uint32_t)(sKey[lo] >> 32);
-    cand[(size_t)q * stride + j] = sLs[h] + off;  // position in the bin-ordered line store (== index into ids[])
-    if (SHARDED) candPos[(size_t)q * stride + j] = sG[h] + sLo[h] + off;
+    cand[(size_t)q * stride + j] = sRec[ent * RW + 1] + off;  // position in the bin-ordered line store (== index into ids[])
+    if (SHARDED) candPos[(size_t)q * stride + j] = sRec[ent * RW] + sRec[ent * RW + 3] + off;
   }
 }
 

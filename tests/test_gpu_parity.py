@@ -353,3 +353,32 @@ def test_exact_rerank_against_raw_vectors(k, raw_u8):
             assert np.all(got_i[qi, n:] == 0xffffffff)
     finally:
         idx.close()
+
+
+def test_bins_overflow_pass_dense_database():
+    """Staged bins kernel: more populated bins than the first pass's LDS arena (1024) -> the query is redone by the
+    full-size second pass; results still equal the oracle."""
+    from common import Fixture
+    # few, fat cells: almost every enumerated bin is populated; W*C2 = 48 -> 2304 tuples, all enumerated
+    def uniform(n, D, seed):
+        return np.random.default_rng(seed).integers(0, 256, (n, D)).astype(np.float32)
+
+    f = Fixture(D=16, P=2, C1=8, C2=6, W=8, LP=4, n_base=30000, n_query=8, seed=91, heur_rows=2304, train=3000, data=uniform)
+    idx = f.hip_index()
+    try:
+        idx.set_option("fused", 0)
+        ids, dist, cnt = idx.query(f.queries, 10 ** 6, 2304, 200)  # Bv beyond the database: every populated bin is included
+        st = idx.stats()
+        assert st["bins_nonempty"] / len(f.queries) > 1024, "fixture no longer overflows the first pass"
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, 10 ** 6, 2304)
+                kk = min(200, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(ids[qi, :kk], s_ids[:kk])
+                assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk]))
+        finally:
+            f.oracle.set_sort_mode(0)
+    finally:
+        idx.close()
