@@ -37,6 +37,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 WORKLOADS = {
     # BASELINE.json configs[1]: "SIFT1M d=128, p=4, c1=32, c2=32 on 1xMI355X, batch=10k queries" (lineparts=16 per configs[0])
     "sift1m": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=1_000_000, n_train=100_000, qn=10_000),
+    # BASELINE.json configs[2] shape: "Synthetic 100M x d=128 float, p=4, c1=64, c2=64, lineparts=32 on 1xMI355X" (optional
+    # run, not the bench line; the index is synthesised chunk by chunk with the product's own build kernel)
+    "synth100m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=100_000_000, n_train=200_000, qn=10_000, chunk=4_000_000),
+    "synth10m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=10_000_000, n_train=200_000, qn=10_000, chunk=2_000_000),
     # small variant for quick checks (not a bench line)
     "tiny": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=50_000, n_train=20_000, qn=1_000),
 }
@@ -50,7 +54,7 @@ def log(*a):
 # ------------------------------------------------------------------------------------------------------
 # synthetic SIFT-shaped data (generated on the device; plumbing, not the product)
 # ------------------------------------------------------------------------------------------------------
-GEN = dict(n_centers=4096, latent=24, lat_noise=4.0, iso_noise=6.0)
+GEN = dict(n_centers=4096, latent=24, lat_noise=4.0, iso_noise=6.0, center_scale=30.0)
 
 
 def sift_like(n, D, seed, dev):
@@ -58,7 +62,7 @@ def sift_like(n, D, seed, dev):
     g = torch.Generator(device=dev)
     g.manual_seed(0xC0DE00)  # the mixture itself is shared by train/base/query
     A = torch.randn(latent, D, generator=g, device=dev)
-    centers = torch.randn(n_centers, latent, generator=g, device=dev) * 30.0
+    centers = torch.randn(n_centers, latent, generator=g, device=dev) * GEN['center_scale']
     g.manual_seed(seed)
     out = torch.empty((n, D), dtype=torch.float32, device=dev)
     step = 1 << 18
@@ -131,7 +135,7 @@ def build_index(pkg, w, dev_index, seed_base=0xC0DE02, shard=None):
     n = base.shape[0]
     bins = torch.empty(n, dtype=torch.int32, device=dev)
     codes = torch.empty((n, LP), dtype=torch.int32, device=dev)
-    idx.assign_encode_dev(base, bins, codes)  # product kernel: insert = id() + prepareReranking
+    idx.assign_encode_dev(base, bins, codes, stream=torch.cuda.current_stream(dev).cuda_stream)  # product kernel: insert = id() + prepareReranking (same stream as the data synthesis)
     torch.cuda.synchronize(dev)
     t2 = time.time()
     # CSR by bin id (vector ids ascending inside a bin = the reference's insertion order)
@@ -168,6 +172,66 @@ def usable_cores(omp_max):
     return max(1, n)
 
 
+def build_index_chunked(pkg, w, dev_index):
+    """Large databases: vectors are generated, assigned and line-encoded chunk by chunk (never resident as a whole)."""
+    dev = torch.device("cuda", dev_index)
+    D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
+    n, chunk = w["n_base"], w["chunk"]
+    t0 = time.time()
+    train = sift_like(w["n_train"], D, 0xC0DE01, dev)
+    cb1, cb2 = train_codebooks(train, P, C1, C2, 0xC0DE04)
+    del train
+    idx = pkg.PqtIndex(D, P, C1, C2, W, LP, device=dev_index)
+    idx.set_codebooks(cb1, cb2)
+    bins = torch.empty(n, dtype=torch.int32, device=dev)
+    codes = torch.empty((n, LP), dtype=torch.int32, device=dev)
+    t1 = time.time()
+    for ci, s0 in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - s0)
+        x = sift_like(m, D, 0xC0DE02 + 7919 * ci, dev)
+        idx.assign_encode_dev(x, bins[s0:s0 + m], codes[s0:s0 + m], stream=torch.cuda.current_stream(dev).cuda_stream)
+        del x
+    torch.cuda.synchronize(dev)
+    t2 = time.time()
+    key = bins.to(torch.int64) & 0xffffffff
+    del bins
+    order = torch.argsort(key, stable=True)
+    ukeys, counts = torch.unique_consecutive(key[order], return_counts=True)
+    del key
+    bin_ids = ukeys.cpu().numpy().astype(np.uint32)
+    sizes = counts.cpu().numpy().astype(np.uint32)
+    members = order.cpu().numpy().astype(np.uint32)
+    del order, ukeys, counts
+    torch.cuda.empty_cache()
+    idx.set_bins(bin_ids, sizes, members)
+    idx.set_lines_dev(codes, 0)
+    t3 = time.time()
+    meta = dict(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), t_data=t1 - t0, t_encode=t2 - t1, t_csr=t3 - t2,
+                cb1=cb1, cb2=cb2, bin_ids=bin_ids, sizes=sizes, members=members)
+    return idx, None, meta
+
+
+def brute_force_gt_chunked(w, queries, dev):
+    """Exact nearest neighbour over the chunk-generated database (chunks are regenerated from their seeds)."""
+    n, chunk, D = w["n_base"], w["chunk"], w["D"]
+    best_d = torch.full((queries.shape[0],), float("inf"), device=dev)
+    best_i = torch.zeros(queries.shape[0], dtype=torch.int64, device=dev)
+    for ci, s0 in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - s0)
+        x = sift_like(m, D, 0xC0DE02 + 7919 * ci, dev)
+        bn = (x * x).sum(1)
+        for a in range(0, queries.shape[0], 2048):
+            q = queries[a:a + 2048]
+            d = bn[None, :] - 2.0 * (q @ x.T)
+            v, i = d.min(1)
+            v = v + (q * q).sum(1)
+            upd = v < best_d[a:a + 2048]
+            best_d[a:a + 2048] = torch.where(upd, v, best_d[a:a + 2048])
+            best_i[a:a + 2048] = torch.where(upd, i + s0, best_i[a:a + 2048])
+        del x, bn
+    return best_i
+
+
 def recall_at(ids, gt0, r):
     r = min(r, ids.shape[1])
     return float((ids[:, :r] == gt0[:, None]).any(1).float().mean())
@@ -188,6 +252,7 @@ def main():
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
     ap.add_argument("--centers", type=int, default=GEN["n_centers"])
+    ap.add_argument("--center-scale", type=float, default=GEN["center_scale"])
     ap.add_argument("--query-mode", default="fresh", choices=["fresh", "perturbed"])
     args = ap.parse_args()
 
@@ -210,8 +275,12 @@ def main():
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # everything (data synthesis and the library's kernels) is enqueued on ONE explicit stream: the C-ABI treats a NULL
+    # stream as "the handle's own non-blocking stream", which is not ordered with torch's legacy default stream
+    work_stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(work_stream)
 
-    GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers)
+    GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers, center_scale=args.center_scale)
     pkg = importlib.import_module("product-quantization-tree_amd")
     pkg.lib()  # fails loudly if the HIP library is missing
     w = WORKLOADS[args.workload]
@@ -219,7 +288,13 @@ def main():
     sharding = importlib.import_module("product-quantization-tree_amd.sharding")
     mode = "single" if world == 1 else ("shard_db" if args.shard_db else "replica")
     shard = sharding.shard_range(rank, world, n) if mode == "shard_db" else None
-    idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
+    chunked = "chunk" in w
+    if chunked:
+        if mode != "single":
+            raise SystemExit("the chunk-built workloads are single-GPU runs")
+        idx, base, meta = build_index_chunked(pkg, w, local_rank)
+    else:
+        idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
     t0 = time.time()
     idx.build_heuristic(max(args.bb, 1))
     log("[bench] index: N=%d bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
@@ -234,8 +309,12 @@ def main():
         queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
     else:  # fresh draws from the same mixture (like SIFT's separate query set)
         queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
-    gt = brute_force_gt(base, queries, 1)[:, 0]
-    raw_u8 = base.to(torch.uint8) if mode != "shard_db" else None  # raw vectors for the optional exact re-rank (8f-4)
+    if chunked:
+        gt = brute_force_gt_chunked(w, queries, dev)
+        raw_u8 = None
+    else:
+        gt = brute_force_gt(base, queries, 1)[:, 0]
+        raw_u8 = base.to(torch.uint8) if mode != "shard_db" else None  # raw vectors for the optional exact re-rank (8f-4)
     del base
     torch.cuda.empty_cache()
 
@@ -355,7 +434,7 @@ def main():
         "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if mode == "shard_db" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "SIFT1M-shape synthetic: N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
+        "config": {"workload": ("SIFT1M-shape synthetic" if args.workload in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
                                "query(boundVectors=%d, boundBins=%d), k=%d" %
                                (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
                    "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
@@ -377,7 +456,7 @@ def main():
 
     # ---- second knob set of BASELINE.md (the CUDA library's defaults k1/maxBins: boundVectors = boundBins = 4096), short leg,
     # reported beside the headline (never as `value`)
-    if mode == "single" and (args.bv, args.bb) == (20000, 500):
+    if mode == "single" and (args.bv, args.bb) == (20000, 500) and not chunked:
         try:
             idx.build_heuristic(4096)
             for _ in range(2):
@@ -398,7 +477,7 @@ def main():
             out["config"]["knobs_4096_4096"] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
-    if mode == "single" and not args.no_cpu:
+    if mode == "single" and not args.no_cpu and not chunked:
         from oracle import Oracle
         o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=1)
         o.set_heuristic(idx.heuristic(max(args.bb, 1)))

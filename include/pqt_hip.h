@@ -161,8 +161,9 @@ int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, 
  *   out_count_dev[QN] u32 (may be NULL) = candidate-list length nCand of each query.
  * Row q holds the first min(k, nCand) entries of the reference's sorted candidate list; unused slots
  * are 0xffffffff / +inf.  Equal distances are ordered by candidate visiting position (stable).
- * hip_stream: a hipStream_t to enqueue on (NULL = the handle's own stream); the call returns after
- * the work is enqueued unless `sync` != 0. */
+ * hip_stream: a hipStream_t to enqueue on; NULL = the handle's own NON-BLOCKING stream, which is not ordered with the
+ * legacy default stream -- callers that produce the inputs asynchronously must pass the producing stream (or
+ * synchronise first).  The call returns after the work is enqueued unless `sync` != 0. */
 int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins,
               uint32_t k, uint32_t* out_idx_dev, float* out_dist_dev, uint32_t* out_count_dev,
               void* hip_stream, int sync);

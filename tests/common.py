@@ -115,6 +115,10 @@ CONFIGS = {
     "wrap": dict(D=32, P=4, C1=32, C2=32, W=1, LP=8, n_base=30000, n_query=32, seed=33, heur_rows=2048),
     # odd sizes: LP not a multiple of 4 (scalar code reads), non-power-of-two everything
     "odd": dict(D=24, P=2, C1=6, C2=4, W=3, LP=6, n_base=3000, n_query=32, seed=44, heur_rows=144),
+    # coarse[LP][C1][C1] = 128 KB: too big for the LDS copy -> the rerank kernels read it through L2 (cfg3/cfg4 shape)
+    "big_coarse": dict(D=64, P=2, C1=32, C2=4, W=2, LP=32, n_base=8000, n_query=32, seed=66, heur_rows=64),
+    # BASELINE cfg3/cfg4 shape (c1=c2=64, lineparts=32, 128-byte code rows, (C1*C2)^3 wraps to 0 in uint32), W=1
+    "cfg3_small": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=20000, n_query=24, seed=77, heur_rows=512, train=6000),
     # exact ties everywhere: duplicated database vectors and duplicated centroids (canonical = stable order)
     "ties": dict(D=32, P=2, C1=8, C2=8, W=4, LP=8, n_base=6000, n_query=32, seed=55, heur_rows=1024, dup_base=2500,
                  dup_centroids=True),
