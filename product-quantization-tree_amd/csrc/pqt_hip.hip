@@ -56,7 +56,8 @@ struct pqt_index {
   uint64_t nTotal = 0;  // database size (all shards)
   // line codes (a7)
   uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
-  uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;  // bin-ordered copy the kernels read (row pos = code of ids[pos])
+  uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
+  uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
@@ -72,7 +73,7 @@ struct pqt_index {
   hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
   int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
-  int numCUs = 256; bool forceUnfused = false; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; uint32_t dbg = 0;
 };
 
 namespace {
@@ -255,8 +256,53 @@ int reorderLines(pqt_index* idx) {
   HIPCHK(hipStreamSynchronize(idx->stream));
   if (nbad) return fail(PQT_ERR_STATE, "bin members reference vector ids outside the line store [id_base, id_base + nvec)");
   if (idx->codesOwned && idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; idx->codesOwned = false; idx->linesDropped = true; }
+  if (idx->d_codesGrp) { (void)hipFree(idx->d_codesGrp); idx->d_codesGrp = nullptr; idx->grpG = 0; }
   idx->binOrdered = true;
   return PQT_OK;
+}
+
+int ensureGroupMajor(pqt_index* idx, int G) {
+  if (idx->d_codesGrp && idx->grpG == G) return PQT_OK;
+  int rc;
+  const size_t words = (size_t)idx->nIds * idx->dp.LP;
+  if ((rc = devAlloc(&idx->d_codesGrp, words))) return rc;
+  if (words) hipLaunchKernelGGL(pqt_k_group_major, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, idx->stream, idx->d_codesBin,
+                                (uint64_t)idx->nIds, idx->dp.LP, (uint32_t)G, idx->d_codesGrp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  idx->grpG = G;
+  return PQT_OK;
+}
+
+// ---- workgroup-per-query rerank+select for coarse tables that do not fit LDS (pqt_k_rerank_select_wg) ----------
+template <int G>
+int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
+               uint32_t* oI, float* oD, uint32_t* oP) {
+  const PqtDevParams& d = idx->dp;
+  int rc0 = ensureGroupMajor(idx, G);
+  if (rc0) return rc0;
+  const size_t lds = (size_t)G * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * (PQT_RS_BEST + PQT_RS_PEND) * 8;
+  const bool p2 = (d.C1 & (d.C1 - 1)) == 0;
+  auto kern = idx->sharded ? (p2 ? pqt_k_rerank_select_wg<G, true, true> : pqt_k_rerank_select_wg<G, true, false>)
+                           : (p2 ? pqt_k_rerank_select_wg<G, false, true> : pqt_k_rerank_select_wg<G, false, false>);
+  int rc = allowLds(kern, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), lds, st, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
+                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->d_counters);
+  return PQT_OK;
+}
+#ifndef PQT_RSWG_SLICE_KB
+#define PQT_RSWG_SLICE_KB 32   // 32 KB slices let two workgroups share a CU (one stages while the other computes)
+#endif
+constexpr size_t kRswgSlice = (size_t)PQT_RSWG_SLICE_KB * 1024;
+// line parts per staged group: the largest of 4, 2, 1 whose table slice fits the budget and divides LP; falls back to a
+// 64 KB slice (C1 = 128); 0 = unsupported
+int rswgGroup(const PqtDevParams& d) {
+  for (int g : {4, 2, 1})
+    if ((size_t)g * d.C1 * d.C1 * 4 <= kRswgSlice && d.LP % g == 0 && (d.C1 * d.C1) % 4 == 0) return g;
+  for (int g : {4, 2, 1})
+    if ((size_t)g * d.C1 * d.C1 * 4 <= 64 * 1024 && d.LP % g == 0 && (d.C1 * d.C1) % 4 == 0) return g;
+  return 0;
 }
 
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
@@ -380,7 +426,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (fused) {
       // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
       const uint32_t grid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
-      if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
+      const int wgG = (!coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
+      if (wgG) {
+        const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
+        rc = wgG == 4 ? launchRSWG<4>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
+           : wgG == 2 ? launchRSWG<2>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
+                      : launchRSWG<1>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP);
+        if (rc) return rc;
+      } else if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                    stride, k, nq, oI, oD, oP))) return rc;
       HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
     } else {
@@ -476,7 +529,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
-                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
+                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
@@ -493,6 +546,7 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out) {
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
+  if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -1224,3 +1224,173 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_exact(
     }
   }
 }
+
+// ===================================================================================================
+// Fused stage a7 + a8 for LARGE first-level codebooks (coarse[LP][C1][C1] > 64 KB: BASELINE cfg3/cfg4/cfg5 shapes,
+// C1 = 64..128, lineparts = 32): one WORKGROUP (8 wavefronts) per query.
+//
+//   The 4th look-up of every ADC term, coarse[p][A][B], cannot live in LDS as a whole (512 KB .. 2 MB) and as a
+//   4-byte gather through the texture path it costs ~64 clk per wave instruction -- the bound of pqt_k_rerank_select
+//   at these shapes.  Here the table is staged into LDS one LINE-PART GROUP at a time (G line parts = 64 KB) and the
+//   whole candidate tile (up to 8192 candidates, 16 per thread, accumulators in registers) is advanced by those G
+//   terms before the next group is staged: 512 KB of L2->LDS traffic per query tile instead of one gather per term.
+//   The sum per candidate still runs p = 0..LP-1 in order (groups ascend, terms ascend inside a group): bit-exact.
+//   Selection: per wavefront as in pqt_k_rerank_select (tau filter, pending buffer, in-register sort), then wave 0
+//   merges the 8 sorted best lists (3 sorts of 512).
+// LDS: G*C1*C1*4 (<= 64 KB) + LP*C1*4 + NW * 512 * 8 bytes.
+// ===================================================================================================
+#define PQT_RS2_NW 8
+#define PQT_RS2_CPT 16  // candidates per thread per tile -> tile = 8192
+
+template <int G, bool SHARDED, bool C1P2>
+__global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
+    const uint32_t* __restrict__ codesGrp /* bin-ordered, group-major: [LP/G][nIds][G] */, uint64_t nIds,
+    const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
+    const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, PqtDevParams prm,
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
+    unsigned long long* __restrict__ counters) {
+  constexpr int NW = PQT_RS2_NW, NT = NW * 64, CPT = PQT_RS2_CPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t C1 = prm.C1, LP = prm.LP;
+  const uint32_t c1sh = C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u;  // power-of-two C1: shifts instead of quarter-rate multiplies
+  const uint32_t chunkFloats = G * C1 * C1;
+  float* sChunk = (float*)smem_raw;
+  float* sVirt = sChunk + chunkFloats;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  uint64_t* sKeysAll = (uint64_t*)(sVirt + LP * C1);
+  uint64_t* sKeys = sKeysAll + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
+  const uint32_t q = blockIdx.x;
+  const uint32_t n = nLocal[q];
+  const uint32_t* cid = cand + (size_t)q * stride;
+  for (uint32_t t = tid; t < LP * C1; t += NT) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
+
+  uint64_t tau = ~0ull;
+  uint32_t npend = 0, off0 = 0;
+  auto flush = [&]() {
+    uint64_t key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t e = lane * 8 + r;
+      key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
+    }
+    pqt_wave_sort_u64<8>(key);
+    if (lane < PQT_RS_BEST / 8) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    tau = sKeys[k - 1];
+    npend = 0;
+    off0 = PQT_RS_BEST;
+  };
+
+  for (uint32_t tile0 = 0; tile0 < n; tile0 += NT * CPT) {
+    const uint32_t tn = (n - tile0 < NT * CPT) ? n - tile0 : NT * CPT;
+    uint32_t pos[CPT];
+    float acc[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const uint32_t j = tid + NT * i;
+      pos[i] = cid[tile0 + (j < tn ? j : 0)];
+      acc[i] = 0.f;
+    }
+    for (uint32_t g = 0; g < LP / G; ++g) {
+      __syncthreads();  // everyone is done with the previous group's table (and sVirt is loaded)
+      {
+        const float4* src = reinterpret_cast<const float4*>(coarse + (size_t)g * chunkFloats);
+        float4* dst = reinterpret_cast<float4*>(sChunk);
+        for (uint32_t t = tid; t < chunkFloats / 4; t += NT) dst[t] = src[t];
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int i = 0; i < CPT; ++i) {
+        const uint32_t j = tid + NT * i;
+        if (j < tn) {
+          uint32_t w[G];
+          // group-major store: the G words of consecutive candidates (consecutive positions inside a bin) are contiguous,
+          // so a wavefront's 64 reads coalesce into one 1 KB (G = 4) transaction
+          const uint32_t* row = codesGrp + ((size_t)g * nIds + pos[i]) * G;
+          if (G == 4) { const uint4 v = *reinterpret_cast<const uint4*>(row); w[0] = v.x; w[1 % G] = v.y; w[2 % G] = v.z; w[3 % G] = v.w; }
+          else if (G == 2) { const uint2 v = *reinterpret_cast<const uint2*>(row); w[0] = v.x; w[1 % G] = v.y; }
+          else { w[0] = row[0]; }
+          float a = acc[i];
+#pragma unroll
+          for (int x = 0; x < G; ++x) {
+            const uint32_t p = g * G + x;
+            const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
+            const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);
+            const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+            const float sb = sVirt[pv + A];
+            const float sa = sVirt[pv + B];
+            const float sc = sChunk[C1P2 ? ((((uint32_t)x << c1sh) + A) << c1sh) + B : (x * C1 + A) * C1 + B];
+            a = a + pqt_extract_distance(sa, sb, sc, lam);
+          }
+          acc[i] = a;
+        }
+      }
+    }
+    // selection: wave-synchronous append of the survivors
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+      const uint32_t j = tid + NT * i;
+      const bool valid = j < tn;
+      const uint64_t key = ((uint64_t)pqt_f2key(acc[i]) << 32) | (tile0 + j);
+      const bool pass = valid && key < tau;
+      uint32_t tot;
+      const uint32_t rk = pqt_ballot_rank(pass, &tot);
+      if (pass) sKeys[off0 + npend + rk] = key;
+      npend += tot;
+      __builtin_amdgcn_wave_barrier();
+      if (off0 + npend + 64 > PQT_RS_BEST + PQT_RS_PEND) flush();
+    }
+  }
+  flush();
+  __syncthreads();
+  // merge the NW sorted best lists (each at sKeysAll[w*512 .. +128)) in wave 0
+  if (wave == 0) {
+    for (uint32_t first = 1; first < NW; first += 3) {
+      uint64_t key[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t e = lane * 8 + r;
+        const uint32_t w = e < PQT_RS_BEST ? 0u : first + (e / PQT_RS_BEST - 1);
+        key[r] = w < NW ? sKeysAll[(size_t)w * (PQT_RS_BEST + PQT_RS_PEND) + (e % PQT_RS_BEST)] : ~0ull;
+      }
+      pqt_wave_sort_u64<8>(key);
+      if (lane < PQT_RS_BEST / 8) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t kk = n < k ? n : k;
+    uint32_t ties = 0;
+    for (uint32_t i = lane; i < k; i += 64) {
+      const size_t o = (size_t)q * k + i;
+      if (i < kk) {
+        const uint64_t key = sKeys[i];
+        const uint32_t j = (uint32_t)key;
+        outIdx[o] = ids[cid[j]];
+        outDist[o] = pqt_key2f((uint32_t)(key >> 32));
+        if (SHARDED) outPos[o] = candPos[(size_t)q * stride + j];
+        if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
+      } else {
+        outIdx[o] = 0xffffffffu;
+        outDist[o] = __uint_as_float(0x7f800000u);
+        if (SHARDED) outPos[o] = 0xffffffffu;
+      }
+    }
+    if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  }
+}
+
+
+// group-major copy of the bin-ordered line store for pqt_k_rerank_select_wg: out[g][pos][x] = in[pos][g*G + x]
+__global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restrict__ in, uint64_t nIds, uint32_t LP, uint32_t G,
+                                                          uint32_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // one word each; consecutive t -> consecutive output words
+  if (t >= nIds * LP) return;
+  const uint64_t g = t / (nIds * G), r = t % (nIds * G), pos = r / G, x = r % G;
+  out[t] = in[pos * LP + g * G + x];
+}

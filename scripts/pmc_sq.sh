@@ -3,13 +3,13 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 run() { # name, counters
-  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d /tmp/pmc_$1 -o p -- python bench.py --no-cpu --steps 3 --warmup 1 > /dev/null 2> gpurun_out/prof/pmc_$1.log
+  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d /tmp/pmc_$1 -o p -- python bench.py --no-cpu --steps 3 --warmup 1 $BENCH_ARGS > /dev/null 2> gpurun_out/prof/pmc_$1.log
   python - <<PY
 import csv, collections, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('/tmp/pmc_$1/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'pqt_k_traverse' in r['Kernel_Name'] or 'pqt_k_rerank_select' in r['Kernel_Name']:
+        if "pqt_k_traverse" in r["Kernel_Name"] or "pqt_k_rerank_select" in r["Kernel_Name"]:
             agg[r['Kernel_Name'].split('<')[0].replace('void ','')][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in agg:
     print(k, {c: round(sum(v)/len(v)) for c, v in sorted(agg[k].items())})
