@@ -248,6 +248,8 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k); "
+                    "off by default so that a profile of the default command contains only the headline path's launches")
     ap.add_argument("--shard-db", action="store_true", help="multi-GPU: range-shard the database instead of the queries")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
@@ -314,7 +316,7 @@ def main():
         raw_u8 = None
     else:
         gt = brute_force_gt(base, queries, 1)[:, 0]
-        raw_u8 = base.to(torch.uint8) if mode != "shard_db" else None  # raw vectors for the optional exact re-rank (8f-4)
+        raw_u8 = base.to(torch.uint8) if (args.extras and mode != "shard_db") else None  # raw vectors for the optional exact re-rank (8f-4)
     del base
     torch.cuda.empty_cache()
 
@@ -379,7 +381,7 @@ def main():
 
     # optional "next" row 8f-4 (not part of the timed path): exact re-rank of the k results against the raw uint8 vectors
     exact = None
-    if raw_u8 is not None and k <= 512:
+    if args.extras and raw_u8 is not None and k <= 512:
         ri = torch.empty_like(out_idx)
         rd = torch.empty_like(out_dist)
         idx.rerank_exact_dev(queries, k, out_idx, raw_u8, ri, rd, stream=stream)
@@ -456,7 +458,7 @@ def main():
 
     # ---- second knob set of BASELINE.md (the CUDA library's defaults k1/maxBins: boundVectors = boundBins = 4096), short leg,
     # reported beside the headline (never as `value`)
-    if mode == "single" and (args.bv, args.bb) == (20000, 500) and not chunked:
+    if args.extras and mode == "single" and (args.bv, args.bb) == (20000, 500) and not chunked:
         try:
             idx.build_heuristic(4096)
             for _ in range(2):
