@@ -689,16 +689,33 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     uint32_t off0 = 0;
 
     auto flush = [&]() {
-      uint64_t key[8];  // [best 128 (after the first flush) | pending npend | padding], 8 keys per lane, blocked
+      // [best 128 (after the first flush) | pending npend | padding], blocked over the lanes; half-size network when
+      // everything fits 256 keys (short candidate lists, and most flushes after tau has tightened)
+      const uint32_t have = off0 + npend;
+      if (have <= 256) {
+        uint64_t key[4];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const uint32_t e = lane * 8 + r;
-        key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
-      }
-      if (!(dbg & 1)) pqt_wave_sort_u64<8>(key);
-      if (lane < PQT_RS_BEST / 8) {
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t e = lane * 4 + r;
+          key[r] = (e < have) ? sKeys[e] : ~0ull;
+        }
+        if (!(dbg & 1)) pqt_wave_sort_u64<4>(key);
+        if (lane < PQT_RS_BEST / 4) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+          for (int r = 0; r < 4; ++r) sKeys[lane * 4 + r] = key[r];
+        }
+      } else {
+        uint64_t key[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const uint32_t e = lane * 8 + r;
+          key[r] = (e < have) ? sKeys[e] : ~0ull;
+        }
+        if (!(dbg & 1)) pqt_wave_sort_u64<8>(key);
+        if (lane < PQT_RS_BEST / 8) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+        }
       }
       __builtin_amdgcn_wave_barrier();
       tau = sKeys[k - 1];  // k-th best so far (~0 while fewer than k seen)
