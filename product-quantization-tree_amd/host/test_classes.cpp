@@ -1,0 +1,63 @@
+// test_classes.cpp -- exercises the reference-shaped class surface (pqt::PerturbationProTree) the way the reference's
+// cpu_version tools use treequantizer: loadTree -> loadBins -> query(boundVectors, boundBins, vec, out) per vector,
+// saveTree/saveBins round trip, and the batch entry queryKNN.  Driven by tests/test_gpu_tools.py, which compares the
+// dumped results with the oracle.
+//   usage: test_classes <dim> <p> <lineparts> <w> <tree> <bins> <queries.fmem-like raw f32 file> <nq> <bv> <bb> <out.bin>
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <fstream>
+#include <iostream>
+#include <vector>
+#include "pqt/PerturbationProTree.hh"
+
+using namespace pqt;
+
+int main(int argc, char** argv) {
+  if (argc < 12) { std::cerr << "bad usage" << std::endl; return 2; }
+  const uint dim = atoi(argv[1]), p = atoi(argv[2]), lp = atoi(argv[3]), w = atoi(argv[4]);
+  const std::string tree = argv[5], bins = argv[6], qfile = argv[7], out = argv[11];
+  const uint nq = atoi(argv[8]), bv = atoi(argv[9]), bb = atoi(argv[10]);
+  try {
+    std::vector<float> q((size_t)nq * dim);
+    std::ifstream fq(qfile.c_str(), std::ios::binary);
+    fq.read((char*)q.data(), q.size() * 4);
+    if (!fq.good()) throw std::runtime_error("cannot read queries");
+    PerturbationProTree t(dim, p, p);
+    t.setW(w);
+    t.prepareEmptyLambda(0, lp);
+    // error behaviour of the reference's readers: missing file -> std::runtime_error
+    bool threw = false;
+    try { t.loadTree(tree + ".does-not-exist"); } catch (const std::runtime_error&) { threw = true; }
+    if (!threw) throw std::runtime_error("loadTree did not throw on a missing file");
+    t.loadTree(tree);
+    t.loadBins(bins);
+    // round trip of both dumps
+    t.saveTree(out + ".tree");
+    t.saveBins(out + ".bins");
+    std::ofstream fo(out.c_str(), std::ios::binary);
+    // per-vector query(): the whole sorted candidate list
+    for (uint i = 0; i < nq; ++i) {
+      std::vector<std::pair<uint, float> > cand;
+      t.query(bv, bb, q.data() + (size_t)i * dim, cand);
+      const uint n = (uint)cand.size();
+      fo.write((const char*)&n, 4);
+      for (auto& c : cand) { fo.write((const char*)&c.first, 4); fo.write((const char*)&c.second, 4); }
+    }
+    // batch queryKNN with a device pointer, like tool_query
+    float* qd = nullptr;
+    if (hipMalloc((void**)&qd, q.size() * 4) != hipSuccess || hipMemcpy(qd, q.data(), q.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      throw std::runtime_error("upload failed");
+    t.setBounds(bv, bb);
+    std::vector<uint> ri; std::vector<float> rd;
+    t.queryKNN(ri, rd, qd, nq, 16);
+    (void)hipFree(qd);
+    fo.write((const char*)ri.data(), ri.size() * 4);
+    fo.write((const char*)rd.data(), rd.size() * 4);
+    std::cout << "ok " << t.getNClusters() << " " << t.getClusters2() << std::endl;
+  } catch (const std::exception& e) {
+    std::cerr << "test_classes: " << e.what() << std::endl;
+    return 1;
+  }
+  return 0;
+}

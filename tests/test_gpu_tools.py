@@ -102,3 +102,43 @@ def test_createdb_trains_tree_identical_to_oracle(tmp_path):
     o.insert(data)
     o.save_bins("oracle.bins")
     assert open("tr_%d_%d_%d_%d.bins" % (D, P, C1, C2), "rb").read() == open("oracle.bins", "rb").read()
+
+
+def test_class_surface_loadtree_loadbins_query(tmp_path):
+    """pqt::PerturbationProTree used like the reference's treequantizer (cpu_version/tools/query.cpp): loadTree,
+    loadBins, query(boundVectors, boundBins, vec, out) per vector, queryKNN per batch, saveTree/saveBins round trip."""
+    if not os.path.exists(os.path.join(HOST, "test_classes")):
+        subprocess.check_call(["make", "-C", HOST])
+    f = fixture("tools_default")
+    c = f.cfg
+    os.chdir(tmp_path)
+    f.oracle.save_tree("o.tree")
+    f.oracle.save_bins("o.bins")
+    nq, bv, bb = 12, 1500, 400
+    f.queries[:nq].astype(np.float32).tofile("q.raw")
+    out = subprocess.run([os.path.join(HOST, "test_classes"), str(c["D"]), str(c["P"]), str(c["LP"]), str(c["W"]), "o.tree", "o.bins",
+                          "q.raw", str(nq), str(bv), str(bb), "res.bin"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.split()[:3] == ["ok", str(c["C1"]), str(c["C2"])]
+    assert open("res.bin.tree", "rb").read() == open("o.tree", "rb").read()
+    assert open("res.bin.bins", "rb").read() == open("o.bins", "rb").read()
+    raw = np.fromfile("res.bin", np.uint32)
+    pos = 0
+    f.oracle.set_sort_mode(1)
+    try:
+        tops = []
+        for i in range(nq):
+            n = int(raw[pos]); pos += 1
+            pairs = raw[pos:pos + 2 * n].reshape(n, 2); pos += 2 * n
+            ids, d = f.oracle.query(f.queries[i], bv, bb)
+            assert n == len(ids)
+            assert np.array_equal(pairs[:, 0], ids)
+            assert np.array_equal(pairs[:, 1], d.view(np.uint32))
+            tops.append((ids[:16], d[:16]))
+    finally:
+        f.oracle.set_sort_mode(0)
+    ri = raw[pos:pos + nq * 16].reshape(nq, 16); pos += nq * 16
+    rd = raw[pos:pos + nq * 16].reshape(nq, 16)
+    for i in range(nq):
+        kk = len(tops[i][0])
+        assert np.array_equal(ri[i, :kk], tops[i][0]) and np.array_equal(rd[i, :kk], tops[i][1].view(np.uint32))
