@@ -172,10 +172,12 @@ int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_ve
 int pqt_query_host(pqt_index* idx, const float* q_host, uint32_t qn, uint32_t bound_vectors,
                    uint32_t bound_bins, uint32_t k, uint32_t* out_idx_host, float* out_dist_host,
                    uint32_t* out_count_host);
-/* Multi-GPU merge helper: out of `nshards` per-shard results laid out [shard][QN][k] (as gathered by
- * an all-gather of pqt_query_shard outputs) produce the global first-k per query.  Device pointers. */
+/* Multi-GPU merge helper: out of `nshards` per-shard results (as gathered by an all-gather of pqt_query_shard
+ * outputs) produce the global first-k per query.  Each of idx/dist/pos points at shard 0's [QN][k] block; the block of
+ * shard s starts shard_stride 32-bit words later (0 = QN*k, i.e. [shard][QN][k]; 3*QN*k when the three arrays of a
+ * shard travel as one [3][QN][k] message).  Device pointers. */
 int pqt_merge_topk(pqt_index* idx, uint32_t nshards, uint32_t qn, uint32_t k,
-                   const uint32_t* idx_dev, const float* dist_dev, const uint32_t* pos_dev,
+                   const uint32_t* idx_dev, const float* dist_dev, const uint32_t* pos_dev, uint64_t shard_stride,
                    uint32_t* out_idx_dev, float* out_dist_dev, void* hip_stream, int sync);
 /* Shard-local query: like pqt_query but also returns each result's global visiting position
  * (out_pos_dev[QN][k]) so that merges break ties exactly like the unsharded engine. */

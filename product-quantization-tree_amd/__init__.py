@@ -93,7 +93,7 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.pqt_merge_topk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                                 C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_rerank_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
                                    C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_debug_stride.argtypes = [C.c_void_p]
@@ -204,8 +204,8 @@ class PqtIndex:
                                     out_pos.data_ptr(), out_count.data_ptr() if out_count is not None else None,
                                     stream, int(sync)))
 
-    def merge_topk_dev(self, nshards, qn, k, idx_all, dist_all, pos_all, out_idx, out_dist, stream=None, sync=False):
-        _chk(self.L.pqt_merge_topk(self.h, nshards, qn, k, idx_all.data_ptr(), dist_all.data_ptr(), pos_all.data_ptr(),
+    def merge_topk_dev(self, nshards, qn, k, idx_all, dist_all, pos_all, out_idx, out_dist, stream=None, sync=False, shard_stride=0):
+        _chk(self.L.pqt_merge_topk(self.h, nshards, qn, k, idx_all.data_ptr(), dist_all.data_ptr(), pos_all.data_ptr(), shard_stride,
                                    out_idx.data_ptr(), out_dist.data_ptr(), stream, int(sync)))
 
     def rerank_exact_dev(self, q, k, in_idx, raw, out_idx, out_dist, raw_id_base=0, stream=None, sync=False):

@@ -831,7 +831,8 @@ int pqt_query_host(pqt_index* idx, const float* q, uint32_t qn, uint32_t Bv, uin
 }
 
 int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const uint32_t* inIdx, const float* inDist,
-                   const uint32_t* inPos, uint32_t* outIdx, float* outDist, void* stream, int sync) {
+                   const uint32_t* inPos, uint64_t shard_stride, uint32_t* outIdx, float* outDist, void* stream, int sync) {
+  if (shard_stride == 0) shard_stride = (uint64_t)qn * k;
   if (!idx || !inIdx || !inDist || !inPos || !outIdx || !outDist || !nsh || !k) return fail(PQT_ERR_INVALID, "null argument");
   int rc = setDevice(idx);
   if (rc) return rc;
@@ -839,7 +840,7 @@ int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const 
   const uint32_t mP2 = np2(std::max<uint32_t>(nsh * k, 2));
   const size_t lds = (size_t)mP2 * 12;
   if ((rc = allowLds(pqt_k_merge, lds))) return rc;
-  if (qn) hipLaunchKernelGGL(pqt_k_merge, dim3(qn), dim3(PQT_BLOCK), lds, st, inIdx, inDist, inPos, nsh, qn, k, mP2, outIdx, outDist);
+  if (qn) hipLaunchKernelGGL(pqt_k_merge, dim3(qn), dim3(PQT_BLOCK), lds, st, inIdx, inDist, inPos, nsh, qn, k, shard_stride, mP2, outIdx, outDist);
   HIPCHK(hipGetLastError());
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;

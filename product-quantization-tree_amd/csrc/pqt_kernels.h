@@ -472,7 +472,8 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
     const uint32_t* __restrict__ inIdx, const float* __restrict__ inDist, const uint32_t* __restrict__ inPos,
-    uint32_t nsh, uint32_t qn, uint32_t k, uint32_t mP2, uint32_t* __restrict__ outIdx, float* __restrict__ outDist) {
+    uint32_t nsh, uint32_t qn, uint32_t k, uint64_t shardStride /* words between the [qn][k] blocks of consecutive shards */,
+    uint32_t mP2, uint32_t* __restrict__ outIdx, float* __restrict__ outDist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint32_t* sI = (uint32_t*)smem_raw;  // mP2 slot indices (0xffffffff = padding)
   uint32_t* sK = sI + mP2;             // mP2 distance keys
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
   for (uint32_t i = tid; i < mP2; i += PQT_BLOCK) {
     uint32_t key = 0xffffffffu, pos = 0xffffffffu;
     if (i < m) {
-      const size_t o = ((size_t)(i / k) * qn + q) * k + (i % k);
+      const size_t o = (size_t)(i / k) * shardStride + (size_t)q * k + (i % k);
       if (inIdx[o] != 0xffffffffu) { key = pqt_f2key(inDist[o]); pos = inPos[o]; }
     }
     sI[i] = i; sK[i] = key; sP[i] = pos;
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
     const uint32_t s = sI[i];
     uint32_t id = 0xffffffffu; float d = __uint_as_float(0x7f800000u);
     if (s < m) {
-      const size_t o = ((size_t)(s / k) * qn + q) * k + (s % k);
+      const size_t o = (size_t)(s / k) * shardStride + (size_t)q * k + (s % k);
       id = inIdx[o]; d = inDist[o];
     }
     outIdx[(size_t)q * k + i] = id;

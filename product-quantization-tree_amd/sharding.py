@@ -8,7 +8,7 @@ all-gather over RCCL/xGMI and merged by (distance, position) -- exactly the orde
 
 The functions take an `engine` exposing
     query_shard(q, bv, bb, k, out_idx, out_dist, out_pos, out_count)
-    merge_topk(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist)
+    merge_topk(world, qn, k, idx0, dist0, pos0, out_idx, out_dist, shard_stride)   # shard s at +s*shard_stride words
 so the same code drives the HIP library (PqtShardEngine below) and, in the CPU test-suite, a stand-in over gloo.
 """
 import torch
@@ -21,19 +21,16 @@ def shard_range(rank, world, n):
 
 class ShardBuffers:
     def __init__(self, world, qn, k, device):
-        i32, f32 = torch.int32, torch.float32
-        self.sh_idx = torch.empty((qn, k), dtype=i32, device=device)
-        self.sh_dist = torch.empty((qn, k), dtype=f32, device=device)
-        self.sh_pos = torch.empty((qn, k), dtype=i32, device=device)
-        self.count = torch.empty(qn, dtype=i32, device=device)
-        # one buffer for the single collective: [world][3][qn][k] 32-bit words (idx | dist bits | pos)
+        i32 = torch.int32
+        # one message per rank for the single collective: [3][qn][k] 32-bit words (idx | dist bits | pos); the shard
+        # kernels write straight into it and the merge kernel reads the gathered [world][3][qn][k] buffer in place
         self.pack = torch.empty((3, qn, k), dtype=i32, device=device)
+        self.sh_idx, self.sh_pos = self.pack[0], self.pack[2]
+        self.sh_dist = self.pack[1].view(torch.float32)
+        self.count = torch.empty(qn, dtype=i32, device=device)
         self.gathered = torch.empty((world, 3, qn, k), dtype=i32, device=device)
-        self.all_idx = torch.empty((world, qn, k), dtype=i32, device=device)
-        self.all_dist = torch.empty((world, qn, k), dtype=f32, device=device)
-        self.all_pos = torch.empty((world, qn, k), dtype=i32, device=device)
         self.out_idx = torch.empty((qn, k), dtype=i32, device=device)
-        self.out_dist = torch.empty((qn, k), dtype=f32, device=device)
+        self.out_dist = torch.empty((qn, k), dtype=torch.float32, device=device)
 
 
 def sharded_query(engine, dist, world, q, bv, bb, k, buf):
@@ -41,17 +38,12 @@ def sharded_query(engine, dist, world, q, bv, bb, k, buf):
     qn = q.shape[0]
     engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
     if world == 1:
-        engine.merge_topk(1, qn, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.out_idx, buf.out_dist)
+        engine.merge_topk(1, qn, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.out_idx, buf.out_dist, 3 * qn * k)
         return buf.out_idx, buf.out_dist, buf.count
-    buf.pack[0].copy_(buf.sh_idx)
-    buf.pack[1].copy_(buf.sh_dist.view(torch.int32))
-    buf.pack[2].copy_(buf.sh_pos)
     # the one exchange step of the path (output viewed as the dim-0 concatenation every backend accepts)
     dist.all_gather_into_tensor(buf.gathered.view(world * 3, qn, k), buf.pack)
-    buf.all_idx.copy_(buf.gathered[:, 0])
-    buf.all_dist.copy_(buf.gathered[:, 1].view(torch.float32))
-    buf.all_pos.copy_(buf.gathered[:, 2])
-    engine.merge_topk(world, qn, k, buf.all_idx, buf.all_dist, buf.all_pos, buf.out_idx, buf.out_dist)
+    g = buf.gathered
+    engine.merge_topk(world, qn, k, g[0, 0], g[0, 1].view(torch.float32), g[0, 2], buf.out_idx, buf.out_dist, 3 * qn * k)
     return buf.out_idx, buf.out_dist, buf.count
 
 
@@ -67,5 +59,6 @@ class PqtShardEngine:
     def query_shard(self, q, bv, bb, k, out_idx, out_dist, out_pos, out_count):
         self.index.query_shard_dev(q, bv, bb, k, out_idx, out_dist, out_pos, out_count, stream=self._stream())
 
-    def merge_topk(self, world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist):
-        self.index.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=self._stream())
+    def merge_topk(self, world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, shard_stride):
+        self.index.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=self._stream(),
+                                  shard_stride=shard_stride)

@@ -36,7 +36,15 @@ class OracleShardEngine:
             out_pos[qi, :n] = torch.from_numpy(pos[order].astype(np.int64)).to(torch.int32)
             out_count[qi] = len(m)
 
-    def merge_topk(self, world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist):
+    def merge_topk(self, world, qn, k, idx0, dist0, pos0, out_idx, out_dist, shard_stride):
+        # idx0/dist0/pos0 are views of shard 0's [qn][k] block inside the gathered buffer; shard s sits shard_stride
+        # 32-bit words further (the same addressing the HIP merge kernel uses)
+        def blocks(t0):
+            base = t0.untyped_storage()
+            flat = torch.tensor([], dtype=t0.dtype).set_(base)
+            o = t0.storage_offset()
+            return torch.stack([flat[o + s * shard_stride:o + s * shard_stride + qn * k].view(qn, k) for s in range(world)])
+        all_idx, all_dist, all_pos = blocks(idx0), blocks(dist0), blocks(pos0)
         for qi in range(qn):
             ids = all_idx[:, qi].reshape(-1).numpy()
             d = all_dist[:, qi].reshape(-1).numpy()

@@ -214,7 +214,7 @@ def test_sharded_two_way_equals_unsharded(pair):
             sh.query_shard_dev(q, Bv, Bb, k, I[s], Dd[s], Pp[s], Cc[s], sync=True)
         oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
         oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
-        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)
+        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)  # [shard][QN][k] layout (shard_stride 0 = QN*k)
         got_ids = oI.cpu().numpy().view(np.uint32)
         got_d = oD.cpu().numpy()
         assert np.array_equal(Cc[0].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
