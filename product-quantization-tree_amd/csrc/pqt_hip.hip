@@ -281,7 +281,7 @@ int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, cons
   const PqtDevParams& d = idx->dp;
   int rc0 = ensureGroupMajor(idx, G);
   if (rc0) return rc0;
-  const size_t lds = (size_t)G * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * (PQT_RS_BEST + PQT_RS_PEND) * 8;
+  const size_t lds = (size_t)G * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8;
   const bool p2 = (d.C1 & (d.C1 - 1)) == 0;
   auto kern = idx->sharded ? (p2 ? pqt_k_rerank_select_wg<G, true, true> : pqt_k_rerank_select_wg<G, true, false>)
                            : (p2 ? pqt_k_rerank_select_wg<G, false, true> : pqt_k_rerank_select_wg<G, false, false>);

@@ -1258,10 +1258,18 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_exact(
 // LDS: G*C1*C1*4 (<= 64 KB) + LP*C1*4 + NW * 512 * 8 bytes.
 // ===================================================================================================
 #define PQT_RS2_NW 8
+#ifndef PQT_RS2_CPT
 #define PQT_RS2_CPT 16  // candidates per thread per tile -> tile = 8192
+#endif
+#ifndef PQT_RS2_KEYS
+#define PQT_RS2_KEYS 512  // key slots per wavefront: [best 128 | pending]; 512 -> sort<8>, 256 -> sort<4>
+#endif
+#ifndef PQT_RS2_WPS
+#define PQT_RS2_WPS 4    // waves per SIMD the register allocator must leave room for
+#endif
 
 template <int G, bool SHARDED, bool C1P2>
-__global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
+__global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_select_wg(
     const uint32_t* __restrict__ codesGrp /* bin-ordered, group-major: [LP/G][nIds][G] */, uint64_t nIds,
     const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
@@ -1277,7 +1285,8 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
   float* sVirt = sChunk + chunkFloats;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   uint64_t* sKeysAll = (uint64_t*)(sVirt + LP * C1);
-  uint64_t* sKeys = sKeysAll + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
+  constexpr int KR = PQT_RS2_KEYS / 64;  // keys per lane in the sorting network
+  uint64_t* sKeys = sKeysAll + (size_t)wave * PQT_RS2_KEYS;
   const uint32_t q = blockIdx.x;
   const uint32_t n = nLocal[q];
   const uint32_t* cid = cand + (size_t)q * stride;
@@ -1286,16 +1295,16 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
   uint64_t tau = ~0ull;
   uint32_t npend = 0, off0 = 0;
   auto flush = [&]() {
-    uint64_t key[8];
+    uint64_t key[KR];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const uint32_t e = lane * 8 + r;
+    for (int r = 0; r < KR; ++r) {
+      const uint32_t e = lane * KR + r;
       key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
     }
-    pqt_wave_sort_u64<8>(key);
-    if (lane < PQT_RS_BEST / 8) {
+    pqt_wave_sort_u64<KR>(key);
+    if (lane < PQT_RS_BEST / KR) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
+      for (int r = 0; r < KR; ++r) sKeys[lane * KR + r] = key[r];
     }
     __builtin_amdgcn_wave_barrier();
     tau = sKeys[k - 1];
@@ -1360,7 +1369,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
       if (pass) sKeys[off0 + npend + rk] = key;
       npend += tot;
       __builtin_amdgcn_wave_barrier();
-      if (off0 + npend + 64 > PQT_RS_BEST + PQT_RS_PEND) flush();
+      if (off0 + npend + 64 > PQT_RS2_KEYS) flush();
     }
   }
   flush();
@@ -1373,7 +1382,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64) void pqt_k_rerank_select_wg(
       for (int r = 0; r < 8; ++r) {
         const uint32_t e = lane * 8 + r;
         const uint32_t w = e < PQT_RS_BEST ? 0u : first + (e / PQT_RS_BEST - 1);
-        key[r] = w < NW ? sKeysAll[(size_t)w * (PQT_RS_BEST + PQT_RS_PEND) + (e % PQT_RS_BEST)] : ~0ull;
+        key[r] = w < NW ? sKeysAll[(size_t)w * PQT_RS2_KEYS + (e % PQT_RS_BEST)] : ~0ull;
       }
       pqt_wave_sort_u64<8>(key);
       if (lane < PQT_RS_BEST / 8) {
