@@ -84,7 +84,10 @@ void pqt_index_destroy(pqt_index* idx);
 int pqt_index_params(const pqt_index* idx, pqt_params* out);
 /* tuning/debug options: "fused" = 1 (default) use the wave-per-query fused kernels (traversal; rerank+select) when
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
- * intermediates readable by pqt_debug_read). Results are identical either way. */
+ * intermediates readable by pqt_debug_read). Results are identical either way.
+ * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
+ * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
+ * candidate lists exceed it are processed in several chunks of queries. */
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);
 
 /* ---- tree ---------------------------------------------------------------------------

@@ -547,6 +547,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
+  if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }
 

@@ -382,3 +382,22 @@ def test_bins_overflow_pass_dense_database():
             f.oracle.set_sort_mode(0)
     finally:
         idx.close()
+
+
+def test_small_scratch_budget_chunks_the_batch():
+    """A 1 MiB candidate arena forces the batch through several chunks of queries: identical results."""
+    f = fixture("tools_default")
+    idx = f.hip_index()
+    try:
+        ref = idx.query(f.queries, 2000, 500, 100)
+        for mode in (1, 0):
+            idx.set_option("fused", mode)
+            idx.set_option("scratch_mb", 1)   # stride ~3000 slots * 8 B -> ~40 queries per chunk
+            got = idx.query(f.queries, 2000, 500, 100)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
+            big = idx.query(f.queries, 2000, 500, 5000)  # full-sort path, chunked too
+            idx.set_option("scratch_mb", 4096)
+            big_ref = idx.query(f.queries, 2000, 500, 5000)
+            assert np.array_equal(big[0], big_ref[0]) and np.array_equal(bits(big[1]), bits(big_ref[1]))
+    finally:
+        idx.close()
