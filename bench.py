@@ -366,6 +366,11 @@ def main():
             d = np.diff(ts[:, :9].astype(np.int64), axis=1)
             log("[tstamp] phase cycles median:", np.median(d, axis=0).astype(int).tolist(), " total median", int(np.median(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64))),
                 " p90", int(np.percentile(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64), 90)))
+            r = ts[:, 9:14].astype(np.int64)
+            tot = r[:, 4] - r[:, 0]
+            log("[tstamp] rerank_select per query (cycles of a 100 MHz counter): total median %d p90 %d max %d | rows wait %d  adc+filter %d  flush %d (medians)"
+                % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3])))
+            log("[tstamp] kernel span (first start .. last end): %d ; sum of per-query totals / 2048 wave slots: %d" % (r[:, 4].max() - r[:, 0].min(), tot.sum() // 2048))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -216,7 +216,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg);
+                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg, idx->d_tstamp);
   return PQT_OK;
 }
 template <int LPV>

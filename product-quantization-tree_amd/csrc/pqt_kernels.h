@@ -652,7 +652,9 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #include "pqt_wave.h"
 
 #define PQT_RS_BEST 128
+#ifndef PQT_RS_PEND
 #define PQT_RS_PEND 384
+#endif
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, bool C1P2>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
-    unsigned long long* __restrict__ counters, uint32_t dbg) {
+    unsigned long long* __restrict__ counters, uint32_t dbg, unsigned long long* __restrict__ tstamp) {
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
   constexpr int U = UREQ;
@@ -681,51 +683,63 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 
   for (uint32_t q = blockIdx.x * NW + wave; q < qn; q += gridDim.x * NW) {
     const uint32_t n = (dbg & 2) ? 0u : nLocal[q];
+    // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
+    unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
+    if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
     const uint32_t* cid = cand + (size_t)q * stride;
     const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
     for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
     __builtin_amdgcn_wave_barrier();
     uint64_t tau = ~0ull;
-    uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = 128 once a best list exists
+    uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
     uint32_t off0 = 0;
 
-    auto flush = [&]() {
-      // [best 128 (after the first flush) | pending npend | padding], blocked over the lanes; half-size network when
-      // everything fits 256 keys (short candidate lists, and most flushes after tau has tightened)
-      const uint32_t have = off0 + npend;
-      if (have <= 256) {
-        uint64_t key[4];
+    auto flush = [&](const bool final) {
+      // [best off0 (unsorted, after the first flush) | pending npend]: keep the k smallest.  More than 128 keys are cut
+      // down by an exact radix select (pqt_wave_kth_u64) instead of a full sort; only the final <= 128 survivors
+      // go through the (small) in-register sorting network.  The keys live in registers during the select, so its
+      // counters reuse the pending area of sKeys (1056 bytes behind the best list).
+      uint32_t have = off0 + npend;
+      if (have > PQT_RS_BEST) {
+        constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
+        uint64_t key[RK];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const uint32_t e = lane * 4 + r;
+        for (int r = 0; r < RK; ++r) {
+          const uint32_t e = r * 64 + lane;
           key[r] = (e < have) ? sKeys[e] : ~0ull;
         }
-        if (!(dbg & 1)) pqt_wave_sort_u64<4>(key);
-        if (lane < PQT_RS_BEST / 4) {
+        __builtin_amdgcn_wave_barrier();
+        tau = pqt_wave_kth_u64<RK>(key, k, reinterpret_cast<uint32_t*>(sKeys + PQT_RS_BEST));
+        uint32_t cnt = 0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sKeys[lane * 4 + r] = key[r];
+        for (int r = 0; r < RK; ++r) {
+          uint32_t tot;
+          const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
+          if (key[r] <= tau) sKeys[cnt + rk] = key[r];
+          cnt += tot;
         }
-      } else {
-        uint64_t key[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const uint32_t e = lane * 8 + r;
-          key[r] = (e < have) ? sKeys[e] : ~0ull;
-        }
-        if (!(dbg & 1)) pqt_wave_sort_u64<8>(key);
-        if (lane < PQT_RS_BEST / 8) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) sKeys[lane * 8 + r] = key[r];
-        }
+        have = k;
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-      tau = sKeys[k - 1];  // k-th best so far (~0 while fewer than k seen)
+      if (final) {
+        uint64_t key[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const uint32_t e = lane * 2 + r;
+          key[r] = (e < have) ? sKeys[e] : ~0ull;
+        }
+        if (!(dbg & 1)) pqt_wave_sort_u64<2>(key);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) sKeys[lane * 2 + r] = key[r];
+        __builtin_amdgcn_wave_barrier();
+      }
       npend = 0;
-      off0 = PQT_RS_BEST;
+      off0 = have;
     };
 
     for (uint32_t base = 0;; base += 64 * U) {
       if (base < n) {
+        if (tstamp) ts0 = __builtin_readcyclecounter();
         uint32_t id[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -740,6 +754,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 #pragma unroll
           for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
         }
+        if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + u * 64 + lane;
@@ -768,10 +783,15 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
           npend += tot;
         }
         __builtin_amdgcn_wave_barrier();
+        if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsAdc += t - ts0; }
       }
       // single flush site: when the pending buffer could overflow on the next batch, and once at the end
       const bool last = base + 64 * U >= n;
-      if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) flush();
+      if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) {
+        if (tstamp) ts0 = __builtin_readcyclecounter();
+        flush(last);
+        if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
+      }
       if (last) break;
     }
     // results: first min(k, n) entries of the best list
@@ -794,6 +814,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     }
     if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
     __builtin_amdgcn_wave_barrier();
+    if (tstamp && lane == 0) {
+      tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
+      tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
+    }
   }
 }
 
