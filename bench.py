@@ -356,7 +356,7 @@ def main():
     # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
     hist = idx.stage_ms_history(min(args.steps, 32))
     st = idx.stats()
-    stage = dict(zip(("tables", "traverse", "rerank_select", "select"), hist.mean(0).tolist()))
+    stage = dict(zip(("tables", "traverse", "order", "rerank_select", "select"), hist.mean(0).tolist()))
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
         ts = np.zeros((qn, 16), np.uint64)
@@ -366,10 +366,12 @@ def main():
             d = np.diff(ts[:, :9].astype(np.int64), axis=1)
             log("[tstamp] phase cycles median:", np.median(d, axis=0).astype(int).tolist(), " total median", int(np.median(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64))),
                 " p90", int(np.percentile(ts[:, 8].astype(np.int64) - ts[:, 0].astype(np.int64), 90)))
+            if os.path.isdir("gpurun_out"): np.save("gpurun_out/tstamps.npy", ts)
             r = ts[:, 9:14].astype(np.int64)
             tot = r[:, 4] - r[:, 0]
-            log("[tstamp] rerank_select per query (cycles of a 100 MHz counter): total median %d p90 %d max %d | rows wait %d  adc+filter %d  flush %d (medians)"
+            log("[tstamp] rerank_select per query (shader clocks): total median %d p90 %d max %d | rows wait %d  adc+filter %d  flush %d (medians)"
                 % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3])))
+            log("[tstamp] rerank_select sVirt load %d  output %d  select part of the last flush %d (medians)" % (np.median(ts[:, 0].astype(np.int64)), np.median(ts[:, 1].astype(np.int64)), np.median(ts[:, 2].astype(np.int64))))
             log("[tstamp] kernel span (first start .. last end): %d ; sum of per-query totals / 2048 wave slots: %d" % (r[:, 4].max() - r[:, 0].min(), tot.sum() // 2048))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

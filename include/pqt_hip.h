@@ -86,6 +86,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
+ * "balance" = 0 disables the balancing order of the wave-per-query rerank (queries by descending candidate count,
+ * dealt to the wavefronts in serpentine order); it only changes the schedule, never a result.
  * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
  * candidate lists exceed it are processed in several chunks of queries. */
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);
@@ -210,8 +212,9 @@ int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* duration (ms) of each launch of the dominant kernel (rerank) in the last call, via HIP events on the
  * stream it ran on; returns the number of launches written (<= cap). */
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
-/* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][4] = {tables, traversal/bins,
- * rerank(+select when fused), select} in ms, from HIP events recorded on the launch stream; returns n (<= cap). */
+/* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][5] = {tables, traversal/bins,
+ * balancing order of the queries, rerank(+select when fused), select} in ms, from HIP events recorded on the launch
+ * stream; returns n (<= cap). */
 int pqt_get_stage_ms_history(const pqt_index* idx, float* out_ms, int cap);
 
 /* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------

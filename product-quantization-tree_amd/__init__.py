@@ -235,8 +235,8 @@ class PqtIndex:
         return s.as_dict()
 
     def stage_ms_history(self, cap=32):
-        """[n][4] per-call device ms of {tables, traversal, rerank(+select), select}, oldest first."""
-        out = np.zeros((cap, 4), np.float32)
+        """[n][5] per-call device ms of {tables, traversal, query order, rerank(+select), select}, oldest first."""
+        out = np.zeros((cap, 5), np.float32)
         n = _chk(self.L.pqt_get_stage_ms_history(self.h, _p(out, f32p), cap))
         return out[:n].copy()
 

@@ -27,7 +27,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 uint32_t upow(uint32_t x, uint32_t n) { uint32_t r = 1; for (uint32_t i = 0; i < n; ++i) r = x * r; return r; }
 uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
 
-enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_RERANK, EV_SELECT, EV_COUNT };
+enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_ORDER, EV_RERANK, EV_SELECT, EV_COUNT };
 constexpr int kMaxChunks = 16;
 constexpr int kRing = 32;        // per-stage event sets of the last kRing query calls
 #ifndef PQT_RS_NW
@@ -62,6 +62,7 @@ struct pqt_index {
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
+  uint32_t* d_order = nullptr; const uint32_t* curOrder = nullptr;  // balancing order of the current chunk (pqt_k_order_queries)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // 8
@@ -73,7 +74,7 @@ struct pqt_index {
   hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
   int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -102,6 +103,7 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_nLocal, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_ovList, (size_t)qn))) return rc;
+  if ((rc = devAlloc(&idx->d_order, (size_t)qn))) return rc;
   if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
   idx->qCap = qn;
   return PQT_OK;
@@ -216,7 +218,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg, idx->d_tstamp);
+                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg, idx->d_tstamp, idx->curOrder);
   return PQT_OK;
 }
 template <int LPV>
@@ -373,7 +375,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
   const bool coarseLds = coarseBytes <= 64 * 1024;
-  const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4);
+  const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -421,11 +423,19 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     }
     HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BINS], st));
+    // balancing order for the wave-per-query rerank: only when a wavefront slot gets more than one query
+    const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
+    idx->curOrder = nullptr;
+    if (fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves) {
+      hipLaunchKernelGGL(pqt_k_order_queries, dim3(1), dim3(1024), 0, st, idx->d_nLocal + q0, nq, idx->d_order + q0);
+      idx->curOrder = idx->d_order + q0;
+    }
+    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_ORDER], st));
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {
       // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
-      const uint32_t grid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
+      const uint32_t grid = rsGrid;
       const int wgG = (!coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
       if (wgG) {
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
@@ -518,6 +528,7 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
   idx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
   if (getenv("PQT_DBG")) idx->dbg = (uint32_t)atoi(getenv("PQT_DBG"));
+  if (getenv("PQT_BALANCE")) idx->noOrder = atoi(getenv("PQT_BALANCE")) == 0;
   if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * 16 * 8) != hipSuccess) idx->d_tstamp = nullptr; }
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
   *out = idx;
@@ -547,6 +558,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
+  if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }
@@ -954,13 +966,13 @@ int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
   for (int i = 0; i < n; ++i) {
     // oldest of the n most recent calls first
     const int slot = (int)((idx->calls - n + i) % kRing);
-    float st[4] = {0, 0, 0, 0};
+    float st[5] = {0, 0, 0, 0, 0};
     for (int ch = 0; ch < idx->ringChunks[slot]; ++ch) {
       float ms = 0;
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 5; ++e)
         if (hipEventElapsedTime(&ms, idx->evRing[slot][ch][e], idx->evRing[slot][ch][e + 1]) == hipSuccess) st[e] += ms;
     }
-    for (int e = 0; e < 4; ++e) out[i * 4 + e] = st[e];
+    for (int e = 0; e < 5; ++e) out[i * 5 + e] = st[e];
   }
   return n;
 }
@@ -971,7 +983,7 @@ int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
   int n = 0;
   for (int ch = 0; ch < idx->nChunks && n < cap; ++ch) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BINS], idx->evRing[idx->ringPos][ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_ORDER], idx->evRing[idx->ringPos][ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
     out[n++] = ms;
   }
   return n;

@@ -662,7 +662,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
-    unsigned long long* __restrict__ counters, uint32_t dbg, unsigned long long* __restrict__ tstamp) {
+    unsigned long long* __restrict__ counters, uint32_t dbg, unsigned long long* __restrict__ tstamp,
+    const uint32_t* __restrict__ order /* pqt_k_order_queries, or null: static round-robin */) {
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
   constexpr int U = UREQ;
@@ -675,21 +676,42 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
   float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
-  if (COARSE_LDS) {
-    if (!(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
-    __syncthreads();
-  }
+  const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4);
+  if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem_raw + ticketOff) = 0;
+  if (COARSE_LDS && !(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
+  __syncthreads();
   const float* cz = COARSE_LDS ? sCoarse : coarse;
 
-  for (uint32_t q = blockIdx.x * NW + wave; q < qn; q += gridDim.x * NW) {
+  // Schedule.  Candidate counts differ several-fold between queries and wavefronts do not run equally fast (the
+  // younger of two wavefronts on a SIMD loses the issue arbitration): with a static round-robin the launch lasted as
+  // long as its unluckiest wavefront, 50-60 % above the mean (debug timestamps).  `order` lists the queries by
+  // descending candidate count.  Workgroup b owns the ranks b, 2G-1-b, 2G+b, 4G-1-b, ... (G workgroups, serpentine:
+  // every workgroup gets the same mix of long and short queries), and its wavefronts take them from that list
+  // longest first through a ticket counter in LDS -- global tickets were tried and are slower than the imbalance
+  // they remove (same-address atomics serialise at ~0.15 us each, even inside one L2).
+  const uint32_t slot = blockIdx.x * NW + wave;
+  const uint32_t G = gridDim.x;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + ticketOff);
+  auto nextQuery = [&]() -> uint32_t {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(sTicket, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    const uint64_t rank = (uint64_t)t * G + ((t & 1) ? G - 1 - blockIdx.x : blockIdx.x);
+    return rank < qn ? order[rank] : 0xffffffffu;
+  };
+  uint32_t round = 0;
+  uint32_t q = order ? nextQuery() : (slot < qn ? slot : 0xffffffffu);
+  while (q != 0xffffffffu) {
     const uint32_t n = (dbg & 2) ? 0u : nLocal[q];
     // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
     unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
     if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
     const uint32_t* cid = cand + (size_t)q * stride;
     const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
+    if (tstamp) ts0 = __builtin_readcyclecounter();
     for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
     __builtin_amdgcn_wave_barrier();
+    if (tstamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) tstamp[(size_t)q * 16 + 0] = __builtin_readcyclecounter() - ts0; }
     uint64_t tau = ~0ull;
     uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
     uint32_t off0 = 0;
@@ -722,6 +744,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         __builtin_amdgcn_wave_barrier();
       }
       if (final) {
+        if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 2] = __builtin_readcyclecounter() - ts0;  // select part of the last flush
         uint64_t key[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -760,6 +783,12 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
           const uint32_t j = base + u * 64 + lane;
           const bool valid = j < n;
           float acc = 0.f;
+          if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
+            uint32_t x = 0;
+#pragma unroll
+            for (int v = 0; v < LPV; ++v) x ^= rows[u][v].x ^ rows[u][v].y ^ rows[u][v].z ^ rows[u][v].w;
+            acc = __uint_as_float(x & 0x3fffffffu);
+          } else
 #pragma unroll
           for (int v = 0; v < LPV; ++v) {
             const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
@@ -797,6 +826,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     // results: first min(k, n) entries of the best list
     const uint32_t kk = n < k ? n : k;
     uint32_t ties = 0;
+    if (tstamp) ts0 = __builtin_readcyclecounter();
     for (uint32_t i = lane; i < k; i += 64) {
       const size_t o = (size_t)q * k + i;
       if (i < kk) {
@@ -812,13 +842,62 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         if (SHARDED) outPos[o] = 0xffffffffu;
       }
     }
+    if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) tstamp[(size_t)q * 16 + 1] = __builtin_readcyclecounter() - ts0; }
     if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
     __builtin_amdgcn_wave_barrier();
     if (tstamp && lane == 0) {
       tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
       tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
+      tstamp[(size_t)q * 16 + 14] = slot;
     }
+    if (order) q = nextQuery();
+    else { ++round; const uint64_t nx = (uint64_t)round * gridDim.x * NW + slot; q = nx < qn ? (uint32_t)nx : 0xffffffffu; }
   }
+}
+
+// Balancing order for pqt_k_rerank_select: the queries of one launch by descending candidate count.  Counting sort on
+// 256 buckets scaled to the largest count (the order inside a bucket is arbitrary: it only steers the schedule, never
+// a result).  One workgroup of 1024 threads; three passes over nLocal.
+__global__ __launch_bounds__(1024) void pqt_k_order_queries(const uint32_t* __restrict__ nLocal, uint32_t qn, uint32_t* __restrict__ order) {
+  __shared__ uint32_t sHist[256];
+  __shared__ uint32_t sWave[4];
+  __shared__ uint32_t sMax;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (tid < 256) sHist[tid] = 0;
+  if (tid == 0) sMax = 0;
+  // the first 16384 counts stay in registers for the three passes (16 independent loads in flight per thread)
+  constexpr int RC = 16;
+  uint32_t cnt[RC];
+#pragma unroll
+  for (int r = 0; r < RC; ++r) { const uint32_t q = tid + 1024u * r; cnt[r] = q < qn ? nLocal[q] : 0u; }
+  uint32_t m = 0;
+#pragma unroll
+  for (int r = 0; r < RC; ++r) m = cnt[r] > m ? cnt[r] : m;
+  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) { const uint32_t n = nLocal[q]; m = n > m ? n : m; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  __syncthreads();
+  if (lane == 0) atomicMax(&sMax, m);
+  __syncthreads();
+  const float scale = 255.f / (float)(sMax ? sMax : 1u);
+  auto bucket = [&](uint32_t n) -> uint32_t { const uint32_t b = (uint32_t)((float)n * scale); return 255u - (b > 255u ? 255u : b); };
+#pragma unroll
+  for (int r = 0; r < RC; ++r) if (tid + 1024u * r < qn) atomicAdd(&sHist[bucket(cnt[r])], 1u);
+  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) atomicAdd(&sHist[bucket(nLocal[q])], 1u);
+  __syncthreads();
+  // exclusive scan of the 256 buckets (largest counts first)
+  uint32_t h = 0, incl = 0;
+  if (tid < 256) { h = sHist[tid]; incl = pqt_wave_incl_scan(h); if (lane == 63) sWave[tid >> 6] = incl; }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) before += sWave[w];
+    sHist[tid] = before + incl - h;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RC; ++r) if (tid + 1024u * r < qn) order[atomicAdd(&sHist[bucket(cnt[r])], 1u)] = tid + 1024u * r;
+  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) order[atomicAdd(&sHist[bucket(nLocal[q])], 1u)] = q;
 }
 
 // ===================================================================================================
