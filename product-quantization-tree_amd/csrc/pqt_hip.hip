@@ -34,6 +34,7 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 #define PQT_RS_NW 8
 #endif
 constexpr int kFusedWaves = PQT_RS_NW;
+constexpr int kCtrRing = 4;
 constexpr int kTravWaves = 4;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
 }  // namespace
@@ -65,13 +66,15 @@ struct pqt_index {
   uint32_t* d_order = nullptr; const uint32_t* curOrder = nullptr;  // balancing order of the current chunk (pqt_k_order_queries)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
-  unsigned long long* d_counters = nullptr;  // 8
+  unsigned long long* d_counters = nullptr;  // kCtrRing blocks of 8 statistics words (one per call, the next one is zeroed on the fly) + 1 spare block
+  unsigned long long* ctr = nullptr; int ctrPos = 0;
   unsigned long long* d_tstamp = nullptr;    // optional per-query phase timestamps (debug)
   uint64_t stride = 0;
   // results of the last call
   pqt_stats stats{};
   uint32_t lastQn = 0; uint32_t lastHe = 0;
   hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
+  uint32_t evMask[kRing][kMaxChunks]{};      // which events of a ring slot were recorded (an event record costs ~5 us of stream time)
   int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
   int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; uint32_t dbg = 0;
@@ -218,7 +221,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->d_counters, idx->dbg, idx->d_tstamp, idx->curOrder);
+                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curOrder);
   return PQT_OK;
 }
 template <int LPV>
@@ -245,7 +248,7 @@ int reorderLines(pqt_index* idx) {
   if (rc) return rc;
   const uint32_t LP = idx->dp.LP;
   if ((rc = devAlloc(&idx->d_codesBin, (size_t)idx->nIds * LP))) return rc;
-  unsigned long long* bad = idx->d_counters + 7;
+  unsigned long long* bad = idx->d_counters + 8 * kCtrRing;
   HIPCHK(hipMemsetAsync(bad, 0, 8, idx->stream));
   const uint64_t pieces = idx->nIds * (uint64_t)(LP % 4 == 0 ? LP / 4 : LP);
   const uint64_t maxGrid = 1ull << 30;
@@ -290,7 +293,7 @@ int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, cons
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), lds, st, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
-                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->d_counters);
+                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr);
   return PQT_OK;
 }
 #ifndef PQT_RSWG_SLICE_KB
@@ -305,6 +308,20 @@ int rswgGroup(const PqtDevParams& d) {
   for (int g : {4, 2, 1})
     if ((size_t)g * d.C1 * d.C1 * 4 <= 64 * 1024 && d.LP % g == 0 && (d.C1 * d.C1) % 4 == 0) return g;
   return 0;
+}
+
+// per-stage ms of one chunk of one ring slot: the time between two consecutive RECORDED events goes to the stage the later
+// one closes ({tables, traversal, order, rerank, select}); returns the last recorded event
+int stageMs(const pqt_index* idx, int slot, int ch, float st[5]) {
+  int prev = EV_BEGIN;
+  if (!(idx->evMask[slot][ch] & 1u)) return -1;
+  for (int e = 1; e < EV_COUNT; ++e) {
+    if (!(idx->evMask[slot][ch] & (1u << e))) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, idx->evRing[slot][ch][prev], idx->evRing[slot][ch][e]) == hipSuccess) st[e - 1] += ms;
+    prev = e;
+  }
+  return prev;
 }
 
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
@@ -349,7 +366,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) HIPCHK(hipEventCreate(&idx->evRing[r][c][e]));
     idx->evCreated = true;
   }
-  HIPCHK(hipMemsetAsync(idx->d_counters, 0, 8 * sizeof(unsigned long long), st));
+  // statistics block of this call; the next call's block is zeroed by the order kernel of this one (or a memset at the
+  // end when none runs), which saves a launch per call
+  idx->ctr = idx->d_counters + 8 * idx->ctrPos;
+  unsigned long long* nextCtr = idx->d_counters + 8 * ((idx->ctrPos + 1) % kCtrRing);
+  bool nextZeroed = false;
 
   const size_t lTab = ldsTables(d);
   if ((rc = allowLds(pqt_k_tables, lTab))) return rc;
@@ -380,19 +401,22 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
   idx->calls++;
+  // the two fused launches are bracketed by three events; the staged path keeps one event per stage
+  const bool leanEvents = travFused && fused;
+#define PQT_REC(e) do { HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][e], st)); idx->evMask[idx->ringPos][c] |= 1u << (e); } while (0)
   for (int c = 0; c < nChunks; ++c) {
     const uint32_t q0 = (uint32_t)c * qChunk;
     const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BEGIN], st));
+    idx->evMask[idx->ringPos][c] = 0;
+    PQT_REC(EV_BEGIN);
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
-      HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
 #define PQT_LAUNCH_TR1(WCR, SH)                                                                                         \
       hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
-                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->d_counters, idx->d_tstamp)
+                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) PQT_LAUNCH_TR1(WCR, true); else PQT_LAUNCH_TR1(WCR, false); } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
@@ -400,8 +424,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     } else {
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                       idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_counters);
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_TABLES], st));
+                       idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->ctr);
+    PQT_REC(EV_TABLES);
     // pass 1: small LDS arena (high occupancy); queries with more populated bins than it holds queue themselves for
     // pass 2, which runs the same kernel with a full-size arena on that (usually empty) list
     HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
@@ -414,23 +438,24 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                            idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->d_counters);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
       else
         hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                            idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->d_counters);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
     }
     }
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_BINS], st));
+    PQT_REC(EV_BINS);
     // balancing order for the wave-per-query rerank: only when a wavefront slot gets more than one query
     const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
     idx->curOrder = nullptr;
     if (fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves) {
-      hipLaunchKernelGGL(pqt_k_order_queries, dim3(1), dim3(1024), 0, st, idx->d_nLocal + q0, nq, idx->d_order + q0);
+      hipLaunchKernelGGL(pqt_k_order_queries, dim3(1), dim3(1024), 0, st, idx->d_nLocal + q0, nq, idx->d_order + q0, nextCtr);
+      nextZeroed = true;
       idx->curOrder = idx->d_order + q0;
     }
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_ORDER], st));
+    if (!leanEvents) PQT_REC(EV_ORDER);
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {
@@ -445,7 +470,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         if (rc) return rc;
       } else if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                    stride, k, nq, oI, oD, oP))) return rc;
-      HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
+      PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,
@@ -455,25 +480,28 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       hipLaunchKernelGGL(pqt_k_rerank<1>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,
                          idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_coarse, idx->d_cand, idx->d_candDist,
                          idx->d_nLocal + q0, stride, d);
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_RERANK], st));
+    PQT_REC(EV_RERANK);
     if (fullSort) {
       if (idx->sharded)
         hipLaunchKernelGGL(pqt_k_fullsort<true>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
-                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
+                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->ctr);
       else
         hipLaunchKernelGGL(pqt_k_fullsort<false>, dim3(nq), dim3(PQT_BLOCK), 0, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
-                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->d_counters);
+                           idx->d_nLocal + q0, stride, k, idx->d_sortKeys, sortP2, oI, oD, oP, idx->ctr);
     } else {
       if (idx->sharded)
         hipLaunchKernelGGL(pqt_k_select<true>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
-                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
+                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->ctr);
       else
         hipLaunchKernelGGL(pqt_k_select<false>, dim3(nq), dim3(PQT_BLOCK), lSel, st, idx->d_ids, idx->d_cand, idx->d_candDist, idx->d_candPos,
-                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->d_counters);
+                           idx->d_nLocal + q0, stride, k, kP2, oI, oD, oP, idx->ctr);
     }
     }
-    HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][EV_SELECT], st));
+    if (!leanEvents) PQT_REC(EV_SELECT);
   }
+#undef PQT_REC
+  if (!nextZeroed) HIPCHK(hipMemsetAsync(nextCtr, 0, 8 * sizeof(unsigned long long), st));
+  idx->ctrPos = (idx->ctrPos + 1) % kCtrRing;
   if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
@@ -520,10 +548,11 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
   for (uint32_t i = 0; i < PQT_MAXP; ++i) d.powers[i] = i < p.p ? upow(p.c1 * p.c2, i) : 0;  // treequantizer.hpp:45-49
   idx->maxMultiIndex = upow(d.WC, p.p);  // treequantizer.hpp:40-41 (wraps in uint32 like the reference)
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&idx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void**)&idx->d_counters, 8 * (kCtrRing + 1) * sizeof(unsigned long long)) != hipSuccess) {
     delete idx;
     return fail(PQT_ERR_DEVICE, "stream/counter allocation failed");
   }
+  (void)hipMemset(idx->d_counters, 0, 8 * (kCtrRing + 1) * sizeof(unsigned long long));
   size_t freeB = 0, totalB = 0;
   idx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
@@ -928,7 +957,7 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   if (rc) return rc;
   HIPCHK(hipDeviceSynchronize());
   unsigned long long c[8] = {0};
-  HIPCHK(hipMemcpy(c, idx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(c, idx->ctr ? idx->ctr : idx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
   pqt_stats s{};
   s.queries = idx->lastQn; s.ties_l1 = c[0]; s.ties_l2 = c[1]; s.ties_bins = c[2]; s.ties_final = c[3];
   s.max_bin = idx->maxBin;
@@ -942,16 +971,15 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
     for (uint32_t v : ni) s.bins_nonempty += v;
     s.bins_visited = (uint64_t)idx->lastHe * idx->lastQn;
   }
+  int lastEv = -1;
   for (int ch = 0; ch < idx->nChunks; ++ch) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BEGIN], idx->evRing[idx->ringPos][ch][EV_TABLES]) == hipSuccess) s.ms_tables += ms;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_TABLES], idx->evRing[idx->ringPos][ch][EV_BINS]) == hipSuccess) s.ms_bins += ms;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_BINS], idx->evRing[idx->ringPos][ch][EV_RERANK]) == hipSuccess) s.ms_rerank += ms;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_RERANK], idx->evRing[idx->ringPos][ch][EV_SELECT]) == hipSuccess) s.ms_select += ms;
+    float st[5] = {0, 0, 0, 0, 0};
+    lastEv = stageMs(idx, idx->ringPos, ch, st);
+    s.ms_tables += st[0]; s.ms_bins += st[1]; s.ms_rerank += st[2] + st[3]; s.ms_select += st[4];
   }
-  if (idx->nChunks > 0) {
+  if (idx->nChunks > 0 && lastEv > 0) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][0][EV_BEGIN], idx->evRing[idx->ringPos][idx->nChunks - 1][EV_SELECT]) == hipSuccess) s.ms_total = ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][0][EV_BEGIN], idx->evRing[idx->ringPos][idx->nChunks - 1][lastEv]) == hipSuccess) s.ms_total = ms;
   }
   idx->stats = s;
   *out = s;
@@ -967,11 +995,7 @@ int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
     // oldest of the n most recent calls first
     const int slot = (int)((idx->calls - n + i) % kRing);
     float st[5] = {0, 0, 0, 0, 0};
-    for (int ch = 0; ch < idx->ringChunks[slot]; ++ch) {
-      float ms = 0;
-      for (int e = 0; e < 5; ++e)
-        if (hipEventElapsedTime(&ms, idx->evRing[slot][ch][e], idx->evRing[slot][ch][e + 1]) == hipSuccess) st[e] += ms;
-    }
+    for (int ch = 0; ch < idx->ringChunks[slot]; ++ch) (void)stageMs(idx, slot, ch, st);
     for (int e = 0; e < 5; ++e) out[i * 5 + e] = st[e];
   }
   return n;
@@ -982,8 +1006,9 @@ int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
   if (hipSetDevice(idx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(PQT_ERR_DEVICE, "sync failed");
   int n = 0;
   for (int ch = 0; ch < idx->nChunks && n < cap; ++ch) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][ch][EV_ORDER], idx->evRing[idx->ringPos][ch][EV_RERANK]) != hipSuccess) return fail(PQT_ERR_DEVICE, "event read failed");
+    float st[5] = {0, 0, 0, 0, 0};
+    if (stageMs(idx, idx->ringPos, ch, st) < 0) return fail(PQT_ERR_DEVICE, "event read failed");
+    const float ms = st[3];
     out[n++] = ms;
   }
   return n;

@@ -858,13 +858,15 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 // Balancing order for pqt_k_rerank_select: the queries of one launch by descending candidate count.  Counting sort on
 // 256 buckets scaled to the largest count (the order inside a bucket is arbitrary: it only steers the schedule, never
 // a result).  One workgroup of 1024 threads; three passes over nLocal.
-__global__ __launch_bounds__(1024) void pqt_k_order_queries(const uint32_t* __restrict__ nLocal, uint32_t qn, uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(1024) void pqt_k_order_queries(const uint32_t* __restrict__ nLocal, uint32_t qn, uint32_t* __restrict__ order,
+                                                            unsigned long long* __restrict__ zero8 /* statistics block of the next call */) {
   __shared__ uint32_t sHist[256];
   __shared__ uint32_t sWave[4];
   __shared__ uint32_t sMax;
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   if (tid < 256) sHist[tid] = 0;
   if (tid == 0) sMax = 0;
+  if (tid < 8 && zero8) zero8[tid] = 0;
   // the first 16384 counts stay in registers for the three passes (16 independent loads in flight per thread)
   constexpr int RC = 16;
   uint32_t cnt[RC];
