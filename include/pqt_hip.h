@@ -214,7 +214,9 @@ int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
 /* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][5] = {tables, traversal/bins,
  * balancing order of the queries, rerank(+select when fused), select} in ms, from HIP events recorded on the launch
- * stream; returns n (<= cap). */
+ * stream; returns n (<= cap).  An event record costs ~5 us of stream time, so the fused path records only three per
+ * chunk: there "tables" and "select" are 0 (those stages are inside the two fused kernels) and the order kernel
+ * (~5 us) is booked under "traversal"; the rerank interval is the rerank kernel alone. */
 int pqt_get_stage_ms_history(const pqt_index* idx, float* out_ms, int cap);
 
 /* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------

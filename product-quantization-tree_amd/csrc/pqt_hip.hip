@@ -35,7 +35,10 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 #endif
 constexpr int kFusedWaves = PQT_RS_NW;
 constexpr int kCtrRing = 4;
-constexpr int kTravWaves = 4;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
+#ifndef PQT_TR_NW
+#define PQT_TR_NW 4
+#endif
+constexpr int kTravWaves = PQT_TR_NW;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
 }  // namespace
 
@@ -381,8 +384,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 
   // fused traversal (wave per query) when the bin list fits the in-register sorter
   const bool travFused = (He <= 512) && (d.WC <= 256) && !idx->forceUnfused;
-  const size_t travR0 = (std::max<size_t>(512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC)) + 15) & ~(size_t)15;
-  const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.D + d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
+  const size_t travR0 = (std::max<size_t>(512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
+  const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
   const size_t lTrav = (size_t)kTravWaves * travPerWave;
   if (travFused) {
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false>, lTrav))) return rc;
@@ -416,7 +419,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
-                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp)
+                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, (idx->dbg >> 5) & 15u)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) PQT_LAUNCH_TR1(WCR, true); else PQT_LAUNCH_TR1(WCR, false); } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
@@ -446,7 +449,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                            stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
     }
     }
-    PQT_REC(EV_BINS);
+    if (!leanEvents) PQT_REC(EV_BINS);
     // balancing order for the wave-per-query rerank: only when a wavefront slot gets more than one query
     const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
     idx->curOrder = nullptr;
@@ -455,7 +458,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       nextZeroed = true;
       idx->curOrder = idx->d_order + q0;
     }
-    if (!leanEvents) PQT_REC(EV_ORDER);
+    // lean recording: the (short) order kernel is booked with the traversal, so that the rerank interval is that kernel alone
+    if (leanEvents) PQT_REC(EV_BINS); else PQT_REC(EV_ORDER);
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {

@@ -775,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         for (int u = 0; u < U; ++u) {
           const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)id[u] * LP);
 #pragma unroll
-          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
+          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
         }
         if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
 #pragma unroll
@@ -912,7 +912,8 @@ __global__ __launch_bounds__(1024) void pqt_k_order_queries(const uint32_t* __re
 //       (8 independent 16-byte random reads in flight per lane), keys (f32 key << 32 | row) sorted in registers (512).
 //   a6  exclusive scan of the populations in visiting order (wave scan), cut, compact list of the non-empty
 //       included bins in LDS, candidates gathered by binary search over that list.
-// LDS per wavefront: D + LP*C1 + P*C1 + P*W + 3*P*WC words + 512 * 8 bytes.
+// LDS per wavefront: max(512 * 8 bytes, D + LP*C1 + P*WC words) time-shared + P*C1 + P*W + 2*P*WC words
+// (6.5 KB for the SIFT configuration: 6 workgroups of 4 wavefronts per CU).
 // ===================================================================================================
 template <int NW, int WCR, bool SHARDED>
 #ifndef PQT_TR_WPS
@@ -925,7 +926,10 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids, uint32_t qn,
     float* __restrict__ qL1virt, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
     uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
-    uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp) {
+    uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp,
+    uint32_t tdbg /* debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results): no bin-table
+                     probes / no cb2 reads / no cb1 reads */) {
+  const uint32_t forceFullOrder = tdbg & 1u;
 #define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, W = prm.W, LP = prm.LP, S = prm.S, SS = prm.SS,
@@ -935,12 +939,12 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   if (q >= qn) return;
   unsigned char* base = smem_raw + (size_t)wave * perWaveBytes;
   // region0 is time-shared: L1virt + unsorted d2 (a1/a2), then the per-row bin records and the compact bin list (a4-a6)
-  const uint32_t r0Bytes = perWaveBytes - 4 * (D + P * C1 + P * W + 2 * P * WC);
+  const uint32_t r0Bytes = perWaveBytes - 4 * (P * C1 + P * W + 2 * P * WC);
   uint64_t* sBin = (uint64_t*)base;                 // 512 : (gcount | lstart<<32) by row, later the compact bin list
   float* sVirt = (float*)base;                      // LP*C1     (dead before sBin is written)
   float* sD2 = sVirt + LP * C1;                     // P*WC unsorted staging (dead before sBin is written)
-  float* sQ = (float*)(base + r0Bytes);             // D
-  float* sL1 = sQ + D;                              // P*C1
+  float* sQ = sD2 + P * WC;                         // D         (read by a1 and a2 only: dead before sBin is written)
+  float* sL1 = (float*)(base + r0Bytes);            // P*C1
   uint32_t* sOrd = (uint32_t*)(sL1 + P * C1);       // P*W
   float* sSegD = (float*)(sOrd + P * W);            // P*WC sorted d2
   uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);    // P*WC sorted bin parts (pre-multiplied)
@@ -960,6 +964,8 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       const float* cen = cb1 + (size_t)c * D + lp * SS;
       const float* qq = sQ + lp * SS;
       float s = 0.f;
+      if (tdbg & 8u) { for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - (float)(c + d); s = s + df * df; } }
+      else
       for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
       acc[u] = s;
       dst[u] = t < C1 * LP ? lp * C1 + c : 0xffffffffu;
@@ -1023,7 +1029,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
         // cache line per lane); same dims in the same order
         const float4* cen4 = cb2T + ((size_t)p * C1 + c1) * (S / 4) * C2 + h2;
         for (uint32_t v = 0; v < S / 4; ++v) {
-          const float4 c = cen4[(size_t)v * C2];
+          const float4 c = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[(size_t)v * C2];
           float df = qq[4 * v] - c.x; s = s + df * df;
           df = qq[4 * v + 1] - c.y; s = s + df * df;
           df = qq[4 * v + 2] - c.z; s = s + df * df;
@@ -1081,6 +1087,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   PQT_TS(4);
   // ---- a4 + a5: 8 rows per lane, row h = lane + 64*r
   uint64_t key[8];
+  uint32_t recG[8], recL[8];  // population of the row's bin (0: empty), start of its members (sharded: table slot)
   {
     uint32_t glob[8];
 #pragma unroll
@@ -1111,116 +1118,197 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const uint32_t h = lane + 64 * r;
-      uint32_t slot;
-      const uint4 x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
-      if (h < He) sBin[h] = (uint64_t)x.y | ((uint64_t)(SHARDED ? slot : x.z) << 32);  // sharded: keep the slot, resolve local fields after the cut
+      uint32_t slot = 0;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (!(tdbg & 2u)) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
+      else if ((glob[r] & 15u) == 0) x = make_uint4(glob[r], 15u, (glob[r] >> 4) & 0xffffu, 15u);
+      recG[r] = h < He ? x.y : 0u;
+      recL[r] = SHARDED ? slot : x.z;  // sharded: keep the slot, resolve the local fields after the cut
     }
   }
-  __builtin_amdgcn_wave_barrier();
   PQT_TS(5);
-  pqt_wave_sort_u64<8>(key);
-  PQT_TS(6);
-  // ---- a6: scan populations in visiting order (element i = lane*8 + r)
-  uint32_t g8[8], ls8[8];
-  uint32_t sum = 0;
-  ties = 0;
+
+  // ---- a6, shared by the two orderings below.  skey: the sorted keys, element i = lane*R + r, low word & 0xffff = index
+  // of the bin's record in sBin; cnt elements.  Scans the populations in visiting order, applies the cut, writes the
+  // compact list of the included populated bins to LDS and gathers the candidates by binary search over it.
+  // Returns the number of included elements and (by reference) the candidate total.
+  auto finish = [&](auto& skey, const uint32_t cnt, uint32_t& totCandOut, uint64_t& lastInclKey) -> uint32_t {
+    constexpr int R = (int)(sizeof(skey) / sizeof(skey[0]));
+    uint32_t g8[R], ls8[R];
+    uint32_t sum = 0;
+    uint32_t tb = 0;
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const uint32_t i = lane * 8 + r;
-    g8[r] = 0; ls8[r] = 0;
-    if (i < He) {
-      const uint64_t b = sBin[(uint32_t)key[r]];
-      g8[r] = (uint32_t)b; ls8[r] = (uint32_t)(b >> 32);
-      const uint32_t hi = (uint32_t)(key[r] >> 32);
-      const uint32_t nx = (r < 7) ? (uint32_t)(key[(r + 1) & 7] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
-      if (i + 1 < He && hi == nx && !(r == 7 && lane == 63)) ++ties;
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = lane * R + r;
+      g8[r] = 0; ls8[r] = 0;
+      if (i < cnt) {
+        const uint64_t b = sBin[(uint32_t)skey[r] & 0xffffu];
+        g8[r] = (uint32_t)b; ls8[r] = (uint32_t)(b >> 32);
+        const uint32_t hi = (uint32_t)(skey[r] >> 32);
+        const uint32_t nx = (r + 1 < R) ? (uint32_t)(skey[(r + 1) % R] >> 32) : __shfl_down((uint32_t)(skey[0] >> 32), 1, 64);
+        if (i + 1 < cnt && hi == nx && !(r + 1 == R && lane == 63)) ++tb;
+      }
+      sum += g8[r];
     }
-    sum += g8[r];
-  }
-  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[2], (unsigned long long)ties); }
-  const uint32_t incl = pqt_wave_incl_scan(sum);
-  uint32_t run = incl - sum;  // exclusive prefix of this lane's first element
-  uint32_t myIncl = 0, myCand = 0, myNonEmpty = 0;
-  uint32_t ex8[8];
+    if (__any(tb != 0)) { if (tb) atomicAdd(&counters[2], (unsigned long long)tb); }
+    const uint32_t incl = pqt_wave_incl_scan(sum);
+    uint32_t run = incl - sum;  // exclusive prefix of this lane's first element
+    uint32_t myIncl = 0, myCand = 0, myNonEmpty = 0;
+    uint32_t ex8[R];
+    uint64_t myLast = 0;  // the keys ascend, so the largest included key is the last included element
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const uint32_t i = lane * 8 + r;
-    const uint32_t g = g8[r];  // 0 beyond He
-    ex8[r] = run;
-    if (i < He && run <= Bv) { ++myIncl; myCand += g; if (g) ++myNonEmpty; } else { g8[r] = 0; }
-    run += g;
-  }
-  __builtin_amdgcn_wave_barrier();
-  // wave totals
-  uint32_t totCand = myCand, totIncl = myIncl;
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) { totCand += __shfl_xor(totCand, d, 64); totIncl += __shfl_xor(totIncl, d, 64); }
-  if constexpr (!SHARDED) {
-    const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
-    const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
-    uint32_t wpos = neIncl - myNonEmpty;
-    // compact list (start in candidate list | lstart<<32), ordered by start; overwrites sBin (all reads done)
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
+    for (int r = 0; r < R; ++r) {
+      const uint32_t i = lane * R + r;
+      const uint32_t g = g8[r];  // 0 beyond cnt
+      ex8[r] = run;
+      if (i < cnt && run <= Bv) { ++myIncl; myCand += g; if (g) ++myNonEmpty; myLast = skey[r]; } else { g8[r] = 0; }
+      run += g;
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; nIncl[q] = totIncl; }
-    PQT_TS(7);
-    for (uint32_t j = lane; j < totCand; j += 64) {
-      uint32_t lo = 0, hi = m;  // last entry with start <= j
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+    // wave totals
+    uint32_t totCand = myCand, totIncl = myIncl;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      totCand += __shfl_xor(totCand, d, 64); totIncl += __shfl_xor(totIncl, d, 64);
+      const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(myLast >> 32), d, 64) << 32) | __shfl_xor((uint32_t)myLast, d, 64);
+      myLast = o > myLast ? o : myLast;
+    }
+    totCandOut = totCand;
+    lastInclKey = myLast;
+    if constexpr (!SHARDED) {
+      const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
+      const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
+      uint32_t wpos = neIncl - myNonEmpty;
+      // compact list (start in candidate list | lstart<<32), ordered by start; overwrites sBin (all reads done)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
       }
-      const uint64_t b = sBin[lo];
-      cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; }
+      PQT_TS(7);
+      for (uint32_t j = lane; j < totCand; j += 64) {
+        uint32_t lo = 0, hi = m;  // last entry with start <= j
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint64_t b = sBin[lo];
+        cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
+      }
+    } else {
+      // range shard: the cut above used the GLOBAL populations; now resolve what this device holds of the included bins
+      // (one more round trip, only for included populated bins) and build the LOCAL candidate list together with each
+      // candidate's global visiting position = global start of its bin + members held by lower shards + offset.
+      const uint4* table4 = reinterpret_cast<const uint4*>(table);
+      uint32_t lc8[R], gp8[R];
+      uint32_t myLocal = 0, myLocalBins = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        lc8[r] = 0; gp8[r] = 0;
+        if (g8[r]) {
+          const uint32_t slot = ls8[r];
+          const uint4 e = table4[slot];
+          ls8[r] = e.z; lc8[r] = e.w; gp8[r] = ex8[r] + lower[slot];
+          myLocal += e.w;
+          if (e.w) ++myLocalBins;
+        }
+      }
+      const uint32_t locIncl = pqt_wave_incl_scan(myLocal);
+      const uint32_t totLocal = __shfl(locIncl, 63, 64);
+      uint32_t lrun = locIncl - myLocal;
+      const uint32_t nbIncl = pqt_wave_incl_scan(myLocalBins);
+      const uint32_t m = __shfl(nbIncl, 63, 64);
+      uint32_t wpos = nbIncl - myLocalBins;
+      uint32_t* sGpos = (uint32_t*)(sBin + 512);  // 512 words: global position of the first local member of a listed bin
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (lc8[r]) { sBin[wpos] = (uint64_t)lrun | ((uint64_t)ls8[r] << 32); sGpos[wpos] = gp8[r]; ++wpos; lrun += lc8[r]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; }
+      PQT_TS(7);
+      for (uint32_t j = lane; j < totLocal; j += 64) {
+        uint32_t lo = 0, hi = m;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint64_t b = sBin[lo];
+        const uint32_t off = j - (uint32_t)b;
+        cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + off;
+        candPos[(size_t)q * stride + j] = sGpos[lo] + off;
+      }
+    }
+    return totIncl;
+  };
+
+  // Only the POPULATED rows have to be ordered: empty bins add nothing to the running count, so their place in the
+  // visiting order changes neither the cut nor a candidate's position.  Of the He rows a query enumerates, a few dozen
+  // are populated (the index holds far fewer bins than the multi-index has cells), and the sorting network is where
+  // this kernel spends its VALU instructions: 64 or 128 keys cost 7 % / 19 % of the 512-key network.
+  // The populated rows are compacted in row order (the tie-break), sorted, and finished as above; more than 128 of
+  // them (rare) fall back to ordering all rows.
+  uint32_t npop = 0;
+  uint32_t ent[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    uint32_t tot;
+    const uint32_t rk = pqt_ballot_rank(recG[r] != 0, &tot);
+    ent[r] = npop + rk;
+    npop += tot;
+  }
+  uint32_t totCand = 0, totIncl = 0;
+  uint64_t lastKey = 0;
+  if (npop <= 128 && !forceFullOrder) {
+    uint64_t* sKeyC = sBin + 128;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      if (recG[r]) {
+        sBin[ent[r]] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
+        sKeyC[ent[r]] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | ent[r];  // (distance, row, record)
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t inclPop;
+    if (npop <= 64) {
+      uint64_t k1[1] = {lane < npop ? sKeyC[lane] : ~0ull};
+      pqt_wave_sort_u64<1>(k1);
+      PQT_TS(6);
+      inclPop = finish(k1, npop, totCand, lastKey);
+    } else {
+      uint64_t k2[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) k2[r] = lane * 2 + r < npop ? sKeyC[lane * 2 + r] : ~0ull;
+      pqt_wave_sort_u64<2>(k2);
+      PQT_TS(6);
+      inclPop = finish(k2, npop, totCand, lastKey);
+    }
+    // rows visited before the cut: all of them unless a populated bin crossed the bound; then those up to that bin
+    totIncl = He;
+    if (inclPop && totCand > Bv) {
+      const uint64_t kx = (lastKey & 0xffffffff00000000ull) | ((lastKey >> 16) & 0xffffull);  // back to (distance, row)
+      uint32_t c = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) c += (key[r] <= kx) ? 1u : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+      totIncl = c;
     }
   } else {
-    // range shard: the cut above used the GLOBAL populations; now resolve what this device holds of the included bins
-    // (one more round trip, only for included populated bins) and build the LOCAL candidate list together with each
-    // candidate's global visiting position = global start of its bin + members held by lower shards + offset.
-    const uint4* table4 = reinterpret_cast<const uint4*>(table);
-    uint32_t lc8[8], gp8[8];
-    uint32_t myLocal = 0, myLocalBins = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      lc8[r] = 0; gp8[r] = 0;
-      if (g8[r]) {
-        const uint32_t slot = ls8[r];
-        const uint4 e = table4[slot];
-        ls8[r] = e.z; lc8[r] = e.w; gp8[r] = ex8[r] + lower[slot];
-        myLocal += e.w;
-        if (e.w) ++myLocalBins;
-      }
-    }
-    const uint32_t locIncl = pqt_wave_incl_scan(myLocal);
-    const uint32_t totLocal = __shfl(locIncl, 63, 64);
-    uint32_t lrun = locIncl - myLocal;
-    const uint32_t nbIncl = pqt_wave_incl_scan(myLocalBins);
-    const uint32_t m = __shfl(nbIncl, 63, 64);
-    uint32_t wpos = nbIncl - myLocalBins;
-    uint32_t* sGpos = (uint32_t*)(sBin + 512);  // 512 words: global position of the first local member of a listed bin
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      if (lc8[r]) { sBin[wpos] = (uint64_t)lrun | ((uint64_t)ls8[r] << 32); sGpos[wpos] = gp8[r]; ++wpos; lrun += lc8[r]; }
+      const uint32_t h = lane + 64 * r;
+      if (h < He) sBin[h] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; nIncl[q] = totIncl; }
-    PQT_TS(7);
-    for (uint32_t j = lane; j < totLocal; j += 64) {
-      uint32_t lo = 0, hi = m;
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
-      }
-      const uint64_t b = sBin[lo];
-      const uint32_t off = j - (uint32_t)b;
-      cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + off;
-      candPos[(size_t)q * stride + j] = sGpos[lo] + off;
-    }
+    pqt_wave_sort_u64<8>(key);
+    PQT_TS(6);
+    totIncl = finish(key, He, totCand, lastKey);
   }
+  if (lane == 0) nIncl[q] = totIncl;
   PQT_TS(8);
+  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef PQT_TS
 }
 
