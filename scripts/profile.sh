@@ -6,10 +6,10 @@ shift
 args="$@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --no-cpu $args > gpurun_out/prof/${tag}_bench.json 2> gpurun_out/prof/${tag}_bench.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --no-cpu $args > gpurun_out/prof/${tag}_bench.json 2> gpurun_out/prof/${tag}_bench.log
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/prof/ 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_${tag}_$c -o $tag -- python bench.py --no-cpu --steps 5 --warmup 2 $args > /dev/null 2> gpurun_out/prof/${tag}_pmc_$c.log
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_${tag}_$c -o $tag -- python bench.py --no-cpu --steps 5 --warmup 2 $args > /dev/null 2> gpurun_out/prof/${tag}_pmc_$c.log
   python - <<PY
 import csv, collections, glob
 fn = glob.glob('/tmp/prof_${tag}_$c/*counter_collection.csv')
