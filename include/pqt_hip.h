@@ -88,6 +88,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
  * "balance" = 0 disables the balancing order of the wave-per-query rerank (queries by descending candidate count,
  * dealt to the wavefronts in serpentine order); it only changes the schedule, never a result.
+ * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
+ * fallback it takes by itself when more than 128 rows are populated); results are identical.
  * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
  * candidate lists exceed it are processed in several chunks of queries. */
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);

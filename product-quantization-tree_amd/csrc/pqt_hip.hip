@@ -592,6 +592,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
+  if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }

@@ -401,3 +401,33 @@ def test_small_scratch_budget_chunks_the_batch():
             assert np.array_equal(big[0], big_ref[0]) and np.array_equal(bits(big[1]), bits(big_ref[1]))
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("name", ["tools_default", "ties", "cfg2_small"])
+def test_schedule_and_ordering_variants_change_nothing(name):
+    """A batch large enough that every wavefront slot of the fused rerank gets several queries (the balancing order and
+    the LDS tickets are active): identical results with the schedule off, with all rows ordered in the traversal, and
+    equal to the small-batch results of the same queries."""
+    f = fixture(name)
+    bv, bb = BV_BB[name]
+    idx = f.hip_index()
+    try:
+        small = idx.query(f.queries, bv, bb, 50)
+        reps = (5000 + len(f.queries) - 1) // len(f.queries)
+        big_q = np.tile(f.queries, (reps, 1))
+        ref = idx.query(big_q, bv, bb, 50)
+        n = len(f.queries)
+        for r in range(reps):
+            assert np.array_equal(ref[0][r * n:(r + 1) * n], small[0]) and np.array_equal(bits(ref[1][r * n:(r + 1) * n]), bits(small[1]))
+            assert np.array_equal(ref[2][r * n:(r + 1) * n], small[2])
+        st_ref = idx.stats()
+        for opt in ("balance", "order_all_rows"):
+            idx.set_option(opt, 0 if opt == "balance" else 1)
+            got = idx.query(big_q, bv, bb, 50)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
+            st = idx.stats()
+            for key in ("candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_final"):
+                assert st[key] == st_ref[key], key
+            idx.set_option(opt, 1 if opt == "balance" else 0)
+    finally:
+        idx.close()
