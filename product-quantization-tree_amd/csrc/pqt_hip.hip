@@ -220,7 +220,8 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   constexpr int UV = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
   const uint32_t c1 = idx->dp.C1;
   const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
-  auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, true> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, false>;
+  auto kern = (CL && c1 == 32) ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 5>
+            : p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,

@@ -656,7 +656,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #define PQT_RS_PEND 384
 #endif
 
-template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, bool C1P2>
+template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     const uint32_t* __restrict__ codes /* bin-ordered */, const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
@@ -669,13 +669,15 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
   constexpr int U = UREQ;
   constexpr uint32_t LP = LPV * 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const uint32_t C1 = prm.C1;
-  const uint32_t c1sh = C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u;  // power-of-two C1: shifts instead of quarter-rate multiplies
+  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : prm.C1;
+  constexpr bool C1P2 = C1M != 0;
+  const uint32_t c1sh = C1M >= 2 ? (uint32_t)C1M : (C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u);  // power-of-two C1: shifts instead of quarter-rate multiplies
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
   float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
+  const uint32_t vOff = (uint32_t)(reinterpret_cast<unsigned char*>(sVirt) - smem_raw);  // byte offset of this wave's L1virt copy
   const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4);
   if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem_raw + ticketOff) = 0;
   if (COARSE_LDS && !(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
@@ -797,9 +799,20 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
               const uint32_t p = v * 4 + x;
               const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
               const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
-              const float sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
-              const float sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
-              const float sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
+              float sb, sa, sc;
+              if constexpr (C1M >= 2 && COARSE_LDS) {
+                // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
+                // the part offsets go into the instructions' immediate fields
+                const uint32_t B4 = B << 2;
+                const uint32_t aV = (A << 2) + vOff, bV = B4 + vOff, aC = (A << (2 + C1M)) + B4;  // v_lshl_add, v_add, v_lshl_add
+                sb = *reinterpret_cast<const float*>(smem_raw + aV + p * (4u << C1M));
+                sa = *reinterpret_cast<const float*>(smem_raw + bV + p * (4u << C1M));
+                sc = *reinterpret_cast<const float*>(smem_raw + aC + p * (4u << (2 * C1M)));
+              } else {
+                sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
+                sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
+                sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
+              }
               acc = acc + pqt_extract_distance(sa, sb, sc, lam);
             }
           }
