@@ -292,8 +292,11 @@ int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, cons
   if (rc0) return rc0;
   const size_t lds = (size_t)G * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8;
   const bool p2 = (d.C1 & (d.C1 - 1)) == 0;
-  auto kern = idx->sharded ? (p2 ? pqt_k_rerank_select_wg<G, true, true> : pqt_k_rerank_select_wg<G, true, false>)
-                           : (p2 ? pqt_k_rerank_select_wg<G, false, true> : pqt_k_rerank_select_wg<G, false, false>);
+  const uint32_t c1v = idx->dp.C1;
+  auto kern = idx->sharded ? (c1v == 64 ? pqt_k_rerank_select_wg<G, true, 6> : c1v == 128 ? pqt_k_rerank_select_wg<G, true, 7>
+                              : p2 ? pqt_k_rerank_select_wg<G, true, 1> : pqt_k_rerank_select_wg<G, true, 0>)
+                           : (c1v == 64 ? pqt_k_rerank_select_wg<G, false, 6> : c1v == 128 ? pqt_k_rerank_select_wg<G, false, 7>
+                              : p2 ? pqt_k_rerank_select_wg<G, false, 1> : pqt_k_rerank_select_wg<G, false, 0>);
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), lds, st, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,

@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_exact(
 #define PQT_RS2_WPS 4    // waves per SIMD the register allocator must leave room for
 #endif
 
-template <int G, bool SHARDED, bool C1P2>
+template <int G, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
 __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_select_wg(
     const uint32_t* __restrict__ codesGrp /* bin-ordered, group-major: [LP/G][nIds][G] */, uint64_t nIds,
     const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
@@ -1484,8 +1484,9 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
     unsigned long long* __restrict__ counters) {
   constexpr int NW = PQT_RS2_NW, NT = NW * 64, CPT = PQT_RS2_CPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const uint32_t C1 = prm.C1, LP = prm.LP;
-  const uint32_t c1sh = C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u;  // power-of-two C1: shifts instead of quarter-rate multiplies
+  constexpr bool C1P2 = C1M != 0;
+  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : prm.C1, LP = prm.LP;
+  const uint32_t c1sh = C1M >= 2 ? (uint32_t)C1M : (C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u);  // power-of-two C1: shifts instead of quarter-rate multiplies
   const uint32_t chunkFloats = G * C1 * C1;
   float* sChunk = (float*)smem_raw;
   float* sVirt = sChunk + chunkFloats;
@@ -1553,10 +1554,20 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
             const uint32_t p = g * G + x;
             const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
             const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);
-            const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
-            const float sb = sVirt[pv + A];
-            const float sa = sVirt[pv + B];
-            const float sc = sChunk[C1P2 ? ((((uint32_t)x << c1sh) + A) << c1sh) + B : (x * C1 + A) * C1 + B];
+            float sb, sa, sc;
+            if constexpr (C1M >= 2) {
+              // compile-time strides: the table offsets fold into one uniform base and the DS immediate fields
+              const uint32_t B4 = B << 2;
+              const uint32_t vOffP = (uint32_t)(G << (2 * C1M + 2)) + ((p << C1M) << 2);  // byte offset of L1virt row p (uniform)
+              sb = *reinterpret_cast<const float*>(smem_raw + ((A << 2) + vOffP));
+              sa = *reinterpret_cast<const float*>(smem_raw + (B4 + vOffP));
+              sc = *reinterpret_cast<const float*>(smem_raw + ((A << (2 + C1M)) + B4) + ((uint32_t)x << (2 * C1M + 2)));
+            } else {
+              const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+              sb = sVirt[pv + A];
+              sa = sVirt[pv + B];
+              sc = sChunk[C1P2 ? ((((uint32_t)x << c1sh) + A) << c1sh) + B : (x * C1 + A) * C1 + B];
+            }
             a = a + pqt_extract_distance(sa, sb, sc, lam);
           }
           acc[i] = a;
