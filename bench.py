@@ -311,6 +311,19 @@ def main():
         queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
     else:  # fresh draws from the same mixture (like SIFT's separate query set)
         queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
+    if os.environ.get("PQT_EXP_QPERM"):
+        # experiment: give every XCD (workgroup b of the static rerank schedule runs on XCD b % 8) the queries of one
+        # contiguous slab of the last part's first-level cells, so that an XCD's L2 sees 1/8 of the code store
+        S_ = w["D"] // w["P"]
+        cb1_t = torch.from_numpy(meta["cb1"]).to(dev)[:, (w["P"] - 1) * S_:]
+        cell = torch.cdist(queries[:, (w["P"] - 1) * S_:], cb1_t).argmin(1)
+        srt = torch.argsort(cell, stable=True)
+        pos = torch.arange(qn, device=dev)
+        xcd = ((pos % 2048) // 8) % 8 if os.environ["PQT_EXP_QPERM"] == "xcd" else (pos * 8 // qn)
+        dest = torch.argsort(xcd, stable=True)          # batch positions grouped by the XCD that will serve them
+        perm = torch.empty(qn, dtype=torch.int64, device=dev)
+        perm[dest] = srt                                # position dest[i] receives the i-th query of the cell order
+        queries = queries[perm].contiguous()
     if chunked:
         gt = brute_force_gt_chunked(w, queries, dev)
         raw_u8 = None

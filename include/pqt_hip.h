@@ -86,8 +86,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
- * "balance" = 0 disables the balancing order of the wave-per-query rerank (queries by descending candidate count,
- * dealt to the wavefronts in serpentine order); it only changes the schedule, never a result.
+ * "balance" = 0 disables the dynamic schedule of the wave-per-query rerank (a workgroup's wavefronts draw its queries
+ * longest-first through an LDS ticket) in favour of a static round-robin; it only changes the schedule, never a result.
  * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
  * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
@@ -215,10 +215,9 @@ int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
  * stream it ran on; returns the number of launches written (<= cap). */
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
 /* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][5] = {tables, traversal/bins,
- * balancing order of the queries, rerank(+select when fused), select} in ms, from HIP events recorded on the launch
- * stream; returns n (<= cap).  An event record costs ~5 us of stream time, so the fused path records only three per
- * chunk: there "tables" and "select" are 0 (those stages are inside the two fused kernels) and the order kernel
- * (~5 us) is booked under "traversal"; the rerank interval is the rerank kernel alone. */
+ * reserved (0), rerank(+select when fused), select} in ms, from HIP events recorded on the launch stream; returns
+ * n (<= cap).  An event record costs ~5 us of stream time, so the fused path records only three per chunk: there
+ * "tables" and "select" are 0 (those stages are inside the two fused kernels). */
 int pqt_get_stage_ms_history(const pqt_index* idx, float* out_ms, int cap);
 
 /* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------

@@ -31,7 +31,7 @@ enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_ORDER, EV_RERANK, EV_SELECT, EV_COUN
 constexpr int kMaxChunks = 16;
 constexpr int kRing = 32;        // per-stage event sets of the last kRing query calls
 #ifndef PQT_RS_NW
-#define PQT_RS_NW 8
+#define PQT_RS_NW 12
 #endif
 constexpr int kFusedWaves = PQT_RS_NW;
 constexpr int kCtrRing = 4;
@@ -66,7 +66,7 @@ struct pqt_index {
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
-  uint32_t* d_order = nullptr; const uint32_t* curOrder = nullptr;  // balancing order of the current chunk (pqt_k_order_queries)
+  bool curDynamic = false; unsigned long long* curZero8 = nullptr;  // rerank schedule and next statistics block of the current chunk
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // kCtrRing blocks of 8 statistics words (one per call, the next one is zeroed on the fly) + 1 spare block
@@ -109,7 +109,6 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_nLocal, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_ovList, (size_t)qn))) return rc;
-  if ((rc = devAlloc(&idx->d_order, (size_t)qn))) return rc;
   if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
   idx->qCap = qn;
   return PQT_OK;
@@ -225,7 +224,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curOrder);
+                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8);
   return PQT_OK;
 }
 template <int LPV>
@@ -373,8 +372,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) HIPCHK(hipEventCreate(&idx->evRing[r][c][e]));
     idx->evCreated = true;
   }
-  // statistics block of this call; the next call's block is zeroed by the order kernel of this one (or a memset at the
-  // end when none runs), which saves a launch per call
+  // statistics block of this call; the next call's block is zeroed by the rerank kernel of this one (or a memset at the
+  // end when that kernel does not run), which saves a launch per call
   idx->ctr = idx->d_counters + 8 * idx->ctrPos;
   unsigned long long* nextCtr = idx->d_counters + 8 * ((idx->ctrPos + 1) % kCtrRing);
   bool nextZeroed = false;
@@ -403,7 +402,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
   const bool coarseLds = coarseBytes <= 64 * 1024;
-  const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16;
+  const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -453,17 +452,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                            stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
     }
     }
-    if (!leanEvents) PQT_REC(EV_BINS);
-    // balancing order for the wave-per-query rerank: only when a wavefront slot gets more than one query
+    // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query
     const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
-    idx->curOrder = nullptr;
-    if (fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves) {
-      hipLaunchKernelGGL(pqt_k_order_queries, dim3(1), dim3(1024), 0, st, idx->d_nLocal + q0, nq, idx->d_order + q0, nextCtr);
-      nextZeroed = true;
-      idx->curOrder = idx->d_order + q0;
-    }
-    // lean recording: the (short) order kernel is booked with the traversal, so that the rerank interval is that kernel alone
-    if (leanEvents) PQT_REC(EV_BINS); else PQT_REC(EV_ORDER);
+    idx->curDynamic = fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves;
+    idx->curZero8 = nullptr;
+    PQT_REC(EV_BINS);
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {
@@ -476,8 +469,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
            : wgG == 2 ? launchRSWG<2>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
                       : launchRSWG<1>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP);
         if (rc) return rc;
-      } else if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
-                                   stride, k, nq, oI, oD, oP))) return rc;
+      } else {
+        idx->curZero8 = nextCtr;  // the kernel also zeroes the statistics block of the next call
+        nextZeroed = true;
+        if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
+                                     stride, k, nq, oI, oD, oP))) return rc;
+      }
       PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)

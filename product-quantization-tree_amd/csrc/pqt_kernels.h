@@ -655,6 +655,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #ifndef PQT_RS_PEND
 #define PQT_RS_PEND 384
 #endif
+#define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
@@ -663,7 +664,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
     unsigned long long* __restrict__ counters, uint32_t dbg, unsigned long long* __restrict__ tstamp,
-    const uint32_t* __restrict__ order /* pqt_k_order_queries, or null: static round-robin */) {
+    uint32_t dynamic /* 1: workgroup-local dynamic schedule (several queries per wavefront), 0: static round-robin */,
+    unsigned long long* __restrict__ zero8 /* statistics block of the next call, zeroed here (saves a memset launch) */) {
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
   constexpr int U = UREQ;
@@ -679,32 +681,76 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
   float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
   const uint32_t vOff = (uint32_t)(reinterpret_cast<unsigned char*>(sVirt) - smem_raw);  // byte offset of this wave's L1virt copy
   const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4);
-  if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(smem_raw + ticketOff) = 0;
+  // Schedule.  Candidate counts differ several-fold between queries and wavefronts do not run equally fast (the
+  // younger of two wavefronts on a SIMD loses the issue arbitration): with a static round-robin over the wavefronts the
+  // launch lasted as long as its unluckiest wavefront, 50-60 % above the mean (debug timestamps).  So a workgroup owns
+  // the queries b, b + G, b + 2G, ... (G workgroups) and its wavefronts draw them through a ticket counter in LDS,
+  // longest first: wavefront 0 ranks the first PQT_RS_LIST of them by candidate count while the others copy the coarse
+  // table.  Tickets in global memory were measured and cost more than the imbalance they remove (same-address
+  // returning atomics serialise at ~0.15 us each even inside one XCD's L2), and a global longest-first order with
+  // serpentine workgroup lists (a separate 8 us kernel) gained less than it cost.
+  const uint32_t G = gridDim.x;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + ticketOff);
+  uint32_t* sList = sTicket + 4;             // PQT_RS_LIST: ordinal in the workgroup's list, longest first
+  uint32_t* sListN = sList + PQT_RS_LIST;    // PQT_RS_LIST: its candidate count
+  uint32_t* sTmpN = sListN + PQT_RS_LIST;    // PQT_RS_LIST: counts in list order (ranking input)
+  const uint32_t L = (dynamic && blockIdx.x < qn) ? (qn - blockIdx.x + G - 1) / G : 0u;
+  const uint32_t Ls = L < PQT_RS_LIST ? L : PQT_RS_LIST;
+  if (threadIdx.x == 0) *sTicket = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 8 && zero8) zero8[threadIdx.x] = 0;
+  if (dynamic && wave == 0) {
+    uint32_t ne[PQT_RS_LIST / 64];
+#pragma unroll
+    for (int j = 0; j < PQT_RS_LIST / 64; ++j) {
+      const uint32_t e = lane + 64 * j;
+      ne[j] = (e < Ls && !(dbg & 2)) ? nLocal[blockIdx.x + (size_t)e * G] : 0u;
+      if (e < Ls) sTmpN[e] = ne[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank[PQT_RS_LIST / 64];
+#pragma unroll
+    for (int j = 0; j < PQT_RS_LIST / 64; ++j) rank[j] = 0;
+    for (uint32_t f = 0; f < Ls; ++f) {
+      const uint32_t nf = sTmpN[f];  // broadcast read
+#pragma unroll
+      for (int j = 0; j < PQT_RS_LIST / 64; ++j) rank[j] += (nf > ne[j] || (nf == ne[j] && f < lane + 64 * j)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PQT_RS_LIST / 64; ++j) {
+      const uint32_t e = lane + 64 * j;
+      if (e < Ls) { sList[rank[j]] = e; sListN[rank[j]] = ne[j]; }
+    }
+  }
   if (COARSE_LDS && !(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
   __syncthreads();
   const float* cz = COARSE_LDS ? sCoarse : coarse;
 
-  // Schedule.  Candidate counts differ several-fold between queries and wavefronts do not run equally fast (the
-  // younger of two wavefronts on a SIMD loses the issue arbitration): with a static round-robin the launch lasted as
-  // long as its unluckiest wavefront, 50-60 % above the mean (debug timestamps).  `order` lists the queries by
-  // descending candidate count.  Workgroup b owns the ranks b, 2G-1-b, 2G+b, 4G-1-b, ... (G workgroups, serpentine:
-  // every workgroup gets the same mix of long and short queries), and its wavefronts take them from that list
-  // longest first through a ticket counter in LDS -- global tickets were tried and are slower than the imbalance
-  // they remove (same-address atomics serialise at ~0.15 us each, even inside one L2).
   const uint32_t slot = blockIdx.x * NW + wave;
-  const uint32_t G = gridDim.x;
-  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + ticketOff);
-  auto nextQuery = [&]() -> uint32_t {
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(sTicket, 1u);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    const uint64_t rank = (uint64_t)t * G + ((t & 1) ? G - 1 - blockIdx.x : blockIdx.x);
-    return rank < qn ? order[rank] : 0xffffffffu;
-  };
+  // next query of this wavefront and its candidate count (0xffffffff: count still to be fetched from global memory)
   uint32_t round = 0;
-  uint32_t q = order ? nextQuery() : (slot < qn ? slot : 0xffffffffu);
+  auto nextQuery = [&](uint32_t& cnt) -> uint32_t {
+    if (dynamic) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(sTicket, 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (t >= L) return 0xffffffffu;
+      uint32_t e = t;
+      cnt = 0xffffffffu;
+      if (t < Ls) { e = sList[t]; cnt = sListN[t]; }
+      return blockIdx.x + e * G;
+    }
+    const uint64_t nx = (uint64_t)round * G * NW + slot;
+    ++round;
+    cnt = 0xffffffffu;
+    return nx < qn ? (uint32_t)nx : 0xffffffffu;
+  };
+  uint32_t n = 0;
+  uint32_t q = nextQuery(n);
+  if (q != 0xffffffffu && n == 0xffffffffu) n = (dbg & 2) ? 0u : nLocal[q];
   while (q != 0xffffffffu) {
-    const uint32_t n = (dbg & 2) ? 0u : nLocal[q];
+    // the next query is chosen now; a count that is not in the LDS list is fetched under the final select + sort below
+    uint32_t nN = 0;
+    const uint32_t qN = nextQuery(nN);
     // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
     unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
     if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
@@ -829,6 +875,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
       }
       // single flush site: when the pending buffer could overflow on the next batch, and once at the end
       const bool last = base + 64 * U >= n;
+      if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
       if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) {
         if (tstamp) ts0 = __builtin_readcyclecounter();
         flush(last);
@@ -863,56 +910,9 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
       tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
       tstamp[(size_t)q * 16 + 14] = slot;
     }
-    if (order) q = nextQuery();
-    else { ++round; const uint64_t nx = (uint64_t)round * gridDim.x * NW + slot; q = nx < qn ? (uint32_t)nx : 0xffffffffu; }
+    q = qN;
+    n = nN;
   }
-}
-
-// Balancing order for pqt_k_rerank_select: the queries of one launch by descending candidate count.  Counting sort on
-// 256 buckets scaled to the largest count (the order inside a bucket is arbitrary: it only steers the schedule, never
-// a result).  One workgroup of 1024 threads; three passes over nLocal.
-__global__ __launch_bounds__(1024) void pqt_k_order_queries(const uint32_t* __restrict__ nLocal, uint32_t qn, uint32_t* __restrict__ order,
-                                                            unsigned long long* __restrict__ zero8 /* statistics block of the next call */) {
-  __shared__ uint32_t sHist[256];
-  __shared__ uint32_t sWave[4];
-  __shared__ uint32_t sMax;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  if (tid < 256) sHist[tid] = 0;
-  if (tid == 0) sMax = 0;
-  if (tid < 8 && zero8) zero8[tid] = 0;
-  // the first 16384 counts stay in registers for the three passes (16 independent loads in flight per thread)
-  constexpr int RC = 16;
-  uint32_t cnt[RC];
-#pragma unroll
-  for (int r = 0; r < RC; ++r) { const uint32_t q = tid + 1024u * r; cnt[r] = q < qn ? nLocal[q] : 0u; }
-  uint32_t m = 0;
-#pragma unroll
-  for (int r = 0; r < RC; ++r) m = cnt[r] > m ? cnt[r] : m;
-  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) { const uint32_t n = nLocal[q]; m = n > m ? n : m; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
-  __syncthreads();
-  if (lane == 0) atomicMax(&sMax, m);
-  __syncthreads();
-  const float scale = 255.f / (float)(sMax ? sMax : 1u);
-  auto bucket = [&](uint32_t n) -> uint32_t { const uint32_t b = (uint32_t)((float)n * scale); return 255u - (b > 255u ? 255u : b); };
-#pragma unroll
-  for (int r = 0; r < RC; ++r) if (tid + 1024u * r < qn) atomicAdd(&sHist[bucket(cnt[r])], 1u);
-  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) atomicAdd(&sHist[bucket(nLocal[q])], 1u);
-  __syncthreads();
-  // exclusive scan of the 256 buckets (largest counts first)
-  uint32_t h = 0, incl = 0;
-  if (tid < 256) { h = sHist[tid]; incl = pqt_wave_incl_scan(h); if (lane == 63) sWave[tid >> 6] = incl; }
-  __syncthreads();
-  if (tid < 256) {
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < (tid >> 6); ++w) before += sWave[w];
-    sHist[tid] = before + incl - h;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < RC; ++r) if (tid + 1024u * r < qn) order[atomicAdd(&sHist[bucket(cnt[r])], 1u)] = tid + 1024u * r;
-  for (uint32_t q = tid + 1024u * RC; q < qn; q += 1024) order[atomicAdd(&sHist[bucket(nLocal[q])], 1u)] = q;
 }
 
 // ===================================================================================================
