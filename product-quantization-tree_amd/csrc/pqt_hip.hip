@@ -36,7 +36,7 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 constexpr int kFusedWaves = PQT_RS_NW;
 constexpr int kCtrRing = 4;
 #ifndef PQT_TR_NW
-#define PQT_TR_NW 4
+#define PQT_TR_NW 1
 #endif
 constexpr int kTravWaves = PQT_TR_NW;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
 
