@@ -472,7 +472,7 @@ def main():
                      "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": rr_ms,
                      "algorithmic_bytes_per_launch": rr_bytes,
                      "timing": "mean over the timed steps of the interval between HIP events the library records on the launch stream; "
-                               "the fused path records 3 per chunk (begin | traversal + ~8 us order kernel | rerank_select)",
+                               "the fused path records 3 per chunk (begin | pqt_k_traverse | pqt_k_rerank_select)",
                      "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
                                                       "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}
                                        for n_ in kern if n_ != dominant}},
