@@ -386,8 +386,9 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   if (!fullSort) { if (idx->sharded) { if ((rc = allowLds(pqt_k_select<true>, lSel))) return rc; } else { if ((rc = allowLds(pqt_k_select<false>, lSel))) return rc; } }
 
   // fused traversal (wave per query) when the bin list fits the in-register sorter
-  const bool travFused = (He <= 512) && (d.WC <= 256) && !idx->forceUnfused;
-  const size_t travR0 = (std::max<size_t>(512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
+  const bool travFused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
+  const bool travWide = travFused && He > 512;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
+  const size_t travR0 = (std::max<size_t>(travWide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
   const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
   const size_t lTrav = (size_t)kTravWaves * travPerWave;
   if (travFused) {
@@ -417,16 +418,32 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     PQT_REC(EV_BEGIN);
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
+      if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
 #define PQT_LAUNCH_TR1(WCR, SH)                                                                                         \
       hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
-                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, (idx->dbg >> 5) & 15u)
+                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, \
+                         idx->d_ovList, idx->d_ovCount, (idx->dbg >> 5) & 15u)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) PQT_LAUNCH_TR1(WCR, true); else PQT_LAUNCH_TR1(WCR, false); } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
 #undef PQT_LAUNCH_TR1
+      if (travWide) {
+        // queries with more than 512 populated rows queued themselves: workgroup-per-query kernel with an He-sized arena
+        // on that (usually empty) list, from the sorted lists the traversal left in segD/segBin
+        if (idx->sharded)
+          hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                             idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                             idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+        else
+          hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
+                             idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
+                             idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+      }
     } else {
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,

@@ -940,6 +940,8 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     float* __restrict__ qL1virt, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
     uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
     uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp,
+    float* __restrict__ segDOut, uint32_t* __restrict__ segBOut /* [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over) */,
+    uint32_t* __restrict__ ovList, uint32_t* __restrict__ ovCount /* queries handed to pqt_k_bins (He > 512 and > 512 populated rows) */,
     uint32_t tdbg /* debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results): no bin-table
                      probes / no cb2 reads / no cb1 reads */) {
   const uint32_t forceFullOrder = tdbg & 1u;
@@ -1086,6 +1088,10 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
             const uint32_t pos = (uint32_t)key[m][r];
             sSegD[p * WC + e] = sD2[p * WC + pos];
             sSegB[p * WC + e] = (sOrd[p * W + pos / C2] * C2 + pos % C2) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
+            if (He > 512) {  // wide enumeration: keep the lists for the overflow hand-over to pqt_k_bins
+              segDOut[((size_t)q * P + p) * WC + e] = sD2[p * WC + pos];
+              segBOut[((size_t)q * P + p) * WC + e] = sOrd[p * W + pos / C2] * C2 + pos % C2;
+            }
           }
           // exact ties between neighbours of the sorted list (statistics only)
           const uint32_t hi = (uint32_t)(key[m][r] >> 32);
@@ -1098,39 +1104,40 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   if (__any(ties != 0)) { if (ties) atomicAdd(&counters[1], (unsigned long long)ties); }
   __builtin_amdgcn_wave_barrier();
   PQT_TS(4);
-  // ---- a4 + a5: 8 rows per lane, row h = lane + 64*r
+  // ---- a4 + a5: 8 rows per lane and block of 512 rows, row h = hb + lane + 64*r
   uint64_t key[8];
   uint32_t recG[8], recL[8];  // population of the row's bin (0: empty), start of its members (sharded: table slot)
-  {
+  auto rowKey = [&](const uint32_t h, uint32_t& globOut) -> uint64_t {
+    const uint4 hv = heur8[h];  // one 16-byte read: the row's P digits
+    const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
+    float fine = 0.f;
+    uint32_t g = 0;
+#pragma unroll
+    for (int p = 0; p < PQT_MAXP; ++p) {
+      if ((uint32_t)p < P) {
+        fine = fine + sSegD[p * WC + dg[p]];
+        g += sSegB[p * WC + dg[p]];
+      }
+    }
+    if (prm.hashMod) g %= prm.hashMod;
+    globOut = g;
+    return ((uint64_t)pqt_f2key(fine) << 32) | h;
+  };
+  auto rowBlock = [&](const uint32_t hb) {
     uint32_t glob[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t h = lane + 64 * r;
+      const uint32_t h = hb + lane + 64 * r;
       key[r] = ~0ull;
       glob[r] = 0;
-      if (h < He) {
-        const uint4 hv = heur8[h];  // one 16-byte read: the row's P digits
-        const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
-        float fine = 0.f;
-        uint32_t g = 0;
-#pragma unroll
-        for (int p = 0; p < PQT_MAXP; ++p) {
-          if ((uint32_t)p < P) {
-            fine = fine + sSegD[p * WC + dg[p]];
-            g += sSegB[p * WC + dg[p]];
-          }
-        }
-        if (prm.hashMod) g %= prm.hashMod;
-        glob[r] = g;
-        key[r] = ((uint64_t)pqt_f2key(fine) << 32) | h;
-      }
+      if (h < He) key[r] = rowKey(h, glob[r]);
     }
     // probes: first touch of all 8 slots is issued before any is consumed
     const uint4* table4 = reinterpret_cast<const uint4*>(table);  // {key, gcount, lstart, lcount}
     // 16 independent 16-byte reads per lane in flight, then resolved: exactly one memory round trip
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t h = lane + 64 * r;
+      const uint32_t h = hb + lane + 64 * r;
       uint32_t slot = 0;
       uint4 x = make_uint4(0, 0, 0, 0);
       if (!(tdbg & 2u)) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
@@ -1138,14 +1145,15 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       recG[r] = h < He ? x.y : 0u;
       recL[r] = SHARDED ? slot : x.z;  // sharded: keep the slot, resolve the local fields after the cut
     }
-  }
+  };
+  if (He <= 512) rowBlock(0);
   PQT_TS(5);
 
   // ---- a6, shared by the two orderings below.  skey: the sorted keys, element i = lane*R + r, low word & 0xffff = index
   // of the bin's record in sBin; cnt elements.  Scans the populations in visiting order, applies the cut, writes the
   // compact list of the included populated bins to LDS and gathers the candidates by binary search over it.
-  // Returns the number of included elements and (by reference) the candidate total.
-  auto finish = [&](auto& skey, const uint32_t cnt, uint32_t& totCandOut, uint64_t& lastInclKey) -> uint32_t {
+  // Returns the number of included populated bins and (by reference) the candidate total.
+  auto finish = [&](auto& skey, const uint32_t cnt, uint32_t& totCandOut) -> uint32_t {
     constexpr int R = (int)(sizeof(skey) / sizeof(skey[0]));
     uint32_t g8[R], ls8[R];
     uint32_t sum = 0;
@@ -1166,28 +1174,22 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     if (__any(tb != 0)) { if (tb) atomicAdd(&counters[2], (unsigned long long)tb); }
     const uint32_t incl = pqt_wave_incl_scan(sum);
     uint32_t run = incl - sum;  // exclusive prefix of this lane's first element
-    uint32_t myIncl = 0, myCand = 0, myNonEmpty = 0;
+    uint32_t myCand = 0, myNonEmpty = 0;
     uint32_t ex8[R];
-    uint64_t myLast = 0;  // the keys ascend, so the largest included key is the last included element
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const uint32_t i = lane * R + r;
       const uint32_t g = g8[r];  // 0 beyond cnt
       ex8[r] = run;
-      if (i < cnt && run <= Bv) { ++myIncl; myCand += g; if (g) ++myNonEmpty; myLast = skey[r]; } else { g8[r] = 0; }
+      if (i < cnt && run <= Bv) { myCand += g; if (g) ++myNonEmpty; } else { g8[r] = 0; }
       run += g;
     }
     __builtin_amdgcn_wave_barrier();
     // wave totals
-    uint32_t totCand = myCand, totIncl = myIncl;
+    uint32_t totCand = myCand, totNe = myNonEmpty;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      totCand += __shfl_xor(totCand, d, 64); totIncl += __shfl_xor(totIncl, d, 64);
-      const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(myLast >> 32), d, 64) << 32) | __shfl_xor((uint32_t)myLast, d, 64);
-      myLast = o > myLast ? o : myLast;
-    }
+    for (int d = 32; d > 0; d >>= 1) { totCand += __shfl_xor(totCand, d, 64); totNe += __shfl_xor(totNe, d, 64); }
     totCandOut = totCand;
-    lastInclKey = myLast;
     if constexpr (!SHARDED) {
       const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
       const uint32_t m = __shfl(neIncl, 63, 64);  // non-empty included bins
@@ -1253,7 +1255,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
         candPos[(size_t)q * stride + j] = sGpos[lo] + off;
       }
     }
-    return totIncl;
+    return totNe;
   };
 
   // Only the POPULATED rows have to be ordered: empty bins add nothing to the running count, so their place in the
@@ -1263,6 +1265,49 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   // The populated rows are compacted in row order (the tie-break), sorted, and finished as above; more than 128 of
   // them (rare) fall back to ordering all rows.
   uint32_t npop = 0;
+  uint32_t totCand = 0, totIncl = 0;  // candidates, included populated bins
+  if (He > 512) {
+    // Wide enumeration (512 < He <= 4096 rows): the rows go by in blocks of 512, their populated ones are appended to a
+    // 512-entry list (records + keys, 8 KB of LDS), which is then ordered and finished like the short list below.
+    // A query with more than 512 populated rows is handed to pqt_k_bins (workgroup per query, He-sized arena).
+    uint64_t* sKeyW = sBin + 512;
+    for (uint32_t hb = 0; hb < He; hb += 512) {
+      rowBlock(hb);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(recG[r] != 0, &tot);
+        const uint32_t e = npop + rk;
+        if (recG[r] && e < 512) {
+          sBin[e] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
+          sKeyW[e] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | e;  // (distance, row, record)
+        }
+        npop += tot;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (npop > 512) {
+      if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; }
+      return;
+    }
+    if (npop <= 128) {
+      uint64_t k2[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) k2[r] = lane * 2 + r < npop ? sKeyW[lane * 2 + r] : ~0ull;
+      pqt_wave_sort_u64<2>(k2);
+      PQT_TS(6);
+      totIncl = finish(k2, npop, totCand);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) key[r] = lane * 8 + r < npop ? sKeyW[lane * 8 + r] : ~0ull;
+      pqt_wave_sort_u64<8>(key);
+      PQT_TS(6);
+      totIncl = finish(key, npop, totCand);
+    }
+    if (lane == 0) nIncl[q] = totIncl;
+    PQT_TS(8);
+    return;
+  }
   uint32_t ent[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -1271,8 +1316,6 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     ent[r] = npop + rk;
     npop += tot;
   }
-  uint32_t totCand = 0, totIncl = 0;
-  uint64_t lastKey = 0;
   if (npop <= 128 && !forceFullOrder) {
     uint64_t* sKeyC = sBin + 128;
 #pragma unroll
@@ -1283,30 +1326,18 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
       }
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t inclPop;
     if (npop <= 64) {
       uint64_t k1[1] = {lane < npop ? sKeyC[lane] : ~0ull};
       pqt_wave_sort_u64<1>(k1);
       PQT_TS(6);
-      inclPop = finish(k1, npop, totCand, lastKey);
+      totIncl = finish(k1, npop, totCand);
     } else {
       uint64_t k2[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) k2[r] = lane * 2 + r < npop ? sKeyC[lane * 2 + r] : ~0ull;
       pqt_wave_sort_u64<2>(k2);
       PQT_TS(6);
-      inclPop = finish(k2, npop, totCand, lastKey);
-    }
-    // rows visited before the cut: all of them unless a populated bin crossed the bound; then those up to that bin
-    totIncl = He;
-    if (inclPop && totCand > Bv) {
-      const uint64_t kx = (lastKey & 0xffffffff00000000ull) | ((lastKey >> 16) & 0xffffull);  // back to (distance, row)
-      uint32_t c = 0;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) c += (key[r] <= kx) ? 1u : 0u;
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-      totIncl = c;
+      totIncl = finish(k2, npop, totCand);
     }
   } else {
 #pragma unroll
@@ -1317,7 +1348,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     __builtin_amdgcn_wave_barrier();
     pqt_wave_sort_u64<8>(key);
     PQT_TS(6);
-    totIncl = finish(key, He, totCand, lastKey);
+    totIncl = finish(key, He, totCand);
   }
   if (lane == 0) nIncl[q] = totIncl;
   PQT_TS(8);

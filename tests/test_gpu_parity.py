@@ -431,3 +431,74 @@ def test_schedule_and_ordering_variants_change_nothing(name):
             idx.set_option(opt, 1 if opt == "balance" else 0)
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("bb", [513, 700, 1300, 2304])
+@pytest.mark.parametrize("bv", [300, 10 ** 6])
+def test_wide_enumeration_in_the_fused_traversal(bb, bv):
+    """boundBins in (512, 4096]: the fused traversal enumerates the rows in blocks of 512 and orders the populated ones
+    (list of <= 512; queries with more are handed to the workgroup-per-query bins kernel).  A dense fixture puts the
+    queries in all three regimes (<= 128 populated rows, <= 512, overflow); results, counts and statistics equal the
+    staged kernels' and the oracle's."""
+    from common import Fixture
+
+    def uniform(n, D, seed):
+        return np.random.default_rng(seed).integers(0, 256, (n, D)).astype(np.float32)
+
+    # W*C2 = 48 -> 2304 tuples; 30000 vectors over <= 48^2 cells of which a query enumerates the bb nearest
+    f = Fixture(D=16, P=2, C1=8, C2=6, W=8, LP=4, n_base=1500 if bb < 1000 else 30000, n_query=24, seed=92, heur_rows=2304, train=1500, data=uniform)
+    idx = f.hip_index()
+    try:
+        idx.set_option("fused", 1)
+        got = idx.query(f.queries, bv, bb, 100)
+        st = idx.stats()
+        idx.set_option("fused", 0)
+        ref = idx.query(f.queries, bv, bb, 100)
+        st_ref = idx.stats()
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
+        for key in ("candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_final"):
+            assert st[key] == st_ref[key], key
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi, q in enumerate(f.queries[:6]):
+                s_ids, s_d = f.oracle.query(q, bv, bb)
+                kk = min(100, len(s_ids))
+                assert int(got[2][qi]) == len(s_ids)
+                assert np.array_equal(got[0][qi, :kk], s_ids[:kk]) and np.array_equal(bits(got[1][qi, :kk]), bits(s_d[:kk]))
+        finally:
+            f.oracle.set_sort_mode(0)
+    finally:
+        idx.close()
+
+
+@pytest.mark.parametrize("name", ["tools_default", "wrap"])
+def test_wide_enumeration_sharded_equals_unsharded(name):
+    """Two range shards with boundBins = 1000 (wide fused traversal, sharded variant): merged result identical to the
+    unsharded engine."""
+    import torch
+    f = fixture(name)
+    Bv, Bb, k = 2000, 1000, 64
+    n = f.oracle.num_vectors
+    cut = n // 3
+    idx = f.hip_index()
+    shards = [f.hip_index(shard=(0, cut)), f.hip_index(shard=(cut, n))]
+    try:
+        ref_ids, ref_d, ref_c = idx.query(f.queries, Bv, Bb, k)
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        I = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Dd = torch.empty((2, qn, k), dtype=torch.float32, device="cuda")
+        Pp = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Cc = torch.empty((2, qn), dtype=torch.int32, device="cuda")
+        for s_, sh in enumerate(shards):
+            sh.query_shard_dev(q, Bv, Bb, k, I[s_], Dd[s_], Pp[s_], Cc[s_], sync=True)
+        oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)
+        assert np.array_equal(Cc[0].cpu().numpy().view(np.uint32), ref_c)
+        assert np.array_equal(oI.cpu().numpy().view(np.uint32), ref_ids)
+        assert np.array_equal(bits(oD.cpu().numpy()), bits(ref_d))
+    finally:
+        idx.close()
+        for sh in shards:
+            sh.close()
