@@ -494,7 +494,7 @@ def main():
             i2 = out_idx.to(torch.int64) & 0xffffffff
             out["config"]["knobs_4096_4096"] = {"queries_per_sec": qn / t2, "ms_per_step": t2 * 1e3, "recall@1": recall_at(i2, gt, 1),
                                                 "recall@100": recall_at(i2, gt, 100), "mean_candidates": float(out_cnt.float().mean()),
-                                                "launch_structure": "staged bins kernel (boundBins > 512) + fused rerank/select"}
+                                                "launch_structure": "fused traversal in wide mode (boundBins > 512: rows in blocks of 512, populated rows listed) + fused rerank/select"}
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)  # restore the headline outputs
             torch.cuda.synchronize(dev)
         except Exception as e:
