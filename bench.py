@@ -386,6 +386,18 @@ def main():
                 % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3])))
             log("[tstamp] rerank_select sVirt load %d  output %d  select part of the last flush %d (medians)" % (np.median(ts[:, 0].astype(np.int64)), np.median(ts[:, 1].astype(np.int64)), np.median(ts[:, 2].astype(np.int64))))
             log("[tstamp] kernel span (first start .. last end): %d ; sum of per-query totals / 2048 wave slots: %d" % (r[:, 4].max() - r[:, 0].min(), tot.sum() // 2048))
+    if os.environ.get("PQT_DBG_SWEEP"):
+        # debug: stage times with parts of the kernels switched off (results wrong), same index, no rebuild
+        for v in os.environ["PQT_DBG_SWEEP"].split(","):
+            idx.set_option("debug_bits", int(v))
+            for _ in range(6):
+                step()
+            barrier()
+            h_ = idx.stage_ms_history(5).mean(0).tolist()
+            log("[dbg-sweep] bits %s: traverse %.4f  rerank_select %.4f ms" % (v, h_[1], h_[3]))
+        idx.set_option("debug_bits", 0)
+        step()
+        barrier()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -430,7 +442,8 @@ def main():
     fused_rs = args.k <= 128
     bytes_trav = qn * (4 * w["D"] + 4 * LP * C1 + 48 * bins_visited) + 8 * cand_local
     bytes_rs = cand_local * (4 * LP + 4 + (0 if fused_rs else 4)) + qn * (4 * LP * C1 + 8 * k)
-    kern = {"traverse": ("pqt_k_traverse", bytes_trav), "rerank_select": ("pqt_k_rerank_select" if fused_rs else "pqt_k_rerank", bytes_rs)}
+    rs_name = ("pqt_k_rerank_select_wg" if 4 * LP * C1 * C1 > 65536 else "pqt_k_rerank_select") if fused_rs else "pqt_k_rerank"
+    kern = {"traverse": ("pqt_k_traverse", bytes_trav), "rerank_select": (rs_name, bytes_rs)}
     dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
     rr_name, rr_bytes = kern[dominant]
     rr_ms = float(stage[dominant])
@@ -472,7 +485,7 @@ def main():
                      "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": rr_ms,
                      "algorithmic_bytes_per_launch": rr_bytes,
                      "timing": "mean over the timed steps of the interval between HIP events the library records on the launch stream; "
-                               "the fused path records 3 per chunk (begin | pqt_k_traverse | pqt_k_rerank_select)",
+                               "the fused path records 3 per chunk (begin | pqt_k_traverse | rerank+select kernel)",
                      "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
                                                       "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}
                                        for n_ in kern if n_ != dominant}},

@@ -299,7 +299,7 @@ int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, cons
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), lds, st, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
-                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr);
+                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr, idx->dbg);
   return PQT_OK;
 }
 #ifndef PQT_RSWG_SLICE_KB
@@ -610,6 +610,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
+  if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);

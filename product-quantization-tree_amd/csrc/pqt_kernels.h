@@ -1501,6 +1501,9 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_exact(
 #ifndef PQT_RS2_KEYS
 #define PQT_RS2_KEYS 512  // key slots per wavefront: [best 128 | pending]; 512 -> sort<8>, 256 -> sort<4>
 #endif
+#ifndef PQT_RS2_PF
+#define PQT_RS2_PF 6    // code-word prefetch distance (candidates per thread in flight; 4..8 measure the same)
+#endif
 #ifndef PQT_RS2_WPS
 #define PQT_RS2_WPS 4    // waves per SIMD the register allocator must leave room for
 #endif
@@ -1512,7 +1515,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, PqtDevParams prm,
     uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
-    unsigned long long* __restrict__ counters) {
+    unsigned long long* __restrict__ counters, uint32_t dbg /* ablation bits (wrong results): 1 no sorts, 8 no ADC arithmetic, 16 cache-resident rows */) {
   constexpr int NW = PQT_RS2_NW, NT = NW * 64, CPT = PQT_RS2_CPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr bool C1P2 = C1M != 0;
@@ -1539,7 +1542,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
       const uint32_t e = lane * KR + r;
       key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
     }
-    pqt_wave_sort_u64<KR>(key);
+    if (!(dbg & 1)) pqt_wave_sort_u64<KR>(key);
     if (lane < PQT_RS_BEST / KR) {
 #pragma unroll
       for (int r = 0; r < KR; ++r) sKeys[lane * KR + r] = key[r];
@@ -1558,9 +1561,24 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
     for (int i = 0; i < CPT; ++i) {
       const uint32_t j = tid + NT * i;
       pos[i] = cid[tile0 + (j < tn ? j : 0)];
+      if (dbg & 16) pos[i] &= 4095u;
       acc[i] = 0.f;
     }
     for (uint32_t g = 0; g < LP / G; ++g) {
+      // the G code words of this group for the first PF candidates of the thread are requested before the table slice is
+      // staged (their round trip overlaps the staging and its barriers), the others PF candidates ahead of the
+      // arithmetic that consumes them.  Group-major store: the G words of consecutive candidates (consecutive positions inside a
+      // bin) are contiguous, so a wavefront's 64 reads coalesce into one 1 KB (G = 4) transaction.
+      constexpr int PF = CPT < PQT_RS2_PF ? CPT : PQT_RS2_PF;  // candidates whose words are in flight ahead of the arithmetic
+      uint32_t wBuf[PF][G];
+      auto loadWords = [&](const int i) {
+        const uint32_t* row = codesGrp + ((size_t)g * nIds + pos[i]) * G;
+        if (G == 4) { const uint4 v = *reinterpret_cast<const uint4*>(row); wBuf[i % PF][0] = v.x; wBuf[i % PF][1 % G] = v.y; wBuf[i % PF][2 % G] = v.z; wBuf[i % PF][3 % G] = v.w; }
+        else if (G == 2) { const uint2 v = *reinterpret_cast<const uint2*>(row); wBuf[i % PF][0] = v.x; wBuf[i % PF][1 % G] = v.y; }
+        else { wBuf[i % PF][0] = row[0]; }
+      };
+#pragma unroll
+      for (int i = 0; i < PF; ++i) loadWords(i);
       __syncthreads();  // everyone is done with the previous group's table (and sVirt is loaded)
       {
         const float4* src = reinterpret_cast<const float4*>(coarse + (size_t)g * chunkFloats);
@@ -1568,18 +1586,18 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
         for (uint32_t t = tid; t < chunkFloats / 4; t += NT) dst[t] = src[t];
       }
       __syncthreads();
-#pragma unroll 4
+#pragma unroll
       for (int i = 0; i < CPT; ++i) {
         const uint32_t j = tid + NT * i;
         if (j < tn) {
           uint32_t w[G];
-          // group-major store: the G words of consecutive candidates (consecutive positions inside a bin) are contiguous,
-          // so a wavefront's 64 reads coalesce into one 1 KB (G = 4) transaction
-          const uint32_t* row = codesGrp + ((size_t)g * nIds + pos[i]) * G;
-          if (G == 4) { const uint4 v = *reinterpret_cast<const uint4*>(row); w[0] = v.x; w[1 % G] = v.y; w[2 % G] = v.z; w[3 % G] = v.w; }
-          else if (G == 2) { const uint2 v = *reinterpret_cast<const uint2*>(row); w[0] = v.x; w[1 % G] = v.y; }
-          else { w[0] = row[0]; }
+#pragma unroll
+          for (int x = 0; x < G; ++x) w[x] = wBuf[i % PF][x];
           float a = acc[i];
+          if (dbg & 8) { uint32_t xx = 0;
+#pragma unroll
+            for (int x = 0; x < G; ++x) xx ^= w[x];
+            a = a + __uint_as_float(xx & 0x3fffffffu); } else
 #pragma unroll
           for (int x = 0; x < G; ++x) {
             const uint32_t p = g * G + x;
@@ -1603,6 +1621,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
           }
           acc[i] = a;
         }
+        if (i + PF < CPT) loadWords(i + PF);  // refill the slot just consumed
       }
     }
     // selection: wave-synchronous append of the survivors
