@@ -1043,12 +1043,26 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
         // a cell read 512..1024 contiguous bytes per instruction (row-per-lane reads of the file layout touch one
         // cache line per lane); same dims in the same order
         const float4* cen4 = cb2T + ((size_t)p * C1 + c1) * (S / 4) * C2 + h2;
-        for (uint32_t v = 0; v < S / 4; ++v) {
-          const float4 c = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[(size_t)v * C2];
-          float df = qq[4 * v] - c.x; s = s + df * df;
-          df = qq[4 * v + 1] - c.y; s = s + df * df;
-          df = qq[4 * v + 2] - c.z; s = s + df * df;
-          df = qq[4 * v + 3] - c.w; s = s + df * df;
+        // 8 vectors of the row are requested together (one round trip per 32 dims instead of one per 4), then summed in
+        // dimension order
+        for (uint32_t v0 = 0; v0 < S / 4; v0 += 8) {
+          float4 c[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t v = v0 + e;
+            c[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < S / 4) c[e] = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[(size_t)v * C2];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const uint32_t v = v0 + e;
+            if (v < S / 4) {
+              float df = qq[4 * v] - c[e].x; s = s + df * df;
+              df = qq[4 * v + 1] - c[e].y; s = s + df * df;
+              df = qq[4 * v + 2] - c[e].z; s = s + df * df;
+              df = qq[4 * v + 3] - c[e].w; s = s + df * df;
+            }
+          }
         }
       } else {
         const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
