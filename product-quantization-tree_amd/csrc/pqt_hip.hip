@@ -948,6 +948,8 @@ int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out, uint32_t qn
 }
 
 int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_bytes, uint64_t gathers, float* out_ms) {
+  const bool coop = (row_bytes & 0x1000u) != 0;  // + 0x1000: one lane per 16-byte piece (adjacent lanes share a row)
+  row_bytes &= 0xfffu;
   if ((row_bytes != 64 && row_bytes != 128) || log2_rows < 10 || log2_rows > 34) return fail(PQT_ERR_INVALID, "row_bytes 64|128, 10 <= log2_rows <= 34");
   HIPCHK(hipSetDevice(device));
   const uint64_t rows = 1ull << log2_rows;
@@ -962,7 +964,11 @@ int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_byte
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipEventRecord(e0, 0));
   const unsigned grid = (unsigned)((gathers + 255) / 256);
-  if (row_bytes == 64) hipLaunchKernelGGL(pqt_k_calib_gather<4>, dim3(grid), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
+  if (coop) {
+    const unsigned gridc = (unsigned)((gathers * (row_bytes / 16) + 255) / 256);
+    if (row_bytes == 64) hipLaunchKernelGGL(pqt_k_calib_gather_coop<4>, dim3(gridc), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
+    else hipLaunchKernelGGL(pqt_k_calib_gather_coop<8>, dim3(gridc), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
+  } else if (row_bytes == 64) hipLaunchKernelGGL(pqt_k_calib_gather<4>, dim3(grid), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
   else hipLaunchKernelGGL(pqt_k_calib_gather<8>, dim3(grid), dim3(256), 0, 0, (const uint4*)table, rows, gathers, sink);
   HIPCHK(hipEventRecord(e1, 0));
   HIPCHK(hipDeviceSynchronize());

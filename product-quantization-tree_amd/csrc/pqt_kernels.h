@@ -1415,6 +1415,19 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restric
   if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
 }
 
+// the same gather with ROWV lanes per row: lane c of a group reads piece c, so a row is one contiguous ROWV*16-byte access of
+// adjacent lanes instead of ROWV separate 16-byte accesses of one lane at 16-byte steps
+template <int ROWV>
+__global__ __launch_bounds__(256) void pqt_k_calib_gather_coop(const uint4* __restrict__ table, uint64_t tableRows, uint64_t gathers,
+                                                                unsigned long long* __restrict__ sink) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t i = t / ROWV;
+  if (i >= gathers) return;
+  const uint64_t row = (i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull) & (tableRows - 1);
+  const uint4 x = table[row * ROWV + (t % ROWV)];
+  const uint32_t acc = x.x ^ x.y ^ x.z ^ x.w;
+  if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // one-off at load time: the line store is permuted into BIN ORDER (row pos holds the code of vector ids[pos]), so
