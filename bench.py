@@ -491,6 +491,29 @@ def main():
                                        for n_ in kern if n_ != dominant}},
     }
 
+    # ---- measured stream bandwidth of this device (device-to-device copy of 1 GiB: read + write), reported beside the nominal
+    # peak the fractions above are priced with
+    if mode == "single":
+        try:
+            a_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            b_ = torch.empty_like(a_)
+            a_.fill_(1.0)
+            for _ in range(2):
+                b_.copy_(a_)
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0_.record()
+            for _ in range(5):
+                b_.copy_(a_)
+            e1_.record()
+            torch.cuda.synchronize(dev)
+            gbs_ = 5 * 2 * a_.numel() * 4 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+            out["roofline"]["measured_stream_GBps"] = gbs_
+            out["roofline"]["frac_of_measured_stream"] = rr_gbs / gbs_
+            del a_, b_
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["roofline"]["measured_stream_GBps"] = None
+
     # ---- second knob set of BASELINE.md (the CUDA library's defaults k1/maxBins: boundVectors = boundBins = 4096), short leg,
     # reported beside the headline (never as `value`)
     if args.extras and mode == "single" and (args.bv, args.bb) == (20000, 500) and not chunked:

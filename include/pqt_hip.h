@@ -90,6 +90,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * longest-first through an LDS ticket) in favour of a static round-robin; it only changes the schedule, never a result.
  * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
+ * "debug_bits" = ablation switches of the fused kernels (measurement only: results are WRONG for non-zero values;
+ * scripts/ablate*.sh, PQT_DBG).
  * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
  * candidate lists exceed it are processed in several chunks of queries. */
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);
