@@ -67,6 +67,7 @@ struct pqt_index {
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
   bool curDynamic = false; unsigned long long* curZero8 = nullptr;  // rerank schedule and next statistics block of the current chunk
+  uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
   unsigned long long* d_counters = nullptr;  // kCtrRing blocks of 8 statistics words (one per call, the next one is zeroed on the fly) + 1 spare block
@@ -177,6 +178,21 @@ int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vect
   if (sharded) {
     if ((rc = devAlloc(&idx->d_lower, tsz))) return rc;
     HIPCHK(hipMemcpy(idx->d_lower, lower.data(), tsz * 4, hipMemcpyHostToDevice));
+  }
+  {
+    // presence filter: >= 64 bits per bin (<= 1.6 % set), between 2^16 and 2^28 bits
+    uint32_t fb = 16;
+    const uint64_t perBin = getenv("PQT_FILTER_BITS_PER_BIN") ? (uint64_t)atoi(getenv("PQT_FILTER_BITS_PER_BIN")) : 64;
+    while (((uint64_t)1 << fb) < perBin * (uint64_t)bins.size() && fb < 28) ++fb;
+    std::vector<uint32_t> filt((size_t)1 << (fb - 5), 0u);
+    for (const BinDesc& b0 : bins) {
+      if (b0.gcount == 0) continue;
+      const uint32_t bit = pqt_hash_filter(b0.key, fb);
+      filt[bit >> 5] |= 1u << (bit & 31u);
+    }
+    if ((rc = devAlloc(&idx->d_filter, filt.size()))) return rc;
+    HIPCHK(hipMemcpy(idx->d_filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
+    idx->filterBits = fb;
   }
   if ((rc = devAlloc(&idx->d_ids, localIds.size()))) return rc;
   if (!localIds.empty()) HIPCHK(hipMemcpy(idx->d_ids, localIds.data(), localIds.size() * 4, hipMemcpyHostToDevice));
@@ -425,7 +441,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
                          idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, \
-                         idx->d_ovList, idx->d_ovCount, (idx->dbg >> 5) & 15u)
+                         idx->d_ovList, idx->d_ovCount, (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) PQT_LAUNCH_TR1(WCR, true); else PQT_LAUNCH_TR1(WCR, false); } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
@@ -590,7 +606,7 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_lower, idx->d_ids,
+  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);

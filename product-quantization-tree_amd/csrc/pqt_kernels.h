@@ -942,6 +942,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp,
     float* __restrict__ segDOut, uint32_t* __restrict__ segBOut /* [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over) */,
     uint32_t* __restrict__ ovList, uint32_t* __restrict__ ovCount /* queries handed to pqt_k_bins (He > 512 and > 512 populated rows) */,
+    const uint32_t* __restrict__ filter, uint32_t filterBits /* presence bitmap over the bin keys, or null */,
     uint32_t tdbg /* debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results): no bin-table
                      probes / no cb2 reads / no cb1 reads */) {
   const uint32_t forceFullOrder = tdbg & 1u;
@@ -1149,12 +1150,25 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     // probes: first touch of all 8 slots is issued before any is consumed
     const uint4* table4 = reinterpret_cast<const uint4*>(table);  // {key, gcount, lstart, lcount}
     // 16 independent 16-byte reads per lane in flight, then resolved: exactly one memory round trip
+    // almost all enumerated rows name empty bins: one 4-byte read of the presence bitmap (a few hundred KB, L2 resident)
+    // settles those, only the rows whose bit is set go on to the two 16-byte table probes (measured: -10 % on the
+    // traversal at 500 rows per query, -27 % at 4096 where the probe rate is the bound)
+    uint32_t maybe = 0xffu;
+    if (filter) {
+      uint32_t fw[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) fw[r] = filter[pqt_hash_filter(glob[r], filterBits) >> 5];
+      maybe = 0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) maybe |= ((fw[r] >> (pqt_hash_filter(glob[r], filterBits) & 31u)) & 1u) << r;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const uint32_t h = hb + lane + 64 * r;
       uint32_t slot = 0;
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (!(tdbg & 2u)) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
+      if (!((maybe >> r) & 1u)) { }
+      else if (!(tdbg & 2u)) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
       else if ((glob[r] & 15u) == 0) x = make_uint4(glob[r], 15u, (glob[r] >> 4) & 0xffffu, 15u);
       recG[r] = h < He ? x.y : 0u;
       recL[r] = SHARDED ? slot : x.z;  // sharded: keep the slot, resolve the local fields after the cut

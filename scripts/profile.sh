@@ -5,6 +5,7 @@ tag=${1:-r01}
 shift
 args="$@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PQT_BENCH_NO_PIPELINE=1   # only the headline launches in the kernel statistics (no half-batch two-stream leg)
 mkdir -p gpurun_out/prof
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --no-cpu $args > gpurun_out/prof/${tag}_bench.json 2> gpurun_out/prof/${tag}_bench.log
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/prof/ 2>/dev/null
