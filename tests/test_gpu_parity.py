@@ -502,3 +502,37 @@ def test_wide_enumeration_sharded_equals_unsharded(name):
         idx.close()
         for sh in shards:
             sh.close()
+
+
+@pytest.mark.parametrize("name,bb", [("tools_default", 500), ("odd", 144), ("tools_default", 900)])
+def test_hashed_db_triple_without_aliasing_equals_exact_bins(name, bb):
+    """The CUDA tools' database triple (prefix, counts, dbIdx over HASH_SIZE slots, PerturbationProTree.hh:66) with a
+    hash size above every bin id (slot == bin id, nothing aliases) must give the results of the exact-key bin table:
+    covers the `% HASH_SIZE` path of the traversal, its presence bitmap and the wide enumeration."""
+    f = fixture(name)
+    bv = BV_BB[name][0]
+    pkg = pqt_pkg()
+    c = f.cfg
+    max_id = int(np.max(f.bin_ids)) if len(f.bin_ids) else 0
+    hash_size = max_id + 17
+    assert hash_size < 2 ** 31
+    prefix = np.zeros(hash_size, np.uint32)
+    counts = np.zeros(hash_size, np.uint32)
+    starts = np.concatenate([[0], np.cumsum(f.bin_sizes)[:-1]]).astype(np.uint32) if len(f.bin_sizes) else np.zeros(0, np.uint32)
+    prefix[f.bin_ids] = starts
+    counts[f.bin_ids] = f.bin_sizes
+    ref_idx = f.hip_index()
+    idx = pkg.PqtIndex(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], device=0)
+    try:
+        idx.set_codebooks(f.cb1, f.cb2)
+        idx.set_heuristic(f.heur)
+        idx.set_db_hashed(prefix, counts, f.members, hash_size)
+        idx.set_lines(f.codes)
+        ref = ref_idx.query(f.queries, bv, bb, 64)
+        for mode in (1, 0):
+            idx.set_option("fused", mode)
+            got = idx.query(f.queries, bv, bb, 64)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
+    finally:
+        idx.close()
+        ref_idx.close()
