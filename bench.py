@@ -369,7 +369,7 @@ def main():
     # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
     hist = idx.stage_ms_history(min(args.steps, 32))
     st = idx.stats()
-    stage = dict(zip(("tables", "traverse", "order", "rerank_select", "select"), hist.mean(0).tolist()))
+    stage = dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), hist.mean(0).tolist()))
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
         ts = np.zeros((qn, 16), np.uint64)
@@ -484,8 +484,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": rr_ms,
                      "algorithmic_bytes_per_launch": rr_bytes,
-                     "timing": "mean over the timed steps of the interval between HIP events the library records on the launch stream; "
-                               "the fused path records 3 per chunk (begin | pqt_k_traverse | rerank+select kernel)",
+                     "timing": "mean over the timed steps of the kernel's own duration: start/stop HIP events attached to the dispatch "
+                               "(hipExtLaunchKernel) on the launch stream, read after the closing barrier",
                      "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
                                                       "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}
                                        for n_ in kern if n_ != dominant}},

@@ -217,9 +217,11 @@ int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
  * stream it ran on; returns the number of launches written (<= cap). */
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
 /* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][5] = {tables, traversal/bins,
- * reserved (0), rerank(+select when fused), select} in ms, from HIP events recorded on the launch stream; returns
- * n (<= cap).  An event record costs ~5 us of stream time, so the fused path records only three per chunk: there
- * "tables" and "select" are 0 (those stages are inside the two fused kernels). */
+ * gap, rerank(+select when fused), select} in ms; returns n (<= cap).  On the fused path the start/stop timestamps ride
+ * on the two kernel dispatches themselves (hipExtLaunchKernel; no event packets on the stream): "traversal" and "rerank"
+ * are the pure durations of pqt_k_traverse and of the rerank+select kernel, "gap" is the time between them, "tables" and
+ * "select" are 0 (those stages are inside the two fused kernels).  The staged path records one HIP event per stage
+ * (gap = 0). */
 int pqt_get_stage_ms_history(const pqt_index* idx, float* out_ms, int cap);
 
 /* ---- scalar helpers (line-quantisation arithmetic; known-answer tests of run.cu:33-113) ----------------

@@ -235,7 +235,7 @@ class PqtIndex:
         return s.as_dict()
 
     def stage_ms_history(self, cap=32):
-        """[n][5] per-call device ms of {tables, traversal, reserved, rerank(+select), select}, oldest first."""
+        """[n][5] per-call device ms of {tables, traversal, gap between the fused kernels, rerank(+select), select}, oldest first."""
         out = np.zeros((cap, 5), np.float32)
         n = _chk(self.L.pqt_get_stage_ms_history(self.h, _p(out, f32p), cap))
         return out[:n].copy()

@@ -1,6 +1,7 @@
 // pqt_hip.hip -- libpqt_hip.so: index management + launch logic behind the C-ABI of include/pqt_hip.h.
 // gfx950 (MI355X) only.  Build: see csrc/Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +67,7 @@ struct pqt_index {
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
+  hipEvent_t lev0 = nullptr, lev1 = nullptr;  // start/stop events attached to the next fused launch (lean timing), or null
   bool curDynamic = false; unsigned long long* curZero8 = nullptr;  // rerank schedule and next statistics block of the current chunk
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
@@ -239,8 +241,9 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
             : p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), lds, st, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                     idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8);
+  // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
+                        idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8);
   return PQT_OK;
 }
 template <int LPV>
@@ -314,8 +317,8 @@ int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, cons
                               : p2 ? pqt_k_rerank_select_wg<G, false, 1> : pqt_k_rerank_select_wg<G, false, 0>);
   int rc = allowLds(kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), lds, st, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
-                     idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr, idx->dbg);
+  hipExtLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
+                        idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr, idx->dbg);
   return PQT_OK;
 }
 #ifndef PQT_RSWG_SLICE_KB
@@ -431,13 +434,18 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     const uint32_t q0 = (uint32_t)c * qChunk;
     const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
     idx->evMask[idx->ringPos][c] = 0;
-    PQT_REC(EV_BEGIN);
+    idx->lev0 = idx->lev1 = nullptr;
+    if (leanEvents) {
+      // lean timing: start/stop timestamps ride on the two fused dispatches (no event packets between the kernels)
+      idx->lev0 = idx->evRing[idx->ringPos][c][EV_BEGIN]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_BINS];
+      idx->evMask[idx->ringPos][c] |= (1u << EV_BEGIN) | (1u << EV_BINS);
+    } else PQT_REC(EV_BEGIN);
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
 #define PQT_LAUNCH_TR1(WCR, SH)                                                                                         \
-      hipLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), lTrav, st,          \
+      hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
                          idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, \
@@ -489,7 +497,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
     idx->curDynamic = fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves;
     idx->curZero8 = nullptr;
-    PQT_REC(EV_BINS);
+    idx->lev0 = idx->lev1 = nullptr;
+    if (leanEvents) {
+      idx->lev0 = idx->evRing[idx->ringPos][c][EV_ORDER]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_RERANK];
+      idx->evMask[idx->ringPos][c] |= (1u << EV_ORDER) | (1u << EV_RERANK);
+    } else PQT_REC(EV_BINS);
     uint32_t* oI = outIdx + (size_t)q0 * k; float* oD = outDist + (size_t)q0 * k;
     uint32_t* oP = outPos ? outPos + (size_t)q0 * k : nullptr;
     if (fused) {
@@ -508,7 +520,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                      stride, k, nq, oI, oD, oP))) return rc;
       }
-      PQT_REC(EV_RERANK);
+      if (!leanEvents) PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,

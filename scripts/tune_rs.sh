@@ -5,7 +5,7 @@ for f in tune/lib_*.so; do
     env $env PQT_LIB=$PWD/$f python bench.py --steps 5 --warmup 2 --no-cpu 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']['stage_ms']
-print(round(c['rerank_select'],4), round(c['order'],4))
+print(round(c['rerank_select'],4), round(c['gap'],4))
 "
   done
 done
