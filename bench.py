@@ -384,7 +384,6 @@ def main():
             tot = r[:, 4] - r[:, 0]
             log("[tstamp] rerank_select per query (shader clocks): total median %d p90 %d max %d | rows wait %d  adc+filter %d  flush %d (medians)"
                 % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3])))
-            log("[tstamp] rerank_select sVirt load %d  output %d  select part of the last flush %d (medians)" % (np.median(ts[:, 0].astype(np.int64)), np.median(ts[:, 1].astype(np.int64)), np.median(ts[:, 2].astype(np.int64))))
             log("[tstamp] kernel span (first start .. last end): %d ; sum of per-query totals / 2048 wave slots: %d" % (r[:, 4].max() - r[:, 0].min(), tot.sum() // 2048))
     if os.environ.get("PQT_DBG_SWEEP"):
         # debug: stage times with parts of the kernels switched off (results wrong), same index, no rebuild

@@ -410,13 +410,22 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t travR0 = (std::max<size_t>(travWide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
   const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
   const size_t lTrav = (size_t)kTravWaves * travPerWave;
-  if (travFused) {
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true>, lTrav))) return rc;
+  auto isP2 = [](uint32_t x) { return x != 0 && (x & (x - 1)) == 0; };
+  // all layout strides powers of two (every BASELINE shape): the traversal uses shifts and masks
+  const bool travP2 = isP2(d.C1) && isP2(d.C2) && isP2(d.W) && isP2(d.LP) && isP2(d.D) && isP2(d.S) && isP2(d.SS) && isP2(d.R) && d.S >= 4;
+  if (travFused && lTrav > 64 * 1024) {
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
   }
   // fused rerank+select (wave per query) whenever the result list fits the in-register selector
   const bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
@@ -444,13 +453,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
-#define PQT_LAUNCH_TR1(WCR, SH)                                                                                         \
-      hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
+#define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
+      hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                          q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
                          idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
                          idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, \
                          idx->d_ovList, idx->d_ovCount, (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u)
-#define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) PQT_LAUNCH_TR1(WCR, true); else PQT_LAUNCH_TR1(WCR, false); } while (0)
+#define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
+                                else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
 #undef PQT_LAUNCH_TR1

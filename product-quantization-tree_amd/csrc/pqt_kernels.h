@@ -759,7 +759,6 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     if (tstamp) ts0 = __builtin_readcyclecounter();
     for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
     __builtin_amdgcn_wave_barrier();
-    if (tstamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (lane == 0) tstamp[(size_t)q * 16 + 0] = __builtin_readcyclecounter() - ts0; }
     uint64_t tau = ~0ull;
     uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
     uint32_t off0 = 0;
@@ -792,7 +791,6 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         __builtin_amdgcn_wave_barrier();
       }
       if (final) {
-        if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 2] = __builtin_readcyclecounter() - ts0;  // select part of the last flush
         uint64_t key[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -902,7 +900,6 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
         if (SHARDED) outPos[o] = 0xffffffffu;
       }
     }
-    if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0) tstamp[(size_t)q * 16 + 1] = __builtin_readcyclecounter() - ts0; }
     if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
     __builtin_amdgcn_wave_barrier();
     if (tstamp && lane == 0) {
@@ -928,7 +925,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 // LDS per wavefront: max(512 * 8 bytes, D + LP*C1 + P*WC words) time-shared + P*C1 + P*W + 2*P*WC words
 // (6.5 KB for the SIFT configuration: 6 workgroups of 4 wavefronts per CU).
 // ===================================================================================================
-template <int NW, int WCR, bool SHARDED>
+template <int NW, int WCR, bool SHARDED, bool P2 /* C1, C2, W, LP, D, S, SS, R all powers of two: shifts and masks instead of
+                                                    runtime integer divisions (~25 VALU each) and quarter-rate multiplies */>
 #ifndef PQT_TR_WPS
 #define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for (66 VGPRs, no spills)
 #endif
@@ -953,6 +951,12 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.x * NW + wave;
   if (q >= qn) return;
+  const uint32_t shC1 = P2 ? (uint32_t)__builtin_ctz(C1) : 0u, shC2 = P2 ? (uint32_t)__builtin_ctz(C2) : 0u, shLP = P2 ? (uint32_t)__builtin_ctz(LP) : 0u,
+                 shWC = P2 ? (uint32_t)__builtin_ctz(WC) : 0u, shW = P2 ? (uint32_t)__builtin_ctz(W) : 0u, shD = P2 ? (uint32_t)__builtin_ctz(D) : 0u,
+                 shS = P2 ? (uint32_t)__builtin_ctz(S) : 0u, shSS = P2 ? (uint32_t)__builtin_ctz(SS) : 0u, shR = P2 ? (uint32_t)__builtin_ctz(R) : 0u;
+#define PQT_MUL(x, v, sh) (P2 ? ((x) << (sh)) : ((x) * (v)))
+#define PQT_DIV(x, v, sh) (P2 ? ((x) >> (sh)) : ((x) / (v)))
+#define PQT_MOD(x, v) (P2 ? ((x) & ((v) - 1u)) : ((x) % (v)))
   unsigned char* base = smem_raw + (size_t)wave * perWaveBytes;
   // region0 is time-shared: L1virt + unsorted d2 (a1/a2), then the per-row bin records and the compact bin list (a4-a6)
   const uint32_t r0Bytes = perWaveBytes - 4 * (P * C1 + P * W + 2 * P * WC);
@@ -976,15 +980,15 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     for (int u = 0; u < 4; ++u) {
       const uint32_t t = t0 + 64 * u;
       const uint32_t tt = t < C1 * LP ? t : t0;
-      const uint32_t c = tt / LP, lp = tt % LP;
-      const float* cen = cb1 + (size_t)c * D + lp * SS;
-      const float* qq = sQ + lp * SS;
+      const uint32_t c = PQT_DIV(tt, LP, shLP), lp = PQT_MOD(tt, LP);
+      const float* cen = cb1 + (size_t)PQT_MUL(c, D, shD) + PQT_MUL(lp, SS, shSS);
+      const float* qq = sQ + PQT_MUL(lp, SS, shSS);
       float s = 0.f;
       if (tdbg & 8u) { for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - (float)(c + d); s = s + df * df; } }
       else
       for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
       acc[u] = s;
-      dst[u] = t < C1 * LP ? lp * C1 + c : 0xffffffffu;
+      dst[u] = t < C1 * LP ? PQT_MUL(lp, C1, shC1) + c : 0xffffffffu;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (dst[u] != 0xffffffffu) sVirt[dst[u]] = acc[u];
@@ -993,19 +997,19 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   PQT_TS(1);
   for (uint32_t t = lane; t < LP * C1; t += 64) qL1virt[(size_t)q * LP * C1 + t] = sVirt[t];
   for (uint32_t t = lane; t < P * C1; t += 64) {
-    const uint32_t p = t / C1, c = t % C1;
+    const uint32_t p = PQT_DIV(t, C1, shC1), c = PQT_MOD(t, C1);
     float d = 0.f;
-    for (uint32_t pp = 0; pp < R; ++pp) d = d + sVirt[(p * R + pp) * C1 + c];
+    for (uint32_t pp = 0; pp < R; ++pp) d = d + sVirt[PQT_MUL(PQT_MUL(p, R, shR) + pp, C1, shC1) + c];
     sL1[t] = d;
   }
   __builtin_amdgcn_wave_barrier();
   uint32_t ties = 0;
   for (uint32_t t = lane; t < P * C1; t += 64) {
-    const uint32_t p = t / C1, c = t % C1;
+    const uint32_t p = PQT_DIV(t, C1, shC1), c = PQT_MOD(t, C1);
     const float my = sL1[t];
     uint32_t rank = 0;
-    if ((C1 & 3) == 0 && (((uint32_t)(uintptr_t)(sL1 + p * C1)) & 15u) == 0) {  // 16-byte LDS reads: 4 cells per ds_read_b128
-      const float4* row4 = reinterpret_cast<const float4*>(sL1 + p * C1);
+    if ((C1 & 3) == 0 && (((uint32_t)(uintptr_t)(sL1 + PQT_MUL(p, C1, shC1))) & 15u) == 0) {  // 16-byte LDS reads: 4 cells per ds_read_b128
+      const float4* row4 = reinterpret_cast<const float4*>(sL1 + PQT_MUL(p, C1, shC1));
       for (uint32_t o4 = 0; o4 < C1 / 4; ++o4) {
         const float4 v4 = row4[o4];
         const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -1035,15 +1039,15 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
     for (int u = 0; u < 2; ++u) {
       const uint32_t t = t0 + 64 * u;
       const uint32_t tt = t < P * WC ? t : t0;
-      const uint32_t p = tt / WC, pos = tt % WC, h1 = pos / C2, h2 = pos % C2;
-      const uint32_t c1 = sOrd[p * W + h1];
-      const float* qq = sQ + p * S;
+      const uint32_t p = PQT_DIV(tt, WC, shWC), pos = PQT_MOD(tt, WC), h1 = PQT_DIV(pos, C2, shC2), h2 = PQT_MOD(pos, C2);
+      const uint32_t c1 = sOrd[PQT_MUL(p, W, shW) + h1];
+      const float* qq = sQ + PQT_MUL(p, S, shS);
       float s = 0.f;
       if (cb2T) {
         // transposed tile: vector v of the C2 rows of a cell is contiguous, so the 32..64 lanes walking the rows of
         // a cell read 512..1024 contiguous bytes per instruction (row-per-lane reads of the file layout touch one
         // cache line per lane); same dims in the same order
-        const float4* cen4 = cb2T + ((size_t)p * C1 + c1) * (S / 4) * C2 + h2;
+        const float4* cen4 = cb2T + PQT_MUL(PQT_MUL((size_t)(PQT_MUL(p, C1, shC1) + c1), S / 4, shS - 2), C2, shC2) + h2;
         // 8 vectors of the row are requested together (one round trip per 32 dims instead of one per 4), then summed in
         // dimension order
         for (uint32_t v0 = 0; v0 < S / 4; v0 += 8) {
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
           for (int e = 0; e < 8; ++e) {
             const uint32_t v = v0 + e;
             c[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < S / 4) c[e] = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[(size_t)v * C2];
+            if (v < S / 4) c[e] = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[PQT_MUL((size_t)v, C2, shC2)];
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -1066,7 +1070,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
           }
         }
       } else {
-        const float* cen = cb2 + (((size_t)p * C1 + c1) * C2 + h2) * S;
+        const float* cen = cb2 + PQT_MUL(PQT_MUL((size_t)(PQT_MUL(p, C1, shC1) + c1), C2, shC2) + h2, S, shS);
         for (uint32_t d = 0; d < S; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
       }
       acc[u] = s;
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
 #pragma unroll
       for (int r = 0; r < WCR; ++r) {
         const uint32_t pos = lane + 64 * r;
-        key[m][r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[p * WC + pos]) << 32) | pos) : ~0ull;
+        key[m][r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[PQT_MUL(p, WC, shWC) + pos]) << 32) | pos) : ~0ull;
       }
     }
 #pragma unroll
@@ -1101,11 +1105,11 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
           const uint32_t e = lane * WCR + r;
           if (e < WC) {
             const uint32_t pos = (uint32_t)key[m][r];
-            sSegD[p * WC + e] = sD2[p * WC + pos];
-            sSegB[p * WC + e] = (sOrd[p * W + pos / C2] * C2 + pos % C2) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
+            sSegD[PQT_MUL(p, WC, shWC) + e] = sD2[PQT_MUL(p, WC, shWC) + pos];
+            sSegB[PQT_MUL(p, WC, shWC) + e] = (PQT_MUL(sOrd[PQT_MUL(p, W, shW) + PQT_DIV(pos, C2, shC2)], C2, shC2) + PQT_MOD(pos, C2)) * prm.powers[p];  // pre-multiplied by (C1*C2)^p, uint32 wrap
             if (He > 512) {  // wide enumeration: keep the lists for the overflow hand-over to pqt_k_bins
               segDOut[((size_t)q * P + p) * WC + e] = sD2[p * WC + pos];
-              segBOut[((size_t)q * P + p) * WC + e] = sOrd[p * W + pos / C2] * C2 + pos % C2;
+              segBOut[((size_t)q * P + p) * WC + e] = PQT_MUL(sOrd[PQT_MUL(p, W, shW) + PQT_DIV(pos, C2, shC2)], C2, shC2) + PQT_MOD(pos, C2);
             }
           }
           // exact ties between neighbours of the sorted list (statistics only)
@@ -1130,8 +1134,8 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
 #pragma unroll
     for (int p = 0; p < PQT_MAXP; ++p) {
       if ((uint32_t)p < P) {
-        fine = fine + sSegD[p * WC + dg[p]];
-        g += sSegB[p * WC + dg[p]];
+        fine = fine + sSegD[PQT_MUL((uint32_t)p, WC, shWC) + dg[p]];
+        g += sSegB[PQT_MUL((uint32_t)p, WC, shWC) + dg[p]];
       }
     }
     if (prm.hashMod) g %= prm.hashMod;
@@ -1382,6 +1386,9 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
   PQT_TS(8);
   if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef PQT_TS
+#undef PQT_MUL
+#undef PQT_DIV
+#undef PQT_MOD
 }
 
 // ---------------------------------------------------------------------------------------------------
