@@ -453,12 +453,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
+      const PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv,
+                              idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
+                              idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, idx->d_tstamp,
+                              idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
+                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
-                         q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv, idx->d_table, idx->d_lower, \
-                         idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand, idx->d_candPos, \
-                         idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, travPerWave, idx->ctr, idx->d_tstamp, idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, \
-                         idx->d_ovList, idx->d_ovCount, (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u)
+                            targs, travPerWave)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
                                 else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
       if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);

@@ -925,39 +925,50 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
 // LDS per wavefront: max(512 * 8 bytes, D + LP*C1 + P*WC words) time-shared + P*C1 + P*W + 2*P*WC words
 // (6.5 KB for the SIFT configuration: 6 workgroups of 4 wavefronts per CU).
 // ===================================================================================================
-template <int NW, int WCR, bool SHARDED, bool P2 /* C1, C2, W, LP, D, S, SS, R all powers of two: shifts and masks instead of
-                                                    runtime integer divisions (~25 VALU each) and quarter-rate multiplies */>
-#ifndef PQT_TR_WPS
-#define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for (66 VGPRs, no spills)
-#endif
-__global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
-    const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2,
-    const float4* __restrict__ cb2T /* per (p,c1): [S/4][C2] 16-byte vectors, or null when S % 4 != 0 */, PqtDevParams prm,
-    const uint4* __restrict__ heur8 /* rows of 8 x u16 */, uint32_t He, uint32_t Bv, const PqtBinEntry* __restrict__ table,
-    const uint32_t* __restrict__ lower, uint32_t tableBits, const uint32_t* __restrict__ ids, uint32_t qn,
-    float* __restrict__ qL1virt, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
-    uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
-    uint32_t perWaveBytes, unsigned long long* __restrict__ counters, unsigned long long* __restrict__ tstamp,
-    float* __restrict__ segDOut, uint32_t* __restrict__ segBOut /* [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over) */,
-    uint32_t* __restrict__ ovList, uint32_t* __restrict__ ovCount /* queries handed to pqt_k_bins (He > 512 and > 512 populated rows) */,
-    const uint32_t* __restrict__ filter, uint32_t filterBits /* presence bitmap over the bin keys, or null */,
-    uint32_t tdbg /* debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results): no bin-table
-                     probes / no cb2 reads / no cb1 reads */) {
+// arguments of the per-query traversal (pqt_traverse_query), shared by pqt_k_traverse and the one-launch kernel
+struct PqtTravArgs {
+  const float* Q; const float* cb1; const float* cb2;
+  const float4* cb2T;  // per (p,c1): [S/4][C2] 16-byte vectors, or null when S % 4 != 0
+  PqtDevParams prm;
+  const uint4* heur8;  // rows of 8 x u16
+  uint32_t He, Bv;
+  const PqtBinEntry* table; const uint32_t* lower; uint32_t tableBits;
+  const uint32_t* ids; uint32_t qn;
+  float* qL1virt; uint32_t* cand; uint32_t* candPos;
+  uint32_t* nCand; uint32_t* nLocal; uint32_t* nIncl; uint64_t stride;
+  unsigned long long* counters; unsigned long long* tstamp;
+  float* segDOut; uint32_t* segBOut;    // [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over)
+  uint32_t* ovList; uint32_t* ovCount;  // queries handed to pqt_k_bins (He > 512 and > 512 populated rows)
+  const uint32_t* filter; uint32_t filterBits;  // presence bitmap over the bin keys, or null
+  uint32_t tdbg;  // debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results)
+};
+
+// the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
+template <int WCR, bool SHARDED, bool P2 /* C1, C2, W, LP, D, S, SS, R all powers of two: shifts and masks instead of
+                                            runtime integer divisions (~25 VALU each) and quarter-rate multiplies */>
+__device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const uint32_t q, unsigned char* const base, const uint32_t perWaveBytes) {
+  const float* __restrict__ Q = A.Q; const float* __restrict__ cb1 = A.cb1; const float* __restrict__ cb2 = A.cb2;
+  const float4* __restrict__ cb2T = A.cb2T; const PqtDevParams& prm = A.prm; const uint4* __restrict__ heur8 = A.heur8;
+  const uint32_t He = A.He, Bv = A.Bv; const PqtBinEntry* __restrict__ table = A.table; const uint32_t* __restrict__ lower = A.lower;
+  const uint32_t tableBits = A.tableBits; float* __restrict__ qL1virt = A.qL1virt;
+  uint32_t* __restrict__ cand = A.cand; uint32_t* __restrict__ candPos = A.candPos; uint32_t* __restrict__ nCand = A.nCand;
+  uint32_t* __restrict__ nLocal = A.nLocal; uint32_t* __restrict__ nIncl = A.nIncl; const uint64_t stride = A.stride;
+  unsigned long long* __restrict__ counters = A.counters; unsigned long long* __restrict__ tstamp = A.tstamp;
+  float* __restrict__ segDOut = A.segDOut; uint32_t* __restrict__ segBOut = A.segBOut;
+  uint32_t* __restrict__ ovList = A.ovList; uint32_t* __restrict__ ovCount = A.ovCount;
+  const uint32_t* __restrict__ filter = A.filter; const uint32_t filterBits = A.filterBits; const uint32_t tdbg = A.tdbg;
+  (void)lower; (void)candPos;
   const uint32_t forceFullOrder = tdbg & 1u;
 #define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, W = prm.W, LP = prm.LP, S = prm.S, SS = prm.SS,
                  R = prm.R, WC = prm.WC;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t q = blockIdx.x * NW + wave;
-  if (q >= qn) return;
+  const uint32_t lane = threadIdx.x & 63;
   const uint32_t shC1 = P2 ? (uint32_t)__builtin_ctz(C1) : 0u, shC2 = P2 ? (uint32_t)__builtin_ctz(C2) : 0u, shLP = P2 ? (uint32_t)__builtin_ctz(LP) : 0u,
                  shWC = P2 ? (uint32_t)__builtin_ctz(WC) : 0u, shW = P2 ? (uint32_t)__builtin_ctz(W) : 0u, shD = P2 ? (uint32_t)__builtin_ctz(D) : 0u,
                  shS = P2 ? (uint32_t)__builtin_ctz(S) : 0u, shSS = P2 ? (uint32_t)__builtin_ctz(SS) : 0u, shR = P2 ? (uint32_t)__builtin_ctz(R) : 0u;
 #define PQT_MUL(x, v, sh) (P2 ? ((x) << (sh)) : ((x) * (v)))
 #define PQT_DIV(x, v, sh) (P2 ? ((x) >> (sh)) : ((x) / (v)))
 #define PQT_MOD(x, v) (P2 ? ((x) & ((v) - 1u)) : ((x) % (v)))
-  unsigned char* base = smem_raw + (size_t)wave * perWaveBytes;
   // region0 is time-shared: L1virt + unsorted d2 (a1/a2), then the per-row bin records and the compact bin list (a4-a6)
   const uint32_t r0Bytes = perWaveBytes - 4 * (P * C1 + P * W + 2 * P * WC);
   uint64_t* sBin = (uint64_t*)base;                 // 512 : (gcount | lstart<<32) by row, later the compact bin list
@@ -1389,6 +1400,18 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(
 #undef PQT_MUL
 #undef PQT_DIV
 #undef PQT_MOD
+}
+
+#ifndef PQT_TR_WPS
+#define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for
+#endif
+template <int NW, int WCR, bool SHARDED, bool P2>
+__global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtTravArgs A /* kernel-argument segment: scalar loads */, uint32_t perWaveBytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t q = blockIdx.x * NW + wave;
+  if (q >= A.qn) return;
+  pqt_traverse_query<WCR, SHARDED, P2>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
 }
 
 // ---------------------------------------------------------------------------------------------------
