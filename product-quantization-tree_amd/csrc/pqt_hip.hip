@@ -242,8 +242,9 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
-  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse,
-                        idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP, idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8);
+  const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+                        idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8};
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
 template <int LPV>

@@ -657,29 +657,210 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #endif
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
-template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
-__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
-    const uint32_t* __restrict__ codes /* bin-ordered */, const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
-    const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
-    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t qn, PqtDevParams prm,
-    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos,
-    unsigned long long* __restrict__ counters, uint32_t dbg, unsigned long long* __restrict__ tstamp,
-    uint32_t dynamic /* 1: workgroup-local dynamic schedule (several queries per wavefront), 0: static round-robin */,
-    unsigned long long* __restrict__ zero8 /* statistics block of the next call, zeroed here (saves a memset launch) */) {
+// arguments of the fused rerank + select (kernel-argument segment)
+struct PqtRsArgs {
+  const uint32_t* codes;  // bin-ordered line store
+  const uint32_t* ids; const float* qL1virt; const float* coarse; const uint32_t* cand; const uint32_t* candPos;
+  const uint32_t* nLocal; uint64_t stride; uint32_t k, qn; PqtDevParams prm;
+  uint32_t* outIdx; float* outDist; uint32_t* outPos;
+  unsigned long long* counters; uint32_t dbg; unsigned long long* tstamp;
+  uint32_t dynamic;          // 1: workgroup-local dynamic schedule (several queries per wavefront), 0: static round-robin
+  unsigned long long* zero8; // statistics block of the next call, zeroed here (saves a memset launch)
+};
+
+// a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
+// sVirt: its LP*C1 floats (loaded here), cz: the coarse table (LDS copy at offset 0 of the dynamic LDS, or global).
+// qN / nN: the wavefront's next query; a count still unknown (0xffffffff) is fetched under the final select + sort.
+template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M>
+__device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
+                                             const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t* __restrict__ codes = A.codes; const uint32_t* __restrict__ ids = A.ids; const float* __restrict__ qL1virt = A.qL1virt;
+  const uint32_t* __restrict__ cand = A.cand; const uint32_t* __restrict__ candPos = A.candPos; const uint32_t* __restrict__ nLocal = A.nLocal;
+  const uint64_t stride = A.stride; const uint32_t k = A.k; uint32_t* __restrict__ outIdx = A.outIdx; float* __restrict__ outDist = A.outDist;
+  uint32_t* __restrict__ outPos = A.outPos; unsigned long long* __restrict__ counters = A.counters; const uint32_t dbg = A.dbg;
+  unsigned long long* __restrict__ tstamp = A.tstamp;
+  (void)candPos; (void)outPos; (void)cz;
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
   constexpr int U = UREQ;
   constexpr uint32_t LP = LPV * 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : prm.C1;
+  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : A.prm.C1;
   constexpr bool C1P2 = C1M != 0;
   const uint32_t c1sh = C1M >= 2 ? (uint32_t)C1M : (C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u);  // power-of-two C1: shifts instead of quarter-rate multiplies
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t vOff = (uint32_t)(reinterpret_cast<unsigned char*>(sVirt) - smem_raw);  // byte offset of this wave's L1virt copy
+  (void)c1sh; (void)vOff;
+  // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
+  unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
+  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
+  const uint32_t* cid = cand + (size_t)q * stride;
+  const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
+  if (tstamp) ts0 = __builtin_readcyclecounter();
+  for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
+  __builtin_amdgcn_wave_barrier();
+  uint64_t tau = ~0ull;
+  uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
+  uint32_t off0 = 0;
+
+  auto flush = [&](const bool final) {
+    // [best off0 (unsorted, after the first flush) | pending npend]: keep the k smallest.  More than 128 keys are cut
+    // down by an exact radix select (pqt_wave_kth_u64) instead of a full sort; only the final <= 128 survivors
+    // go through the (small) in-register sorting network.  The keys live in registers during the select, so its
+    // counters reuse the pending area of sKeys (1056 bytes behind the best list).
+    uint32_t have = off0 + npend;
+    if (have > PQT_RS_BEST) {
+      constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
+      uint64_t key[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const uint32_t e = r * 64 + lane;
+        key[r] = (e < have) ? sKeys[e] : ~0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      tau = pqt_wave_kth_u64<RK>(key, k, reinterpret_cast<uint32_t*>(sKeys + PQT_RS_BEST));
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
+        if (key[r] <= tau) sKeys[cnt + rk] = key[r];
+        cnt += tot;
+      }
+      have = k;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (final) {
+      uint64_t key[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint32_t e = lane * 2 + r;
+        key[r] = (e < have) ? sKeys[e] : ~0ull;
+      }
+      if (!(dbg & 1)) pqt_wave_sort_u64<2>(key);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) sKeys[lane * 2 + r] = key[r];
+      __builtin_amdgcn_wave_barrier();
+    }
+    npend = 0;
+    off0 = have;
+  };
+
+  for (uint32_t base = 0;; base += 64 * U) {
+    if (base < n) {
+      if (tstamp) ts0 = __builtin_readcyclecounter();
+      uint32_t id[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t j = base + u * 64 + lane;
+        id[u] = cid[j < n ? j : n - 1];  // position in the bin-ordered line store
+        if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
+      }
+      uint4 rows[U][LPV];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)id[u] * LP);
+#pragma unroll
+        for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
+      }
+      if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t j = base + u * 64 + lane;
+        const bool valid = j < n;
+        float acc = 0.f;
+        if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
+          uint32_t x = 0;
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) x ^= rows[u][v].x ^ rows[u][v].y ^ rows[u][v].z ^ rows[u][v].w;
+          acc = __uint_as_float(x & 0x3fffffffu);
+        } else
+#pragma unroll
+        for (int v = 0; v < LPV; ++v) {
+          const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const uint32_t p = v * 4 + x;
+            const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
+            const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
+            float sb, sa, sc;
+            if constexpr (C1M >= 2 && COARSE_LDS) {
+              // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
+              // the part offsets go into the instructions' immediate fields
+              const uint32_t B4 = B << 2;
+              const uint32_t aV = (A << 2) + vOff, bV = B4 + vOff, aC = (A << (2 + C1M)) + B4;  // v_lshl_add, v_add, v_lshl_add
+              sb = *reinterpret_cast<const float*>(smem_raw + aV + p * (4u << C1M));
+              sa = *reinterpret_cast<const float*>(smem_raw + bV + p * (4u << C1M));
+              sc = *reinterpret_cast<const float*>(smem_raw + aC + p * (4u << (2 * C1M)));
+            } else {
+              sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
+              sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
+              sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
+            }
+            acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+          }
+        }
+        // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
+        const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
+        const bool pass = valid && key < tau;
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(pass, &tot);
+        if (pass) sKeys[off0 + npend + rk] = key;
+        npend += tot;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsAdc += t - ts0; }
+    }
+    // single flush site: when the pending buffer could overflow on the next batch, and once at the end
+    const bool last = base + 64 * U >= n;
+    if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
+    if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) {
+      if (tstamp) ts0 = __builtin_readcyclecounter();
+      flush(last);
+      if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
+    }
+    if (last) break;
+  }
+  // results: first min(k, n) entries of the best list
+  const uint32_t kk = n < k ? n : k;
+  uint32_t ties = 0;
+  if (tstamp) ts0 = __builtin_readcyclecounter();
+  for (uint32_t i = lane; i < k; i += 64) {
+    const size_t o = (size_t)q * k + i;
+    if (i < kk) {
+      const uint64_t key = sKeys[i];
+      const uint32_t j = (uint32_t)key;
+      outIdx[o] = ids[cid[j]];
+      outDist[o] = pqt_key2f((uint32_t)(key >> 32));
+      if (SHARDED) outPos[o] = cpos[j];
+      if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
+    } else {
+      outIdx[o] = 0xffffffffu;
+      outDist[o] = __uint_as_float(0x7f800000u);
+      if (SHARDED) outPos[o] = 0xffffffffu;
+    }
+  }
+  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  __builtin_amdgcn_wave_barrier();
+  if (tstamp && lane == 0) {
+    tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
+    tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
+    tstamp[(size_t)q * 16 + 14] = slot;
+  }
+}
+
+template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
+__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A) {
+  const float* __restrict__ coarse = A.coarse; const uint32_t* __restrict__ nLocal = A.nLocal; const uint32_t qn = A.qn;
+  const PqtDevParams& prm = A.prm; const uint32_t dbg = A.dbg; const uint32_t dynamic = A.dynamic; unsigned long long* __restrict__ zero8 = A.zero8;
+  constexpr uint32_t LP = LPV * 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : prm.C1;
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
   float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
-  const uint32_t vOff = (uint32_t)(reinterpret_cast<unsigned char*>(sVirt) - smem_raw);  // byte offset of this wave's L1virt copy
   const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4);
   // Schedule.  Candidate counts differ several-fold between queries and wavefronts do not run equally fast (the
   // younger of two wavefronts on a SIMD loses the issue arbitration): with a static round-robin over the wavefronts the
@@ -751,162 +932,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(
     // the next query is chosen now; a count that is not in the LDS list is fetched under the final select + sort below
     uint32_t nN = 0;
     const uint32_t qN = nextQuery(nN);
-    // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
-    unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
-    if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
-    const uint32_t* cid = cand + (size_t)q * stride;
-    const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
-    if (tstamp) ts0 = __builtin_readcyclecounter();
-    for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
-    __builtin_amdgcn_wave_barrier();
-    uint64_t tau = ~0ull;
-    uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
-    uint32_t off0 = 0;
-
-    auto flush = [&](const bool final) {
-      // [best off0 (unsorted, after the first flush) | pending npend]: keep the k smallest.  More than 128 keys are cut
-      // down by an exact radix select (pqt_wave_kth_u64) instead of a full sort; only the final <= 128 survivors
-      // go through the (small) in-register sorting network.  The keys live in registers during the select, so its
-      // counters reuse the pending area of sKeys (1056 bytes behind the best list).
-      uint32_t have = off0 + npend;
-      if (have > PQT_RS_BEST) {
-        constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
-        uint64_t key[RK];
-#pragma unroll
-        for (int r = 0; r < RK; ++r) {
-          const uint32_t e = r * 64 + lane;
-          key[r] = (e < have) ? sKeys[e] : ~0ull;
-        }
-        __builtin_amdgcn_wave_barrier();
-        tau = pqt_wave_kth_u64<RK>(key, k, reinterpret_cast<uint32_t*>(sKeys + PQT_RS_BEST));
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int r = 0; r < RK; ++r) {
-          uint32_t tot;
-          const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
-          if (key[r] <= tau) sKeys[cnt + rk] = key[r];
-          cnt += tot;
-        }
-        have = k;
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (final) {
-        uint64_t key[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const uint32_t e = lane * 2 + r;
-          key[r] = (e < have) ? sKeys[e] : ~0ull;
-        }
-        if (!(dbg & 1)) pqt_wave_sort_u64<2>(key);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) sKeys[lane * 2 + r] = key[r];
-        __builtin_amdgcn_wave_barrier();
-      }
-      npend = 0;
-      off0 = have;
-    };
-
-    for (uint32_t base = 0;; base += 64 * U) {
-      if (base < n) {
-        if (tstamp) ts0 = __builtin_readcyclecounter();
-        uint32_t id[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t j = base + u * 64 + lane;
-          id[u] = cid[j < n ? j : n - 1];  // position in the bin-ordered line store
-          if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
-        }
-        uint4 rows[U][LPV];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)id[u] * LP);
-#pragma unroll
-          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
-        }
-        if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t j = base + u * 64 + lane;
-          const bool valid = j < n;
-          float acc = 0.f;
-          if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
-            uint32_t x = 0;
-#pragma unroll
-            for (int v = 0; v < LPV; ++v) x ^= rows[u][v].x ^ rows[u][v].y ^ rows[u][v].z ^ rows[u][v].w;
-            acc = __uint_as_float(x & 0x3fffffffu);
-          } else
-#pragma unroll
-          for (int v = 0; v < LPV; ++v) {
-            const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const uint32_t p = v * 4 + x;
-              const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
-              const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
-              float sb, sa, sc;
-              if constexpr (C1M >= 2 && COARSE_LDS) {
-                // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
-                // the part offsets go into the instructions' immediate fields
-                const uint32_t B4 = B << 2;
-                const uint32_t aV = (A << 2) + vOff, bV = B4 + vOff, aC = (A << (2 + C1M)) + B4;  // v_lshl_add, v_add, v_lshl_add
-                sb = *reinterpret_cast<const float*>(smem_raw + aV + p * (4u << C1M));
-                sa = *reinterpret_cast<const float*>(smem_raw + bV + p * (4u << C1M));
-                sc = *reinterpret_cast<const float*>(smem_raw + aC + p * (4u << (2 * C1M)));
-              } else {
-                sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
-                sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
-                sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
-              }
-              acc = acc + pqt_extract_distance(sa, sb, sc, lam);
-            }
-          }
-          // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
-          const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
-          const bool pass = valid && key < tau;
-          uint32_t tot;
-          const uint32_t rk = pqt_ballot_rank(pass, &tot);
-          if (pass) sKeys[off0 + npend + rk] = key;
-          npend += tot;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsAdc += t - ts0; }
-      }
-      // single flush site: when the pending buffer could overflow on the next batch, and once at the end
-      const bool last = base + 64 * U >= n;
-      if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
-      if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) {
-        if (tstamp) ts0 = __builtin_readcyclecounter();
-        flush(last);
-        if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
-      }
-      if (last) break;
-    }
-    // results: first min(k, n) entries of the best list
-    const uint32_t kk = n < k ? n : k;
-    uint32_t ties = 0;
-    if (tstamp) ts0 = __builtin_readcyclecounter();
-    for (uint32_t i = lane; i < k; i += 64) {
-      const size_t o = (size_t)q * k + i;
-      if (i < kk) {
-        const uint64_t key = sKeys[i];
-        const uint32_t j = (uint32_t)key;
-        outIdx[o] = ids[cid[j]];
-        outDist[o] = pqt_key2f((uint32_t)(key >> 32));
-        if (SHARDED) outPos[o] = cpos[j];
-        if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
-      } else {
-        outIdx[o] = 0xffffffffu;
-        outDist[o] = __uint_as_float(0x7f800000u);
-        if (SHARDED) outPos[o] = 0xffffffffu;
-      }
-    }
-    if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
-    __builtin_amdgcn_wave_barrier();
-    if (tstamp && lane == 0) {
-      tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
-      tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
-      tstamp[(size_t)q * 16 + 14] = slot;
-    }
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M>(A, q, n, sKeys, sVirt, cz, qN, nN, slot);
     q = qN;
     n = nN;
   }
