@@ -1632,22 +1632,44 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
 
   uint64_t tau = ~0ull;
   uint32_t npend = 0, off0 = 0;
-  auto flush = [&]() {
-    uint64_t key[KR];
+  auto flush = [&](const bool final) {
+    // as in pqt_rs_query: more than 128 keys are cut down to the k smallest by the exact radix select, only the final
+    // survivors of the wavefront are sorted (the merge below wants sorted, ~0-padded lists of 128)
+    uint32_t have = off0 + npend;
+    if (have > PQT_RS_BEST) {
+      uint64_t key[KR];
 #pragma unroll
-    for (int r = 0; r < KR; ++r) {
-      const uint32_t e = lane * KR + r;
-      key[r] = (e < off0 + npend) ? sKeys[e] : ~0ull;
-    }
-    if (!(dbg & 1)) pqt_wave_sort_u64<KR>(key);
-    if (lane < PQT_RS_BEST / KR) {
+      for (int r = 0; r < KR; ++r) {
+        const uint32_t e = r * 64 + lane;
+        key[r] = (e < have) ? sKeys[e] : ~0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      tau = pqt_wave_kth_u64<KR>(key, k, reinterpret_cast<uint32_t*>(sKeys + PQT_RS_BEST));
+      uint32_t cnt = 0;
 #pragma unroll
-      for (int r = 0; r < KR; ++r) sKeys[lane * KR + r] = key[r];
+      for (int r = 0; r < KR; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
+        if (key[r] <= tau) sKeys[cnt + rk] = key[r];
+        cnt += tot;
+      }
+      have = k;
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    tau = sKeys[k - 1];
+    if (final) {
+      uint64_t key[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const uint32_t e = lane * 2 + r;
+        key[r] = (e < have) ? sKeys[e] : ~0ull;
+      }
+      if (!(dbg & 1)) pqt_wave_sort_u64<2>(key);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) sKeys[lane * 2 + r] = key[r];
+      __builtin_amdgcn_wave_barrier();
+    }
     npend = 0;
-    off0 = PQT_RS_BEST;
+    off0 = have;
   };
 
   for (uint32_t tile0 = 0; tile0 < n; tile0 += NT * CPT) {
@@ -1733,10 +1755,10 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
       if (pass) sKeys[off0 + npend + rk] = key;
       npend += tot;
       __builtin_amdgcn_wave_barrier();
-      if (off0 + npend + 64 > PQT_RS2_KEYS) flush();
+      if (off0 + npend + 64 > PQT_RS2_KEYS) flush(false);
     }
   }
-  flush();
+  flush(true);
   __syncthreads();
   // merge the NW sorted best lists (each at sKeysAll[w*512 .. +128)) in wave 0
   if (wave == 0) {
