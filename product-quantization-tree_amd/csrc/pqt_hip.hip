@@ -237,8 +237,8 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   constexpr int UV = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
   const uint32_t c1 = idx->dp.C1;
   const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
-  auto kern = (CL && c1 == 32) ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 5>
-            : p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
+  auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
+  if constexpr (CL) { if (c1 == 32) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5>; }  // compile-time C1 only where the table is in LDS
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
