@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,7 +28,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
   } while (0)
 
 uint32_t upow(uint32_t x, uint32_t n) { uint32_t r = 1; for (uint32_t i = 0; i < n; ++i) r = x * r; return r; }
-uint32_t np2(uint32_t x) { uint32_t r = 1; while (r < x) r <<= 1; return r; }
+uint32_t np2(uint64_t x) { uint64_t r = 1; while (r < x && r < (1ull << 31)) r <<= 1; return (uint32_t)r; }
 
 enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_ORDER, EV_RERANK, EV_SELECT, EV_COUNT };
 constexpr int kMaxChunks = 16;
@@ -78,7 +80,7 @@ struct pqt_index {
   uint64_t stride = 0;
   // results of the last call
   pqt_stats stats{};
-  uint32_t lastQn = 0; uint32_t lastHe = 0;
+  uint32_t lastQn = 0; uint32_t lastHe = 0; bool lastSegKept = false; bool lastDistKept = false;
   hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
   uint32_t evMask[kRing][kMaxChunks]{};      // which events of a ring slot were recorded (an event record costs ~5 us of stream time)
   int nChunks = 0; bool evCreated = false;
@@ -219,10 +221,21 @@ size_t ldsEncode(const PqtDevParams& d) {
 }
 constexpr size_t kMaxLds = 160 * 1024;
 
+// the dynamic-LDS ceiling of a kernel is raised once per (device, kernel, size), not on every query call
+std::mutex g_ldsMu;
+std::map<std::pair<int, const void*>, size_t> g_ldsSet;
 template <class K>
 int allowLds(K kernel, size_t bytes) {
   if (bytes > kMaxLds) return fail(PQT_ERR_LIMIT, "request needs more than 160 KiB of LDS per workgroup");
-  if (bytes > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (bytes <= 64 * 1024) return PQT_OK;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ldsMu);
+  size_t& have = g_ldsSet[{dev, (const void*)kernel}];
+  if (bytes > have) {
+    HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
   return PQT_OK;
 }
 
@@ -234,7 +247,10 @@ template <int LPV, bool CL, bool SH>
 int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
              uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
   constexpr int U0 = (PQT_RS_U16 * 4) / LPV;
-  constexpr int UV = U0 < 1 ? 1 : (U0 > 8 ? 8 : U0);
+  // 64*UV keys are appended per batch behind a best list of up to PQT_RS_BEST keys: they must fit the pending area
+  // (U = 8 at LP = 4/8 overran the wave's key slots when > 512 - k candidates of a batch beat tau)
+  constexpr int UV = U0 < 1 ? 1 : (U0 > 4 ? 4 : U0);
+  static_assert(64 * UV <= PQT_RS_PEND, "a batch of appended keys must fit the pending area");
   const uint32_t c1 = idx->dp.C1;
   const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
   auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
@@ -243,7 +259,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                        idx->ctr, idx->dbg, idx->d_tstamp, idx->curDynamic ? 1u : 0u, idx->curZero8};
+                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -374,16 +390,17 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   // candidate list bound: the reference overshoots Bv by at most the bin that crosses it
   uint64_t stride = std::min<uint64_t>((uint64_t)Bv + idx->maxBin + 1, (uint64_t)He * idx->maxBin + 1);
   stride = (stride + 63) & ~(uint64_t)63;
+  if (stride > ((uint64_t)1 << 31)) return fail(PQT_ERR_LIMIT, "candidate list bound (bound_vectors + largest bin) exceeds 2^31 entries per query");
   idx->stride = stride;
   const bool fullSort = (k > 4096);
   const uint32_t kP2 = np2(std::max<uint32_t>(k, 2));
-  const size_t perQueryBytes = stride * (idx->sharded ? 12 : 8) + (fullSort ? (size_t)np2((uint32_t)stride) * 8 : 0);
+  const size_t perQueryBytes = stride * (idx->sharded ? 12 : 8) + (fullSort ? (size_t)np2(stride) * 8 : 0);
   uint32_t qChunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(qn, idx->scratchBudget / perQueryBytes));
   int nChunks = (int)((qn + qChunk - 1) / qChunk);
   if (nChunks > kMaxChunks) { qChunk = (qn + kMaxChunks - 1) / kMaxChunks; nChunks = (int)((qn + qChunk - 1) / qChunk); }
   if ((rc = ensureQueryScratch(idx, qn))) return rc;
   if ((rc = ensureCandScratch(idx, (uint64_t)qChunk * stride))) return rc;
-  const uint32_t sortP2 = np2((uint32_t)stride);
+  const uint32_t sortP2 = fullSort ? np2(stride) : 0;
   if (fullSort && (uint64_t)qChunk * sortP2 > idx->sortCap) {
     if ((rc = devAlloc(&idx->d_sortKeys, (size_t)qChunk * sortP2))) return rc;
     idx->sortCap = (uint64_t)qChunk * sortP2;
@@ -429,10 +446,15 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
   }
   // fused rerank+select (wave per query) whenever the result list fits the in-register selector
-  const bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
+  bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
   const bool coarseLds = coarseBytes <= 64 * 1024;
   const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
+  int wgG = (fused && !coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
+  if (wgG && (size_t)wgG * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8 > kMaxLds) wgG = 0;
+  // a shape whose fused kernel does not fit the LDS (e.g. C1 = 256 with >= 16 line parts) runs the staged rerank/select,
+  // which needs LP*C1*4 bytes only
+  if (fused && !wgG && lFused > kMaxLds) fused = false;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -450,13 +472,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       idx->lev0 = idx->evRing[idx->ringPos][c][EV_BEGIN]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_BINS];
       idx->evMask[idx->ringPos][c] |= (1u << EV_BEGIN) | (1u << EV_BINS);
     } else PQT_REC(EV_BEGIN);
+    unsigned long long* const tstamp = (nq <= (1u << 16)) ? idx->d_tstamp : nullptr;  // debug buffer holds 65536 query records
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
       const PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv,
                               idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
-                              idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, idx->d_tstamp,
+                              idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
                               (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
@@ -520,7 +543,6 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (fused) {
       // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
       const uint32_t grid = rsGrid;
-      const int wgG = (!coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
       if (wgG) {
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         rc = wgG == 4 ? launchRSWG<4>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
@@ -568,6 +590,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
+  idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
+  idx->lastDistKept = !fused;                 // the fused rerank never writes candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
 }
@@ -960,6 +984,10 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
   if (qn > idx->lastQn) return fail(PQT_ERR_STATE, "no such batch held");
   if (idx->nChunks > 1 && (candIdx || candDist)) return fail(PQT_ERR_STATE, "last batch ran in several chunks; candidates of earlier chunks are gone");
+  if ((segd || segbin) && !idx->lastSegKept)
+    return fail(PQT_ERR_STATE, "the last call ran the fused traversal, which keeps seg_d2/seg_bin on chip: set_option(\"fused\", 0) first");
+  if (candDist && !idx->lastDistKept)
+    return fail(PQT_ERR_STATE, "the last call ran the fused rerank+select, which never writes cand_dist: use k > 128 or set_option(\"fused\", 0)");
   int rc = setDevice(idx);
   if (rc) return rc;
   const PqtDevParams& d = idx->dp;

@@ -184,8 +184,10 @@ def test_single_query_and_ragged_batches(pair):
 
 
 def test_heuristic_built_by_library_matches_oracle(pair):
+    """a3 at every fixture shape, the BASELINE ones included ((W*C2)^P = 64^4 tuples for cfg2 and cfg3): the prefix the
+    library builds (pqt_index_build_heuristic) == the prefix the oracle's own prepareHeuristic restatement built."""
     name, f, idx = pair
-    if f.oracle.max_multi_index > (1 << 22):
+    if f.oracle.max_multi_index > (1 << 26):
         pytest.skip("full tuple space too large for a unit test")
     rows = len(f.heur)
     idx.build_heuristic(rows)
@@ -536,3 +538,43 @@ def test_hashed_db_triple_without_aliasing_equals_exact_bins(name, bb):
     finally:
         idx.close()
         ref_idx.close()
+
+
+@pytest.mark.parametrize("LP", [4, 8, 16])
+def test_improving_candidates_fill_the_pending_buffer(LP):
+    """with 4 or 8 line parts the fused rerank+select appended up to 512 keys per batch behind a best
+    list of k keys in a 512-slot area.  Worst case for the pending buffer: more than 1024 candidates whose distances
+    DEcrease in visiting order (every candidate beats tau).  Two big bins, members re-ordered by descending ADC distance
+    to query 0 (any member order is a valid bin list); results must equal the oracle's for every k."""
+    from common import Fixture
+    f = Fixture(D=16, P=1, C1=4, C2=2, W=1, LP=LP, n_base=9000, n_query=6, seed=91, heur_rows=2, train=1500)
+    o = f.oracle
+    u_ids, u_d = o.query_unsorted(f.queries[0], 10 ** 6, 2)
+    assert len(u_ids) > 1024
+    rank = {int(v): -float(d) for v, d in zip(u_ids, u_d)}  # descending distance first
+    members = f.members.copy()
+    off = 0
+    for sz in f.bin_sizes.tolist():
+        seg = members[off:off + sz]
+        if int(seg[0]) in rank:
+            members[off:off + sz] = np.array(sorted(seg.tolist(), key=lambda v: (rank[v], v)), np.uint32)
+        off += sz
+    o.import_bins(f.bin_ids, f.bin_sizes, members)
+    f.members = members
+    idx = f.hip_index()
+    try:
+        o.set_sort_mode(1)
+        u2, d2 = o.query_unsorted(f.queries[0], 10 ** 6, 2)
+        first = int(f.bin_sizes[list(f.bin_ids).index(o.bin_id(f.base[int(u2[0])]))])
+        assert np.all(np.diff(d2[:first]) <= 0), "fixture: first bin not in descending-distance order"
+        for k in (1, 37, 100, 128):
+            ids, dist, cnt = idx.query(f.queries, 10 ** 6, 2, k)
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = o.query(q, 10 ** 6, 2)
+                n = min(k, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(bits(dist[qi, :n]), bits(s_d[:n])), (LP, k, qi)
+                assert np.array_equal(ids[qi, :n], s_ids[:n]), (LP, k, qi)
+    finally:
+        o.set_sort_mode(0)
+        idx.close()
