@@ -9,14 +9,17 @@ rerank -> top-k) over one batch of QN synthetic SIFT-shaped queries, inputs and 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU (--gpus N > 1), one process per GPU.  Two ways the path shards:
-  * default for this workload (the 1 M-vector index is 70 MB, it fits every GPU): queries are the units -- every rank
-    holds the whole index and answers its own batch of QN queries; no data-path collective; per-GPU work is fixed
-    as N grows => "scaling": "weak", value = N*QN*steps / time.
-  * --shard-db (the north-star layout for databases that do not fit one GPU, SIFT1B): the database is range-sharded
-    by vector id, every rank runs the traversal for the whole batch, reranks its own slice, and the per-shard top-k
-    lists are merged after ONE RCCL all-gather => "scaling": "strong", value = QN*steps / time.  A short leg in this
-    layout also runs after the default one and is reported as config.db_sharded (never as `value`).
+Multi-GPU (--gpus N > 1), one process per GPU:
+  * default = the north-star layout: the database is RANGE-SHARDED by vector id (every rank synthesises, assigns and
+    line-encodes only its own id range, chunk by chunk; the per-bin global populations come from one all-gather at
+    build time), every rank runs the traversal for the whole batch, reranks its own slice, and the per-shard top-k
+    lists are merged after ONE RCCL all-gather per batch => "scaling": "strong", value = QN*steps / time.
+    Workload: BASELINE.json configs[2] shape, 100 M vectors (fits one GPU, so the same database is also timed on rank 0
+    alone after the timed region: config.same_workload_1gpu, the denominator of the strong-scaling ratio); with
+    --gpus 8 the default is configs[3]'s size, 1 B vectors (125 M per GPU).  --workload overrides either.
+  * --replicas: queries are the units instead -- every rank holds the whole SIFT1M-shape index and answers its own
+    batch, no data-path collective => "scaling": "weak", value = N*QN*steps / time (never the default: it does not
+    exercise the exchange step).
 """
 import argparse
 import importlib
@@ -41,6 +44,10 @@ WORKLOADS = {
     # run, not the bench line; the index is synthesised chunk by chunk with the product's own build kernel)
     "synth100m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=100_000_000, n_train=200_000, qn=10_000, chunk=4_000_000),
     "synth10m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=10_000_000, n_train=200_000, qn=10_000, chunk=2_000_000),
+    # BASELINE.json configs[3] size: 1 B vectors, range-sharded (16 GB of line codes per GPU at 8 GPUs)
+    "synth1b": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=1_000_000_000, n_train=200_000, qn=10_000, chunk=4_000_000),
+    # cfg3 shape at 1 M vectors: functional checks of the chunk-built / sharded path (not a bench line)
+    "synth1m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=1_000_000, n_train=100_000, qn=2_000, chunk=300_000),
     # small variant for quick checks (not a bench line)
     "tiny": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=50_000, n_train=20_000, qn=1_000),
 }
@@ -120,43 +127,89 @@ def brute_force_gt(base, queries, k):
 
 
 # ------------------------------------------------------------------------------------------------------
-def build_index(pkg, w, dev_index, seed_base=0xC0DE02, shard=None):
-    """Synthesise the database and load it into a PqtIndex.  Returns (index, base (device), meta)."""
-    dev = torch.device("cuda", dev_index)
-    D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
-    t0 = time.time()
+CHUNK_SEED = 0xC0DE02  # chunk ci of the database is sift_like(m, D, CHUNK_SEED + 7919 * ci)
+
+
+def chunk_ranges(w, lo, hi):
+    """(chunk index, first id of the chunk, chunk length, [a, b) = part of the chunk inside [lo, hi)) for every chunk of the
+    database that intersects [lo, hi).  The chunk grid is global, so a vector's value does not depend on the sharding."""
+    n, chunk = w["n_base"], w.get("chunk", w["n_base"])
+    out = []
+    for ci in range(lo // chunk, (max(hi, lo + 1) - 1) // chunk + 1):
+        s0 = ci * chunk
+        m = min(chunk, n - s0)
+        a, b = max(lo, s0), min(hi, s0 + m)
+        if b > a:
+            out.append((ci, s0, m, a, b))
+    return out
+
+
+def make_codebooks(w, dev, dist=None, world=1):
+    """Tree of the benchmark index; rank 0's codebooks are broadcast (the k-means M step uses atomics: not bit-reproducible)."""
+    D, P, C1, C2 = (w[k] for k in ("D", "P", "C1", "C2"))
     train = sift_like(w["n_train"], D, 0xC0DE01, dev)
-    base = sift_like(w["n_base"], D, seed_base, dev)
     cb1, cb2 = train_codebooks(train, P, C1, C2, 0xC0DE04)
     del train
-    t1 = time.time()
+    if world > 1:
+        t1, t2 = torch.from_numpy(cb1).to(dev), torch.from_numpy(cb2).to(dev)
+        dist.broadcast(t1, 0)
+        dist.broadcast(t2, 0)
+        cb1, cb2 = t1.cpu().numpy(), t2.cpu().numpy()
+    return cb1, cb2
+
+
+def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codebooks=None):
+    """Synthesise the database chunk by chunk with the product's own build kernel (insert = id() + prepareReranking) and load
+    it into a PqtIndex.  shard = (lo, hi): only that id range is generated, encoded and held (range shard built by the
+    shard itself; the per-bin global counts come from ONE all-gather, sharding.global_bin_counts).
+    Returns (index, base vectors on the device if the database is a single unsharded chunk else None, meta)."""
+    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
+    dev = torch.device("cuda", dev_index)
+    D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
+    n = w["n_base"]
+    lo, hi = shard if shard is not None else (0, n)
+    t0 = time.time()
+    cb1, cb2 = codebooks if codebooks is not None else make_codebooks(w, dev, dist, world)
     idx = pkg.PqtIndex(D, P, C1, C2, W, LP, device=dev_index)
     idx.set_codebooks(cb1, cb2)
-    n = base.shape[0]
-    bins = torch.empty(n, dtype=torch.int32, device=dev)
-    codes = torch.empty((n, LP), dtype=torch.int32, device=dev)
-    idx.assign_encode_dev(base, bins, codes, stream=torch.cuda.current_stream(dev).cuda_stream)  # product kernel: insert = id() + prepareReranking (same stream as the data synthesis)
+    nl = hi - lo
+    bins = torch.empty(nl, dtype=torch.int32, device=dev)
+    codes = torch.empty((nl, LP), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream  # same stream as the data synthesis
+    t1 = time.time()
+    base = None
+    ranges = chunk_ranges(w, lo, hi)
+    for ci, s0, m, a, b in ranges:
+        x = sift_like(m, D, CHUNK_SEED + 7919 * ci, dev)
+        idx.assign_encode_dev(x[a - s0:b - s0], bins[a - lo:b - lo], codes[a - lo:b - lo], stream=stream)
+        if shard is None and len(ranges) == 1:
+            base = x
+        del x
     torch.cuda.synchronize(dev)
     t2 = time.time()
     # CSR by bin id (vector ids ascending inside a bin = the reference's insertion order)
-    key = (bins.to(torch.int64) & 0xffffffff)
-    order = torch.argsort(key, stable=True)
-    ukeys, counts = torch.unique_consecutive(key[order], return_counts=True)
-    bin_ids = ukeys.cpu().numpy().astype(np.uint32)
-    sizes = counts.cpu().numpy().astype(np.uint32)
-    members = order.cpu().numpy().astype(np.uint32)
+    keys, counts, members = sharding.local_bin_lists(bins, lo)
+    del bins
+    meta = dict(cb1=cb1, cb2=cb2)
     if shard is None:
-        idx.set_bins(bin_ids, sizes, members)
+        bin_ids = keys.cpu().numpy().astype(np.uint32)
+        sizes = counts.cpu().numpy().astype(np.uint32)
+        mem = members.cpu().numpy().astype(np.uint32)
+        del keys, counts, members
+        torch.cuda.empty_cache()
+        idx.set_bins(bin_ids, sizes, mem)
         idx.set_lines_dev(codes, 0)
+        meta.update(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), bin_ids=bin_ids, sizes=sizes, members=mem)
     else:
-        lo, hi = shard
-        idx.set_bins_shard(bin_ids, sizes, members, lo, hi)
-        local = codes[lo:hi].clone()
-        del codes
-        idx.set_lines_dev(local, lo)
+        uk, gs, low, ls = sharding.global_bin_counts(dist, world, rank, keys, counts)
+        assert int(gs.max()) < 2 ** 32 and int(gs.sum()) == n, "global bin counts do not add up to the database size"
+        idx.set_bins_local(uk.cpu().numpy(), gs.cpu().numpy(), low.cpu().numpy(), ls.cpu().numpy(), members.cpu().numpy(), n)
+        idx.set_lines_dev(codes, lo)
+        meta.update(n_bins=int(uk.numel()), max_bin=int(gs.max()), local_vectors=nl)
+        del keys, counts, members
+        torch.cuda.empty_cache()
     t3 = time.time()
-    meta = dict(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), t_data=t1 - t0, t_encode=t2 - t1, t_csr=t3 - t2,
-                cb1=cb1, cb2=cb2, bin_ids=bin_ids, sizes=sizes, members=members)
+    meta.update(t_data=t1 - t0, t_encode=t2 - t1, t_csr=t3 - t2)
     return idx, base, meta
 
 
@@ -172,63 +225,31 @@ def usable_cores(omp_max):
     return max(1, n)
 
 
-def build_index_chunked(pkg, w, dev_index):
-    """Large databases: vectors are generated, assigned and line-encoded chunk by chunk (never resident as a whole)."""
-    dev = torch.device("cuda", dev_index)
-    D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
-    n, chunk = w["n_base"], w["chunk"]
-    t0 = time.time()
-    train = sift_like(w["n_train"], D, 0xC0DE01, dev)
-    cb1, cb2 = train_codebooks(train, P, C1, C2, 0xC0DE04)
-    del train
-    idx = pkg.PqtIndex(D, P, C1, C2, W, LP, device=dev_index)
-    idx.set_codebooks(cb1, cb2)
-    bins = torch.empty(n, dtype=torch.int32, device=dev)
-    codes = torch.empty((n, LP), dtype=torch.int32, device=dev)
-    t1 = time.time()
-    for ci, s0 in enumerate(range(0, n, chunk)):
-        m = min(chunk, n - s0)
-        x = sift_like(m, D, 0xC0DE02 + 7919 * ci, dev)
-        idx.assign_encode_dev(x, bins[s0:s0 + m], codes[s0:s0 + m], stream=torch.cuda.current_stream(dev).cuda_stream)
-        del x
-    torch.cuda.synchronize(dev)
-    t2 = time.time()
-    key = bins.to(torch.int64) & 0xffffffff
-    del bins
-    order = torch.argsort(key, stable=True)
-    ukeys, counts = torch.unique_consecutive(key[order], return_counts=True)
-    del key
-    bin_ids = ukeys.cpu().numpy().astype(np.uint32)
-    sizes = counts.cpu().numpy().astype(np.uint32)
-    members = order.cpu().numpy().astype(np.uint32)
-    del order, ukeys, counts
-    torch.cuda.empty_cache()
-    idx.set_bins(bin_ids, sizes, members)
-    idx.set_lines_dev(codes, 0)
-    t3 = time.time()
-    meta = dict(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), t_data=t1 - t0, t_encode=t2 - t1, t_csr=t3 - t2,
-                cb1=cb1, cb2=cb2, bin_ids=bin_ids, sizes=sizes, members=members)
-    return idx, None, meta
-
-
-def brute_force_gt_chunked(w, queries, dev):
-    """Exact nearest neighbour over the chunk-generated database (chunks are regenerated from their seeds)."""
-    n, chunk, D = w["n_base"], w["chunk"], w["D"]
+def brute_force_gt_chunked(w, queries, dev, lo=0, hi=None, dist=None, world=1):
+    """Exact nearest neighbour over the chunk-generated database (chunks are regenerated from their seeds); with a range
+    shard every rank scans its own ids and the per-query minimum is all-reduced (ties -> lowest id)."""
+    hi = w["n_base"] if hi is None else hi
+    D = w["D"]
     best_d = torch.full((queries.shape[0],), float("inf"), device=dev)
-    best_i = torch.zeros(queries.shape[0], dtype=torch.int64, device=dev)
-    for ci, s0 in enumerate(range(0, n, chunk)):
-        m = min(chunk, n - s0)
-        x = sift_like(m, D, 0xC0DE02 + 7919 * ci, dev)
+    best_i = torch.full((queries.shape[0],), 2 ** 62, dtype=torch.int64, device=dev)
+    qq = (queries * queries).sum(1)
+    for ci, s0, m, a, b in chunk_ranges(w, lo, hi):
+        x = sift_like(m, D, CHUNK_SEED + 7919 * ci, dev)[a - s0:b - s0]
         bn = (x * x).sum(1)
-        for a in range(0, queries.shape[0], 2048):
-            q = queries[a:a + 2048]
+        for qa in range(0, queries.shape[0], 2048):
+            q = queries[qa:qa + 2048]
             d = bn[None, :] - 2.0 * (q @ x.T)
             v, i = d.min(1)
-            v = v + (q * q).sum(1)
-            upd = v < best_d[a:a + 2048]
-            best_d[a:a + 2048] = torch.where(upd, v, best_d[a:a + 2048])
-            best_i[a:a + 2048] = torch.where(upd, i + s0, best_i[a:a + 2048])
+            v = v + qq[qa:qa + 2048]
+            upd = v < best_d[qa:qa + 2048]
+            best_d[qa:qa + 2048] = torch.where(upd, v, best_d[qa:qa + 2048])
+            best_i[qa:qa + 2048] = torch.where(upd, i + a, best_i[qa:qa + 2048])
         del x, bn
+    if world > 1:
+        gd = best_d.clone()
+        dist.all_reduce(gd, op=dist.ReduceOp.MIN)
+        best_i = torch.where(best_d == gd, best_i, torch.full_like(best_i, 2 ** 62))
+        dist.all_reduce(best_i, op=dist.ReduceOp.MIN)
     return best_i
 
 
@@ -237,20 +258,50 @@ def recall_at(ids, gt0, r):
     return float((ids[:, :r] == gt0[:, None]).any(1).float().mean())
 
 
+def kernel_bytes(w, qn, k, He, cand_local, fused_rs):
+    """Algorithmic bytes per launch of the two kernels of the path: SURVEY.md 8(d) terms only.
+         traversal  (a1-a6): 4*D (query) + 8*Bb (bin look-up: one (offset, count) pair per enumerated heuristic row)   per query
+         rerank+sel (a7-a8): 4*nCand (id gather) + 4*LP*nCand (line codes) + 8*k (results)                             per query
+       What the two-launch structure moves besides (NOT algorithmic: created by not fusing the two kernels) is returned as
+       `intermediate`: L1virt[LP][C1] written by the traversal and read by the rerank, the candidate list written and read
+       (+ candDist written and read when the staged k > 128 select runs)."""
+    LP, C1, D = w["LP"], w["C1"], w["D"]
+    trav = qn * (4 * D + 8 * He)
+    rs = cand_local * (4 + 4 * LP) + qn * 8 * k
+    inter_trav = qn * 4 * LP * C1 + 4 * cand_local
+    inter_rs = qn * 4 * LP * C1 + 4 * cand_local + (0 if fused_rs else 8 * cand_local)
+    return {"traverse": (trav, inter_trav), "rerank_select": (rs, inter_rs)}
+
+
+def time_steps(step, barrier, warmup, steps):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="sift1m", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
+                    help="default: sift1m on 1 GPU (BASELINE configs[1]); synth100m range-sharded on 2..7 GPUs, synth1b on 8 (configs[2]/[3])")
     ap.add_argument("--bv", type=int, default=20000, help="boundVectors (reference default: query(20000, 500, ...))")
     ap.add_argument("--bb", type=int, default=500, help="boundBins")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k); "
-                    "off by default so that a profile of the default command contains only the headline path's launches")
-    ap.add_argument("--shard-db", action="store_true", help="multi-GPU: range-shard the database instead of the queries")
+    ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k, "
+                    "opt-in ADC modes); off by default so that a profile of the default command contains only the headline path's launches")
+    ap.add_argument("--shard-db", action="store_true", help="(default for --gpus N > 1) range-shard the database")
+    ap.add_argument("--replicas", action="store_true", help="multi-GPU: replicate the index and shard the queries instead (weak scaling, no collective)")
+    ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
+    ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
     ap.add_argument("--centers", type=int, default=GEN["n_centers"])
@@ -264,6 +315,7 @@ def main():
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -285,51 +337,41 @@ def main():
     GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers, center_scale=args.center_scale)
     pkg = importlib.import_module("product-quantization-tree_amd")
     pkg.lib()  # fails loudly if the HIP library is missing
-    w = WORKLOADS[args.workload]
+    mode = "single" if world == 1 else ("replica" if args.replicas else "shard_db")
+    wl_name = args.workload or ("sift1m" if mode != "shard_db" else ("synth1b" if world >= 8 else "synth100m"))
+    w = WORKLOADS[wl_name]
     n = w["n_base"]
     sharding = importlib.import_module("product-quantization-tree_amd.sharding")
-    mode = "single" if world == 1 else ("shard_db" if args.shard_db else "replica")
     shard = sharding.shard_range(rank, world, n) if mode == "shard_db" else None
-    chunked = "chunk" in w
-    if chunked:
-        if mode != "single":
-            raise SystemExit("the chunk-built workloads are single-GPU runs")
-        idx, base, meta = build_index_chunked(pkg, w, local_rank)
-    else:
-        idx, base, meta = build_index(pkg, w, local_rank, shard=shard)
+    chunked = w.get("chunk", n) < n
+    idx, base, meta = build_index(pkg, w, local_rank, shard=shard, dist=dist, world=world if mode == "shard_db" else 1, rank=rank)
+    for ov in args.option:
+        name_, val_ = ov.split("=")
+        idx.set_option(name_, int(val_))
     t0 = time.time()
     idx.build_heuristic(max(args.bb, 1))
-    log("[bench] index: N=%d bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
-        (n, meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"], meta["t_csr"], time.time() - t0))
+    log("[bench] %s index: N=%d%s bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
+        (wl_name, n, (" (this rank: ids [%d, %d))" % shard) if shard else "", meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"],
+         meta["t_csr"], time.time() - t0))
 
-    # queries = perturbed base rows (seed 0xC0DE03), ground truth by exact brute force
+    # queries: fresh draws from the same mixture (like SIFT's separate query set), ground truth by exact brute force
     g = torch.Generator(device=dev)
     g.manual_seed(0xC0DE03)
     qn = w["qn"]
-    if args.query_mode == "perturbed":
+    if args.query_mode == "perturbed" and base is not None:
         pick = torch.randint(0, n, (qn,), generator=g, device=dev)
         queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
-    else:  # fresh draws from the same mixture (like SIFT's separate query set)
-        queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
-    if os.environ.get("PQT_EXP_QPERM"):
-        # experiment: give every XCD (workgroup b of the static rerank schedule runs on XCD b % 8) the queries of one
-        # contiguous slab of the last part's first-level cells, so that an XCD's L2 sees 1/8 of the code store
-        S_ = w["D"] // w["P"]
-        cb1_t = torch.from_numpy(meta["cb1"]).to(dev)[:, (w["P"] - 1) * S_:]
-        cell = torch.cdist(queries[:, (w["P"] - 1) * S_:], cb1_t).argmin(1)
-        srt = torch.argsort(cell, stable=True)
-        pos = torch.arange(qn, device=dev)
-        xcd = ((pos % 2048) // 8) % 8 if os.environ["PQT_EXP_QPERM"] == "xcd" else (pos * 8 // qn)
-        dest = torch.argsort(xcd, stable=True)          # batch positions grouped by the XCD that will serve them
-        perm = torch.empty(qn, dtype=torch.int64, device=dev)
-        perm[dest] = srt                                # position dest[i] receives the i-th query of the cell order
-        queries = queries[perm].contiguous()
-    if chunked:
-        gt = brute_force_gt_chunked(w, queries, dev)
-        raw_u8 = None
     else:
+        queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
+    if mode == "shard_db":
+        dist.broadcast(queries, 0)  # the SAME batch on every rank
+    if base is not None:
         gt = brute_force_gt(base, queries, 1)[:, 0]
-        raw_u8 = base.to(torch.uint8) if (args.extras and mode != "shard_db") else None  # raw vectors for the optional exact re-rank (8f-4)
+        raw_u8 = base.to(torch.uint8) if args.extras else None  # raw vectors for the optional exact re-rank (8f-4)
+    else:
+        lo_, hi_ = shard if shard else (0, n)
+        gt = brute_force_gt_chunked(w, queries, dev, lo_, hi_, dist, world if mode == "shard_db" else 1)
+        raw_u8 = None
     del base
     torch.cuda.empty_cache()
 
@@ -347,24 +389,18 @@ def main():
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
         else:
             # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
-            oi, od, oc = sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf)
-            out_idx.copy_(oi)
-            out_dist.copy_(od)
-            out_cnt.copy_(oc)
+            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time_steps(step, barrier, args.warmup, args.steps)
+    if mode == "shard_db":
+        out_idx.copy_(sbuf.out_idx)
+        out_dist.copy_(sbuf.out_dist)
+        out_cnt.copy_(sbuf.count)
     # per-stage device times of the timed steps themselves: the library records HIP events around every kernel on the
     # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
     hist = idx.stage_ms_history(min(args.steps, 32))
@@ -404,15 +440,15 @@ def main():
 
     ids_t = out_idx.to(torch.int64) & 0xffffffff
     r1, r10, r100 = recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100)
-    ncand_mean = float(out_cnt.to(torch.int64).float().mean())
+    ncand_mean = float(out_cnt.to(torch.int64).float().mean())  # GLOBAL candidates per query (all shards)
     cq = torch.quantile(out_cnt.to(torch.float32), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
     log("[bench] candidates per query: median %.0f p90 %.0f p99 %.0f max %.0f" % tuple(cq))
     cand_local = st["candidates"]  # local candidates reranked on this rank in the last step
-    bins_visited = st["bins_visited"] / max(1, st["queries"])
+    He = st["bins_visited"] / max(1, st["queries"])  # heuristic rows enumerated per query
 
     # optional "next" row 8f-4 (not part of the timed path): exact re-rank of the k results against the raw uint8 vectors
     exact = None
-    if args.extras and raw_u8 is not None and k <= 512:
+    if args.extras and raw_u8 is not None and k <= 512 and mode != "shard_db":
         ri = torch.empty_like(out_idx)
         rd = torch.empty_like(out_dist)
         idx.rerank_exact_dev(queries, k, out_idx, raw_u8, ri, rd, stream=stream)
@@ -427,28 +463,28 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     units = qn * (world if mode == "replica" else 1)  # queries answered by the whole job per step
     qps = units * args.steps / elapsed
-    if world > 1:  # job-wide recall / candidate statistics (outside the timed region)
+    if mode == "replica":  # job-wide recall / candidate statistics (outside the timed region)
         agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
         dist.all_reduce(agg)
         r1, r10, r100, ncand_mean = (agg / world).tolist()
 
     # ---- roofline of the dominant kernel (largest mean launch duration over the timed steps) ---------------------
-    # algorithmic bytes per launch (SURVEY.md 8d per-unit figures x the units one launch processes):
-    #   traversal  (a1-a6): query 4D + L1virt out 4*LP*C1 + heuristic rows 16*Bb + bin probes 2*16*Bb
-    #                       + candidate ids in/out 8*nCand                                   per query
-    #   rerank+sel (a7-a8): code rows 4*LP*nCand + candidate ids 4*nCand + L1virt in 4*LP*C1 + results 8*k per query
     LP, C1 = w["LP"], w["C1"]
     fused_rs = args.k <= 128
-    bytes_trav = qn * (4 * w["D"] + 4 * LP * C1 + 48 * bins_visited) + 8 * cand_local
-    bytes_rs = cand_local * (4 * LP + 4 + (0 if fused_rs else 4)) + qn * (4 * LP * C1 + 8 * k)
+    kb = kernel_bytes(w, qn, k, He, cand_local, fused_rs)
     rs_name = ("pqt_k_rerank_select_wg" if 4 * LP * C1 * C1 > 65536 else "pqt_k_rerank_select") if fused_rs else "pqt_k_rerank"
-    kern = {"traverse": ("pqt_k_traverse", bytes_trav), "rerank_select": (rs_name, bytes_rs)}
+    kname = {"traverse": "pqt_k_traverse", "rerank_select": rs_name}
     dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
-    rr_name, rr_bytes = kern[dominant]
+    rr_name = kname[dominant]
+    rr_bytes, rr_inter = kb[dominant]
     rr_ms = float(stage[dominant])
     rr_gbs = rr_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
-    # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k
-    path_bytes_q = 4 * w["D"] + 8 * bins_visited + 4 * ncand_mean + 4 * LP * ncand_mean + 8 * k
+    # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k (this rank's candidates)
+    ncand_rank = cand_local / max(1, qn)
+    path_bytes_q = 4 * w["D"] + 8 * He + 4 * ncand_rank + 4 * LP * ncand_rank + 8 * k
+    n_local = (shard[1] - shard[0]) if shard else n
+    store_bytes = n_local * LP * 4
+    resident = "infinity_cache" if store_bytes < (256 << 20) else "hbm"
 
     # HBM traffic of the dominant kernel from the committed PMC profile of this very command (profiles/pmc_latest.json,
     # produced by scripts/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor from the
@@ -456,10 +492,11 @@ def main():
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if pm.get("workload") == args.workload and pm.get("bv") == args.bv and pm.get("bb") == args.bb and pm.get("k") == args.k and world == 1:
-            ent = pm["kernels"].get(rr_name)
+        pms = pm if "runs" not in pm else next((r_ for r_ in pm["runs"] if r_.get("workload") == wl_name and r_.get("bv") == args.bv and r_.get("bb") == args.bb and r_.get("k") == args.k), {})
+        if pms.get("workload") == wl_name and pms.get("bv") == args.bv and pms.get("bb") == args.bb and pms.get("k") == args.k and world == 1 and not args.option:
+            ent = pms["kernels"].get(rr_name)
             if ent:
-                traffic = (ent["FETCH_SIZE_KiB"] * pm["fetch_factor"] + ent["WRITE_SIZE_KiB"]) * 1024.0
+                traffic = (ent["FETCH_SIZE_KiB"] * pms["fetch_factor"] + ent["WRITE_SIZE_KiB"]) * 1024.0
     except Exception:
         traffic = None
 
@@ -468,27 +505,41 @@ def main():
         "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if mode == "shard_db" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("SIFT1M-shape synthetic" if args.workload in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
+        "config": {"workload": ("SIFT1M-shape synthetic" if wl_name in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
                                "query(boundVectors=%d, boundBins=%d), k=%d" %
                                (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
+                   "workload_name": wl_name,
                    "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
-                                   "shard_db": "%d GPUs: db range-sharded + one RCCL all-gather of per-shard top-k" % world}[mode],
+                                   "shard_db": "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), traversal replicated, "
+                                               "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge" % (world, n_local)}[mode],
+                   "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if world > 1 else None), "collective_world_size": world,
+                   "options": args.option,
                    "global_batch": units,
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
-                   "mean_bins_visited": bins_visited, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
+                   "mean_candidates_this_rank": ncand_rank,
+                   "mean_bins_visited": He, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
                    "exact_rerank_of_topk": exact,
                    "algorithmic_bytes_per_query": path_bytes_q,
-                   "path_GBps": path_bytes_q * qps / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qps / 1e9 / HBM_PEAK_GBS,
-                   "stage_ms": stage, "dominant_kernel_by_time": rr_name},
+                   "path_GBps": path_bytes_q * qn * args.steps / elapsed / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qn * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                   "stage_ms": stage, "dominant_kernel_by_time": rr_name, "build_s": {k_: meta[k_] for k_ in ("t_data", "t_encode", "t_csr")}},
         "roofline": {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": rr_ms,
+                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_ratio": (traffic / rr_bytes) if traffic else None,
+                     "resident": resident, "line_store_bytes": store_bytes,
+                     "avg_launch_ms": rr_ms,
                      "algorithmic_bytes_per_launch": rr_bytes,
+                     "intermediate_bytes": rr_inter,
+                     "accounting": "SURVEY 8(d) terms only -- rerank+select: 4*nCand + 4*LP*nCand + 8k per query; traversal: 4*D + 8*Bb per query; "
+                                   "intermediate_bytes (L1virt and candidate-list round trips between the two launches) are listed, not priced",
                      "timing": "mean over the timed steps of the kernel's own duration: start/stop HIP events attached to the dispatch "
                                "(hipExtLaunchKernel) on the launch stream, read after the closing barrier",
-                     "other_kernels": {kern[n_][0]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kern[n_][1],
-                                                      "GBps": kern[n_][1] / max(stage[n_], 1e-9) / 1e6}
-                                       for n_ in kern if n_ != dominant}},
+                     "other_kernels": {kname[n_]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kb[n_][0], "intermediate_bytes": kb[n_][1],
+                                                   "GBps": kb[n_][0] / max(stage[n_], 1e-9) / 1e6, "frac": kb[n_][0] / max(stage[n_], 1e-9) / 1e6 / HBM_PEAK_GBS}
+                                       for n_ in kname if n_ != dominant}},
     }
+    if resident == "infinity_cache":
+        out["roofline"]["note"] = ("the %d MB line store of this workload stays in the 256 MiB Infinity Cache across batches: `frac` is priced against the HBM "
+                                   "peak but is not an HBM-bound result; the HBM-roofline configuration is --workload synth100m (BASELINE configs[2])" % (store_bytes >> 20))
 
     # ---- measured stream bandwidth of this device (device-to-device copy of 1 GiB: read + write), reported beside the nominal
     # peak the fractions above are priced with
@@ -513,23 +564,38 @@ def main():
         except Exception as e:
             out["roofline"]["measured_stream_GBps"] = None
 
+    def side_leg(bv_, bb_, k_, reps=5):
+        oi_ = torch.empty((qn, k_), dtype=torch.int32, device=dev)
+        od_ = torch.empty((qn, k_), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            idx.query_dev(queries, bv_, bb_, k_, oi_, od_, out_cnt, stream=stream)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(reps):
+            idx.query_dev(queries, bv_, bb_, k_, oi_, od_, out_cnt, stream=stream)
+        torch.cuda.synchronize(dev)
+        t2 = (time.perf_counter() - t2) / reps
+        h_ = idx.stage_ms_history(reps).mean(0).tolist()
+        st_ = idx.stats()
+        i2 = oi_.to(torch.int64) & 0xffffffff
+        kb_ = kernel_bytes(w, qn, k_, st_["bins_visited"] / max(1, st_["queries"]), st_["candidates"], k_ <= 128)
+        return {"queries_per_sec": qn / t2, "ms_per_step": t2 * 1e3, "k": k_, "recall@1": recall_at(i2, gt, 1), "recall@100": recall_at(i2, gt, 100),
+                "mean_candidates": float(out_cnt.float().mean()),
+                "stage_ms": dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), h_)),
+                "rerank_select_GBps": kb_["rerank_select"][0] / max(h_[3], 1e-9) / 1e6,
+                "rerank_select_frac": kb_["rerank_select"][0] / max(h_[3], 1e-9) / 1e6 / HBM_PEAK_GBS}, oi_, od_
+
     # ---- second knob set of BASELINE.md (the CUDA library's defaults k1/maxBins: boundVectors = boundBins = 4096), short leg,
     # reported beside the headline (never as `value`)
-    if args.extras and mode == "single" and (args.bv, args.bb) == (20000, 500) and not chunked:
+    if args.extras and mode == "single" and (args.bv, args.bb) == (20000, 500):
         try:
             idx.build_heuristic(4096)
-            for _ in range(2):
-                idx.query_dev(queries, 4096, 4096, k, out_idx, out_dist, out_cnt, stream=stream)
-            torch.cuda.synchronize(dev)
-            t2 = time.perf_counter()
-            for _ in range(5):
-                idx.query_dev(queries, 4096, 4096, k, out_idx, out_dist, out_cnt, stream=stream)
-            torch.cuda.synchronize(dev)
-            t2 = (time.perf_counter() - t2) / 5
-            i2 = out_idx.to(torch.int64) & 0xffffffff
-            out["config"]["knobs_4096_4096"] = {"queries_per_sec": qn / t2, "ms_per_step": t2 * 1e3, "recall@1": recall_at(i2, gt, 1),
-                                                "recall@100": recall_at(i2, gt, 100), "mean_candidates": float(out_cnt.float().mean()),
-                                                "launch_structure": "fused traversal in wide mode (boundBins > 512: rows in blocks of 512, populated rows listed) + fused rerank/select"}
+            leg, _, _ = side_leg(4096, 4096, k)
+            leg["launch_structure"] = "fused traversal in wide mode (boundBins > 512: rows in blocks of 512, populated rows listed) + fused rerank/select"
+            out["config"]["knobs_4096_4096"] = leg
+            if os.environ.get("PQT_BENCH_K4096"):
+                leg, _, _ = side_leg(4096, 4096, 4096, reps=3)  # the reference front-end's own call: queryKNN(..., 4096) (tool_query.cpp:155)
+                out["config"]["knobs_4096_4096_k4096"] = leg
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)  # restore the headline outputs
             torch.cuda.synchronize(dev)
         except Exception as e:
@@ -537,7 +603,7 @@ def main():
 
     # ---- batch split over two handles on two streams (same index data): the traversal of one half overlaps the rerank of
     # the other.  Reported beside the headline (never as `value`: the per-kernel roofline accounting above is single-stream)
-    if mode == "single" and not chunked and not os.environ.get("PQT_BENCH_NO_PIPELINE"):
+    if mode == "single" and not chunked and not os.environ.get("PQT_BENCH_NO_PIPELINE") and not args.option:
         try:
             idx2 = pkg.PqtIndex(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], device=dev.index or 0)
             idx2.set_codebooks(meta["cb1"], meta["cb2"])
@@ -574,8 +640,9 @@ def main():
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
     if mode == "single" and not args.no_cpu and not chunked:
         from oracle import Oracle
-        o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=1)
-        o.set_heuristic(idx.heuristic(max(args.bb, 1)))
+        # the checker builds its OWN heuristic table (prepareHeuristic restatement) -- it is compared with the library's below
+        o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=max(args.bb, 1))
+        heur_same = bool(np.array_equal(o.heuristic(max(args.bb, 1)), idx.heuristic(max(args.bb, 1))))
         o.set_codebooks(meta["cb1"], meta["cb2"])
         o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
         codes_host = idx._keep[0].cpu().numpy().view(np.uint32)
@@ -609,43 +676,75 @@ def main():
                                "sample": "%d passes over the %d bench queries (%.1f s of work), same index, all host threads (OpenMP over queries, one context per thread)"
                                          % (reps, qn, cpu_t),
                                "single_thread_qps": s1 / cpu1_t, "single_thread_ms_per_query": cpu1_t / s1 * 1e3,
-                               "result_lists_identical_frac": same}
-    # ---- north-star layout on the same job (short leg, never the headline value) ----------------------------------
-    if mode == "replica":
+                               "result_lists_identical_frac": same, "heuristic_table_identical": heur_same}
+    elif mode == "single" and not args.no_cpu and chunked and n <= 20_000_000:
+        out["cpu_baseline"] = cpu_baseline_chunked(pkg, idx, w, meta, queries, args, out_idx, out_dist, k)
+
+    # ---- range-sharded run: the SAME database on ONE GPU (rank 0 builds it whole and times the single-GPU path while the
+    # others wait), so the line carries the denominator of its own strong-scaling ratio
+    if mode == "shard_db":
+        ref1 = None
         try:
-            idx.close()
-            del idx
-            torch.cuda.empty_cache()
-            sidx, sbase, smeta = build_index(pkg, w, local_rank, shard=sharding.shard_range(rank, world, n))
-            del sbase
-            sidx.build_heuristic(max(args.bb, 1))
-            squeries = sift_like(qn, w["D"], 0xC0DE03, dev)  # the SAME batch on every rank
-            sbuf = sharding.ShardBuffers(world, qn, k, dev)
-            engine = sharding.PqtShardEngine(sidx)
-            for _ in range(2):
-                sharding.sharded_query(engine, dist, world, squeries, args.bv, args.bb, k, sbuf)
-            barrier()
-            ts = time.perf_counter()
-            nstep = max(3, min(args.steps, 10))
-            for _ in range(nstep):
-                sharding.sharded_query(engine, dist, world, squeries, args.bv, args.bb, k, sbuf)
-            barrier()
-            tsh = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
-            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
-            # every rank must hold the same merged result
-            chk = sbuf.out_idx.to(torch.int64).sum().reshape(1)
-            lo, hi = chk.clone(), chk.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            out["config"]["db_sharded"] = {"queries_per_sec": qn * nstep / float(tsh.item()), "ms_per_step": float(tsh.item()) / nstep * 1e3,
-                                           "scaling": "strong", "ranks_agree": bool(lo.item() == hi.item()),
-                                           "layout": "db range-sharded x%d, replicated traversal, one RCCL all-gather of [3][QN][k] words, exact merge" % world}
-        except Exception as e:  # the headline measurement above stands on its own
-            out["config"]["db_sharded"] = {"error": repr(e)[:300]}
+            if not args.no_ref1 and n <= 200_000_000:
+                if rank == 0:
+                    ridx, _, rmeta = build_index(pkg, w, local_rank, codebooks=(meta["cb1"], meta["cb2"]))
+                    ridx.build_heuristic(max(args.bb, 1))
+                    for ov in args.option:
+                        ridx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
+                    ro = (torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty((qn, k), dtype=torch.float32, device=dev), torch.empty(qn, dtype=torch.int32, device=dev))
+                    nst = max(3, min(args.steps, 10))
+                    t1g = time_steps(lambda: ridx.query_dev(queries, args.bv, args.bb, k, ro[0], ro[1], ro[2], stream=stream),
+                                     lambda: torch.cuda.synchronize(dev), 2, nst)
+                    same = bool(torch.equal(ro[0], out_idx) and torch.equal(ro[1], out_dist) and torch.equal(ro[2], out_cnt))
+                    h1 = ridx.stage_ms_history(nst).mean(0).tolist()
+                    ref1 = {"queries_per_sec": qn * nst / t1g, "ms_per_step": t1g / nst * 1e3, "results_identical_to_sharded": same,
+                            "stage_ms": dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), h1)),
+                            "speedup_of_this_run": qps / (qn * nst / t1g)}
+                    ridx.close()
+                dist.barrier()
+        except Exception as e:
+            ref1 = {"error": repr(e)[:300]}
+        out["config"]["same_workload_1gpu"] = ref1
+        # every rank must hold the same merged result
+        chk = (sbuf.out_idx.to(torch.int64) & 0xffffffff).sum().reshape(1)
+        lo_c, hi_c = chk.clone(), chk.clone()
+        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
+        out["config"]["ranks_agree"] = bool(lo_c.item() == hi_c.item())
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline_chunked(pkg, idx, w, meta, queries, args, out_idx, out_dist, k):
+    """cpu_baseline for a chunk-built database of <= 20 M vectors: the oracle is loaded with the engine-built bins and codes
+    (insert() is bit-identical to the build kernel, tests/test_gpu_parity.py) and timed on a bounded sample."""
+    from oracle import Oracle
+    o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=max(args.bb, 1))
+    heur_same = bool(np.array_equal(o.heuristic(max(args.bb, 1)), idx.heuristic(max(args.bb, 1))))
+    o.set_codebooks(meta["cb1"], meta["cb2"])
+    o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
+    o.import_codes(idx._keep[0].cpu().numpy().view(np.uint32))
+    qh = queries.cpu().numpy()
+    cores = usable_cores(o.max_threads())
+    ns = min(qh.shape[0], 256)
+    t = time.perf_counter()
+    o.query_batch(qh[:ns], args.bv, args.bb, k, nthreads=cores)
+    pass_t = time.perf_counter() - t
+    reps = int(max(1, min(200, args.cpu_seconds / max(pass_t, 1e-6))))
+    t = time.perf_counter()
+    for _ in range(reps):
+        o.query_batch(qh[:ns], args.bv, args.bb, k, nthreads=cores)
+    cpu_t = time.perf_counter() - t
+    o.set_sort_mode(1)
+    ci, cd, cc = o.query_batch(qh[:ns], args.bv, args.bb, k, nthreads=cores)
+    gi = out_idx[:ns].cpu().numpy().view(np.uint32)
+    gd = out_dist[:ns].cpu().numpy()
+    same = float(np.mean([np.array_equal(gi[i], ci[i]) and np.array_equal(gd[i].view(np.uint32), cd[i].view(np.uint32)) for i in range(ns)]))
+    return {"value": reps * ns / cpu_t, "unit": "queries/sec", "cores": cores, "kind": "port",
+            "sample": "%d passes over the first %d bench queries (%.1f s of work), same index, all host threads" % (reps, ns, cpu_t),
+            "result_lists_identical_frac": same, "heuristic_table_identical": heur_same}
 
 
 if __name__ == "__main__":

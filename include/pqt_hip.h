@@ -126,6 +126,15 @@ int pqt_index_set_bins(pqt_index* idx, uint64_t nbins, const uint32_t* bin_ids_h
 int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* bin_ids_host,
                              const uint32_t* bin_sizes_host, const uint32_t* members_host,
                              uint32_t id_lo, uint32_t id_hi);
+/* The same range shard described from the shard's side, for indices built shard by shard (each device encodes only its own
+ * id range and never sees the other members): for every bin of the WHOLE database its id, its global population,
+ * the number of its members held by lower-ranked shards (ids below this shard's range) and by this shard, and the
+ * concatenated local member lists (ids ascending inside a bin = the reference's insertion order).  n_total = database
+ * size over all shards.  Counterpart of the chunked build + CSR merge of test/test1B.cpp:783-871, with the merge
+ * reduced to the per-bin counts (one all-gather at build time, see bench.py / sharding.py). */
+int pqt_index_set_bins_local(pqt_index* idx, uint64_t nbins, const uint32_t* bin_ids_host, const uint32_t* global_sizes_host,
+                             const uint32_t* lower_sizes_host, const uint32_t* local_sizes_host,
+                             const uint32_t* local_members_host, uint64_t n_total);
 /* replaces: PerturbationProTree::setDB(N, prefix, counts, dbIdx) (PerturbationProTree.hh:66,
  * .cu:1184-1229): the CUDA library's dense hashed CSR, slot = bin id % hash_size.  Host pointers. */
 int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix_host,

@@ -44,7 +44,7 @@ EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
     "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather", "pqt_rerank_exact",
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
-    "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_db_hashed",
+    "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
     "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle",
@@ -83,6 +83,7 @@ def lib():
     L.pqt_index_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_index_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p]
     L.pqt_index_set_bins_shard.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint32, C.c_uint32]
+    L.pqt_index_set_bins_local.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, u32p, u32p, C.c_uint64]
     L.pqt_index_set_db_hashed.argtypes = [C.c_void_p, C.c_uint32, u32p, u32p, u32p, C.c_uint32]
     L.pqt_index_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64, C.c_uint64]
     L.pqt_index_set_lines_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -178,6 +179,13 @@ class PqtIndex:
         ids, sizes, members = _np(ids, np.uint32), _np(sizes, np.uint32), _np(members, np.uint32)
         _chk(self.L.pqt_index_set_bins_shard(self.h, ids.shape[0], _p(ids, u32p), _p(sizes, u32p), _p(members, u32p),
                                              id_lo, id_hi))
+
+    def set_bins_local(self, ids, gsizes, lower, lsizes, local_members, n_total):
+        """Range shard described from the shard's side (see include/pqt_hip.h: pqt_index_set_bins_local)."""
+        ids, gsizes, lower, lsizes, local_members = (_np(a, np.uint32) for a in (ids, gsizes, lower, lsizes, local_members))
+        assert ids.shape == gsizes.shape == lower.shape == lsizes.shape
+        _chk(self.L.pqt_index_set_bins_local(self.h, ids.shape[0], _p(ids, u32p), _p(gsizes, u32p), _p(lower, u32p), _p(lsizes, u32p),
+                                             _p(local_members, u32p), int(n_total)))
 
     def set_db_hashed(self, prefix, counts, dbidx, hash_size):
         prefix, counts, dbidx = _np(prefix, np.uint32), _np(counts, np.uint32), _np(dbidx, np.uint32)

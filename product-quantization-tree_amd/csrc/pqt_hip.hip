@@ -827,6 +827,24 @@ int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* ids
   return uploadBins(idx, bins, local, true);
 }
 
+int pqt_index_set_bins_local(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* gsizes, const uint32_t* lower,
+                             const uint32_t* lsizes, const uint32_t* members, uint64_t n_total) {
+  if (!idx || (nbins && (!ids || !gsizes || !lower || !lsizes)) ) return fail(PQT_ERR_INVALID, "null argument");
+  std::vector<BinDesc> bins(nbins);
+  uint64_t off = 0;
+  for (uint64_t b = 0; b < nbins; ++b) {
+    if ((uint64_t)lower[b] + lsizes[b] > gsizes[b]) return fail(PQT_ERR_INVALID, "lower + local members exceed the bin's global population");
+    if (off > 0xffffffffull) return fail(PQT_ERR_LIMIT, "more than 2^32 local members");
+    bins[b] = {ids[b], gsizes[b], (uint32_t)off, lsizes[b], lower[b]};
+    off += lsizes[b];
+  }
+  if (off && !members) return fail(PQT_ERR_INVALID, "null argument");
+  std::vector<uint32_t> local(members, members + off);
+  idx->dp.hashMod = 0;
+  idx->nTotal = n_total;
+  return uploadBins(idx, bins, local, true);
+}
+
 int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix, const uint32_t* counts, const uint32_t* dbidx,
                             uint32_t hash_size) {
   if (!idx || !prefix || !counts || !dbidx || !hash_size) return fail(PQT_ERR_INVALID, "null argument");

@@ -19,6 +19,55 @@ def shard_range(rank, world, n):
     return rank * n // world, (rank + 1) * n // world
 
 
+def local_bin_lists(bin_keys, id_lo):
+    """CSR of one shard from the bin id of each of its vectors (rows id_lo, id_lo + 1, ...): returns (keys ascending,
+    sizes, members) with the members of a bin in ascending id order = the reference's insertion order
+    (treequantizer.hpp:212-217, std::map<uint, vector<uint>>::push_back).  Pure tensor plumbing on bin_keys' device."""
+    key = bin_keys.to(torch.int64) & 0xffffffff
+    order = torch.argsort(key, stable=True)
+    ukeys, counts = torch.unique_consecutive(key[order], return_counts=True)
+    return ukeys, counts, order + id_lo
+
+
+def merge_bin_counts(all_keys, all_counts, rank):
+    """Pure part of the build-time exchange: from every shard's (bin ids ascending, local populations) derive, for the union
+    of bins in ascending id order, gsize = global population (drives the identical cut on every shard), lower = members
+    on lower ranks (offset of this shard's members inside the bin's global member list), lsize = members on `rank`."""
+    dev = all_keys[0].device
+    ks = torch.cat([k.to(torch.int64) for k in all_keys])
+    cs = torch.cat([c.to(torch.int64) for c in all_counts])
+    rs = torch.cat([torch.full((k.numel(),), r, dtype=torch.int64, device=dev) for r, k in enumerate(all_keys)])
+    uk, inv = torch.unique(ks, return_inverse=True)  # sorted ascending
+    z = torch.zeros(uk.numel(), dtype=torch.int64, device=dev)
+    gsize = z.clone().index_add_(0, inv, cs)
+    lower = z.clone().index_add_(0, inv[rs < rank], cs[rs < rank])
+    lsize = z.clone().index_add_(0, inv[rs == rank], cs[rs == rank])
+    return uk, gsize, lower, lsize
+
+
+def global_bin_counts(dist, world, rank, keys, counts):
+    """Build-time exchange of a database built shard by shard (the CSR merge of test/test1B.cpp:783-871 reduced to the
+    per-bin counts): every rank contributes (bin id, local population) of its non-empty bins through ONE padded
+    all-gather and derives merge_bin_counts() of the gathered lists.
+    keys/counts: int64 tensors (keys ascending, unique).  Returns (ukeys, gsize, lower, lsize) as int64 tensors."""
+    dev = keys.device
+    keys, counts = keys.to(torch.int64), counts.to(torch.int64)
+    if world == 1:
+        return keys, counts, torch.zeros_like(counts), counts
+    n = torch.tensor([keys.numel()], dtype=torch.int64, device=dev)
+    ns = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(ns, n)
+    ns = ns.tolist()
+    m = max(max(ns), 1)
+    pad = torch.zeros((2, m), dtype=torch.int64, device=dev)
+    pad[0, :keys.numel()] = keys
+    pad[1, :keys.numel()] = counts
+    allp = torch.empty((world * 2, m), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allp, pad)
+    allp = allp.view(world, 2, m)
+    return merge_bin_counts([allp[r, 0, :ns[r]] for r in range(world)], [allp[r, 1, :ns[r]] for r in range(world)], rank)
+
+
 class ShardBuffers:
     def __init__(self, world, qn, k, device):
         i32 = torch.int32

@@ -90,8 +90,8 @@ def test_fullsize_oracle_spot_check(big):
     """64 queries of the 10 k batch against the oracle loaded with the same 1 M-vector index."""
     from oracle import Oracle
     pkg, w, idx, base, meta, queries = big
-    o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=1)
-    o.set_heuristic(idx.heuristic(500))
+    o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=500)  # the checker builds its OWN 64^4-tuple table
+    assert np.array_equal(o.heuristic(500), idx.heuristic(500))
     o.set_codebooks(meta["cb1"], meta["cb2"])
     o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
     o.import_codes(idx._keep[0].cpu().numpy().view(np.uint32))
@@ -115,3 +115,127 @@ def test_fullsize_oracle_spot_check(big):
             if j is not None:
                 members.update(meta["members"][starts[j]:starts[j + 1]].tolist())
         assert set(ids[i, :n].tolist()) <= members
+
+
+# =====================================================================================================================
+# BASELINE.json configs[2]/[3] shape (d=128 p=4 c1=c2=64 lineparts=32, 128-byte code rows, workgroup-per-query rerank with
+# the group-major store), chunk-built at 10 M vectors: the sizes at which the cfg3/cfg4 code paths run for real.
+# =====================================================================================================================
+@pytest.fixture(scope="module")
+def big3():
+    import importlib
+    import torch
+    import bench
+    pkg = importlib.import_module("product-quantization-tree_amd")
+    w = bench.WORKLOADS["synth10m"]
+    idx, base, meta = bench.build_index(pkg, w, 0)
+    assert base is None  # chunk-built: the raw vectors are never resident as a whole
+    idx.build_heuristic(4096)
+    queries = bench.sift_like(512, w["D"], 0xC0DE03, torch.device("cuda", 0))
+    yield pkg, w, idx, meta, queries
+    idx.close()
+
+
+@pytest.mark.parametrize("bv,bb", [(20000, 500), (4096, 4096)])
+def test_cfg3_fullsize_properties(big3, bv, bb):
+    pkg, w, idx, meta, queries = big3
+    ids, dist, cnt = run(idx, queries, bv, bb, 100)
+    qn = ids.shape[0]
+    n_valid = np.minimum(cnt, 100)
+    for qi in range(qn):
+        n = int(n_valid[qi])
+        d = dist[qi, :n]
+        assert np.all(d[1:] >= d[:-1])
+        assert np.all(ids[qi, n:] == 0xffffffff) and np.all(np.isinf(dist[qi, n:]))
+        assert ids[qi, :n].max(initial=0) < w["n_base"]
+    st = idx.stats()
+    assert int(cnt.astype(np.int64).sum()) == st["candidates"]
+    assert int(cnt.max()) <= bv + meta["max_bin"]
+    assert int(cnt.max()) > 1000  # the rerank really works on long lists here
+    ids10, dist10, cnt10 = run(idx, queries, bv, bb, 10)
+    assert np.array_equal(ids10, ids[:, :10]) and np.array_equal(dist10.view(np.uint32), dist[:, :10].view(np.uint32))
+    ids2, dist2, cnt2 = run(idx, queries, bv, bb, 100)
+    assert np.array_equal(ids2, ids) and np.array_equal(dist2.view(np.uint32), dist.view(np.uint32))
+    pieces = [run(idx, queries[a:b], bv, bb, 100) for a, b in ((0, 1), (1, 130), (130, qn))]
+    assert np.array_equal(np.concatenate([p[0] for p in pieces]), ids)
+    assert np.array_equal(np.concatenate([p[1] for p in pieces]).view(np.uint32), dist.view(np.uint32))
+    # structure independence: workgroup-per-query fused rerank (group-major store) == staged kernels == wave-per-query kernel
+    for opt, val, back in (("fused", 0, 1), ("wg_rerank", 0, 1)):
+        idx.set_option(opt, val)
+        try:
+            ids_s, dist_s, cnt_s = run(idx, queries[:128], bv, bb, 100)
+        finally:
+            idx.set_option(opt, back)
+        assert np.array_equal(ids_s, ids[:128]) and np.array_equal(dist_s.view(np.uint32), dist[:128].view(np.uint32)) and np.array_equal(cnt_s, cnt[:128]), opt
+    # k > 128 (staged select) agrees with the fused top-100 on its prefix
+    ids_k, dist_k, _ = run(idx, queries[:64], bv, bb, 1000)
+    assert np.array_equal(ids_k[:, :100], ids[:64]) and np.array_equal(dist_k[:, :100].view(np.uint32), dist[:64].view(np.uint32))
+
+
+def test_cfg3_fullsize_oracle_spot_check(big3):
+    """64 queries against the oracle loaded with the same 10 M-vector index; the oracle builds its own heuristic table."""
+    from oracle import Oracle
+    pkg, w, idx, meta, queries = big3
+    o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=4096)
+    assert np.array_equal(o.heuristic(4096), idx.heuristic(4096))
+    o.set_codebooks(meta["cb1"], meta["cb2"])
+    o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
+    o.import_codes(idx._keep[0].cpu().numpy().view(np.uint32))
+    o.set_sort_mode(1)
+    qh = queries[:64].cpu().numpy()
+    for bv, bb in ((20000, 500), (4096, 4096)):
+        ids, dist, cnt = run(idx, queries[:64], bv, bb, 100)
+        for i in range(64):
+            s_ids, s_d = o.query(qh[i], bv, bb)
+            n = min(100, len(s_ids))
+            assert int(cnt[i]) == len(s_ids), (bv, bb, i)
+            assert np.array_equal(dist[i, :n].view(np.uint32), s_d[:n].view(np.uint32)), (bv, bb, i)
+            assert np.array_equal(ids[i, :n], s_ids[:n]), (bv, bb, i)
+
+
+def test_cfg3_fullsize_eight_way_shards_equal_unsharded(big3):
+    """The north-star layout on one device: 8 range shards described from the shard's side (pqt_index_set_bins_local with
+    the counts of sharding.merge_bin_counts), each queried with pqt_query_shard, merged with pqt_merge_topk at 8 x k."""
+    import importlib
+    import torch
+    pkg, w, idx, meta, queries = big3
+    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
+    n, world, k = w["n_base"], 8, 100
+    dev = queries.device
+    bin_of_vec = torch.empty(n, dtype=torch.int64, device=dev)
+    bin_of_vec[torch.from_numpy(meta["members"].astype(np.int64)).to(dev)] = \
+        torch.repeat_interleave(torch.from_numpy(meta["bin_ids"].astype(np.int64)), torch.from_numpy(meta["sizes"].astype(np.int64))).to(dev)
+    codes = idx._keep[0]
+    ranges = [sharding.shard_range(r, world, n) for r in range(world)]
+    local = [sharding.local_bin_lists(bin_of_vec[lo:hi], lo) for lo, hi in ranges]
+    shards = []
+    try:
+        for r, (lo, hi) in enumerate(ranges):
+            uk, gs, low, ls = sharding.merge_bin_counts([l[0] for l in local], [l[1] for l in local], r)
+            assert int(gs.sum()) == n and int(ls.sum()) == hi - lo
+            sh = pkg.PqtIndex(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], device=0)
+            sh.set_codebooks(meta["cb1"], meta["cb2"])
+            sh.build_heuristic(4096)
+            sh.set_bins_local(uk.cpu().numpy(), gs.cpu().numpy(), low.cpu().numpy(), ls.cpu().numpy(), local[r][2].cpu().numpy(), n)
+            sh.set_lines_dev(codes[lo:hi], lo)
+            shards.append(sh)
+        q = queries[:256]
+        qn = q.shape[0]
+        for bv, bb in ((20000, 500), (4096, 4096)):
+            ref_ids, ref_d, ref_c = run(idx, q, bv, bb, k)
+            pack = torch.empty((world, 3, qn, k), dtype=torch.int32, device=dev)
+            Cc = torch.empty((world, qn), dtype=torch.int32, device=dev)
+            tot_local = 0
+            for s, sh in enumerate(shards):
+                sh.query_shard_dev(q, bv, bb, k, pack[s, 0], pack[s, 1].view(torch.float32), pack[s, 2], Cc[s], sync=True)
+                tot_local += sh.stats()["candidates"]
+                assert np.array_equal(Cc[s].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
+            assert tot_local == int(ref_c.astype(np.int64).sum())  # the shards partition the candidates
+            oI = torch.empty((qn, k), dtype=torch.int32, device=dev)
+            oD = torch.empty((qn, k), dtype=torch.float32, device=dev)
+            shards[0].merge_topk_dev(world, qn, k, pack[0, 0], pack[0, 1].view(torch.float32), pack[0, 2], oI, oD, sync=True, shard_stride=3 * qn * k)
+            assert np.array_equal(oI.cpu().numpy().view(np.uint32), ref_ids), (bv, bb)
+            assert np.array_equal(oD.cpu().numpy().view(np.uint32), ref_d.view(np.uint32)), (bv, bb)
+    finally:
+        for sh in shards:
+            sh.close()
