@@ -41,6 +41,7 @@ def _lib():
     L.pqo_create.argtypes = [C.c_uint] * 6 + [C.c_ulonglong, C.c_int]
     L.pqo_destroy.argtypes = [C.c_void_p]
     L.pqo_set_sort_mode.argtypes = [C.c_void_p, C.c_int]
+    L.pqo_set_sum_mode.argtypes = [C.c_void_p, C.c_int]
     L.pqo_max_multi_index.restype = C.c_ulonglong
     L.pqo_max_multi_index.argtypes = [C.c_void_p]
     L.pqo_heuristic_rows.restype = C.c_ulonglong
@@ -159,6 +160,10 @@ class Oracle:
     # ---- configuration -----------------------------------------------------------
     def set_sort_mode(self, m):
         self.L.pqo_set_sort_mode(self.h, m)
+
+    def set_sum_mode(self, m):
+        """Sensitivity probe: order of the squared-norm sums (0 = sequential, the parity definition; 1..5 see pqt_oracle.cpp)."""
+        self.L.pqo_set_sum_mode(self.h, m)
 
     @property
     def max_multi_index(self):

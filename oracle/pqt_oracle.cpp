@@ -83,17 +83,71 @@ static inline float extract_distance(float a, float b, float c, float l) {
 // ---- cpu_version/helper.hpp:169-172  calcRatio
 static inline float calc_ratio(float a, float b, float c) { return -0.5f * (a - b - c) / c; }
 
-// squared norm of (x - y) over n dims, sequential left-to-right, separate mul and add.
-// Stands for `(vec - cec).segment(..).squaredNorm()` (treequantizer.hpp:645-655,
-// vectorquantizer.hpp:106-109); see header note on Eigen's unpinned order.
-static inline float sqdist_seq(const float* x, const float* y, uint n) {
-  float s = 0;
-  for (uint i = 0; i < n; ++i) {
-    const float d = x[i] - y[i];
-    s += d * d;
+// squared norm of (x - y) over n dims.  Stands for `(vec - cec).segment(..).squaredNorm()` (treequantizer.hpp:197,
+// 645-655, vectorquantizer.hpp:88,106-109, productquantizer.hpp:55).  Eigen's reduction order is not pinned by anything in
+// the reference (un-vendored library, version unknown), so the order is a run-time mode:
+//   0  sequential left to right, separate multiply and add: the literal reading of the source.  DEFAULT, and the order
+//      the HIP kernels implement (bit-identical tables).
+//   1..5  SENSITIVITY PROBES (tests/test_cpu_sum_order.py): the orders Eigen's vectorised redux would produce, restated
+//      from Eigen's published algorithm (Core/Redux.h: packet partial sums, then a horizontal add `predux`):
+//      1  SSE2 packets of 4 -- what the reference's own build flags select (cpu_version/CMakeLists.txt:20 has no -march)
+//         -- linear traversal with two packet accumulators (Eigen 3.3 NoUnrolling), predux (a0+a2)+(a1+a3)
+//      2  SSE2 packets of 4, balanced tree over the packets (CompleteUnrolling of a fixed-size vector), same predux
+//      3  SSE2 packets of 4, one packet accumulator (Eigen 3.2), same predux
+//      4  AVX packets of 8 (a -march=native build): two accumulators, predux = fold halves then the SSE predux; fewer
+//         than 8 elements are summed sequentially (too small to vectorise)
+//      5  sequential with fused multiply-add (a -Ofast -march=native scalar loop)
+//      For 4 and 8 elements (the L1virt segments of every BASELINE shape) modes 1-3 coincide.
+static inline float predux4(const float* a) { return (a[0] + a[2]) + (a[1] + a[3]); }
+static inline float sqdist(int mode, const float* x, const float* y, uint n) {
+  if (mode == 0 || n < 4 || (mode == 4 && n < 8)) {
+    float s = 0;
+    for (uint i = 0; i < n; ++i) {
+      const float d = x[i] - y[i];
+      s += d * d;
+    }
+    return s;
   }
+  if (mode == 5) {
+    float s = 0;
+    for (uint i = 0; i < n; ++i) { const float d = x[i] - y[i]; s = __builtin_fmaf(d, d, s); }
+    return s;
+  }
+  const uint PS = mode == 4 ? 8 : 4;
+  const uint np = n / PS;  // whole packets; the tail is added sequentially after the horizontal add (Redux.h)
+  float pk[64][8];
+  if (np > 64) return -1.f;
+  for (uint k = 0; k < np; ++k)
+    for (uint l = 0; l < PS; ++l) { const float d = x[k * PS + l] - y[k * PS + l]; pk[k][l] = d * d; }
+  auto addp = [&](float* a, const float* b2) { for (uint l = 0; l < PS; ++l) a[l] = a[l] + b2[l]; };
+  float acc[8];
+  if (mode == 2) {
+    // balanced tree: redux_vec_unroller splits [start, start+len) into halves
+    struct T { static void run(float (*pk)[8], uint PS, uint s0, uint len, float* out) {
+      if (len == 1) { for (uint l = 0; l < PS; ++l) out[l] = pk[s0][l]; return; }
+      float a[8], b[8];
+      run(pk, PS, s0, len / 2, a); run(pk, PS, s0 + len / 2, len - len / 2, b);
+      for (uint l = 0; l < PS; ++l) out[l] = a[l] + b[l];
+    } };
+    T::run(pk, PS, 0, np, acc);
+  } else if (mode == 3 || np == 1) {
+    for (uint l = 0; l < PS; ++l) acc[l] = pk[0][l];
+    for (uint k = 1; k < np; ++k) addp(acc, pk[k]);
+  } else {  // modes 1, 4: two accumulators over pairs of packets, then res0 + res1, then a possible odd last packet
+    float r1[8];
+    for (uint l = 0; l < PS; ++l) { acc[l] = pk[0][l]; r1[l] = pk[1][l]; }
+    const uint np2 = np / 2 * 2;
+    for (uint k = 2; k < np2; k += 2) { addp(acc, pk[k]); addp(r1, pk[k + 1]); }
+    addp(acc, r1);
+    if (np > np2) addp(acc, pk[np2]);
+  }
+  float s;
+  if (PS == 8) { float h[4]; for (uint l = 0; l < 4; ++l) h[l] = acc[l] + acc[l + 4]; s = predux4(h); }
+  else s = predux4(acc);
+  for (uint i = np * PS; i < n; ++i) { const float d = x[i] - y[i]; s += d * d; }
   return s;
 }
+static inline float sqdist_seq(const float* x, const float* y, uint n) { return sqdist(0, x, y, n); }
 
 template <class It, class Cmp>
 static inline void do_sort(int mode, It b, It e, Cmp c) {
@@ -120,6 +174,7 @@ struct Oracle {
   std::vector<uint32_t> codes;
   size_t curId;
   int sortMode;
+  int sumMode = 0;  // order of the squared-norm sums, see sqdist(); 0 = sequential (the parity definition)
   Ctx ctx;  // context used by the single-query entry points
 
   void initCtx(Ctx& c) const {
@@ -167,7 +222,7 @@ struct Oracle {
     for (uint i = 0; i < C1; ++i)
       for (uint j = i; j < C1; ++j)
         for (uint p = 0; p < LP; ++p) {
-          const float d = sqdist_seq(&cb1[(size_t)i * D + p * SS], &cb1[(size_t)j * D + p * SS], SS);
+          const float d = sqdist(sumMode, &cb1[(size_t)i * D + p * SS], &cb1[(size_t)j * D + p * SS], SS);
           coarse[((size_t)p * C1 + j) * C1 + i] = d;
           coarse[((size_t)p * C1 + i) * C1 + j] = d;
         }
@@ -176,7 +231,7 @@ struct Oracle {
   // ---- vectorquantizer.hpp:104-115 dist(): distances of a segment to the C2 centroids of one cell
   void vqDist(Ctx& c, uint p, uint c1, const float* seg) const {
     const float* cen = cb2ptr(p, c1);
-    for (uint k = 0; k < C2; ++k) { c.vqd[k] = sqdist_seq(seg, cen + (size_t)k * S, S); c.vqo[k] = k; }
+    for (uint k = 0; k < C2; ++k) { c.vqd[k] = sqdist(sumMode, seg, cen + (size_t)k * S, S); c.vqo[k] = k; }
   }
   // ---- vectorquantizer.hpp:83-102 id(): dist() + sort of the order array, returns the nearest
   // (the comparator's uint8_t parameters truncate the indices; harmless for C2 <= 256)
@@ -197,7 +252,7 @@ struct Oracle {
         float d = 0;
         for (uint pp = 0; pp < R; ++pp) {
           const uint lp = pp + p * R;
-          const float dd = sqdist_seq(vec + lp * SS, cen + lp * SS, SS);
+          const float dd = sqdist(sumMode, vec + lp * SS, cen + lp * SS, SS);
           c.L1virt[(size_t)lp * C1 + cc] = dd;
           d += dd;
         }
@@ -228,7 +283,7 @@ struct Oracle {
         float d = 0;
         for (uint pp = 0; pp < R; ++pp) {
           const uint lp = pp + p * R;
-          const float dd = sqdist_seq(vec + lp * SS, cen + lp * SS, SS);
+          const float dd = sqdist(sumMode, vec + lp * SS, cen + lp * SS, SS);
           c.L1virt[(size_t)lp * C1 + cc] = dd;
           d += dd;
         }
@@ -485,6 +540,8 @@ void* pqo_create(uint D, uint P, uint C1, uint C2, uint W, uint LP, unsigned lon
 }
 void pqo_destroy(void* h) { delete (Oracle*)h; }
 void pqo_set_sort_mode(void* h, int m) { ((Oracle*)h)->sortMode = m; }
+// sensitivity probe: order of the squared-norm sums (see sqdist); the coarse table is recomputed in the new order
+void pqo_set_sum_mode(void* h, int m) { Oracle* o = (Oracle*)h; o->sumMode = m; if (!o->cb1.empty()) o->computeLookupTable(); }
 unsigned long long pqo_max_multi_index(void* h) { return ((Oracle*)h)->maxMultiIndex; }
 unsigned long long pqo_heuristic_rows(void* h) { return ((Oracle*)h)->heurRows; }
 void pqo_get_heuristic(void* h, uint* out, unsigned long long rows) {

@@ -259,3 +259,25 @@ def test_converters_roundtrip(tmp_path):
     r = subprocess.run([os.path.join(host, "convert_fvecs"), "--fvecs", str(tmp_path / "b.fvecs"), "--umem", str(tmp_path / "b.umem")],
                        capture_output=True)
     assert r.returncode != 0
+
+
+def test_committed_dump_pair_reloads_into_the_oracle():
+    """tests/golden/dump_small.{tree,bins} (reference on-disk formats) re-loaded by the oracle's loadTree/loadBins reproduce
+    the committed candidate lists: guards the restatement (and the dump readers) against drift between machines/compilers."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    exp = np.load(os.path.join(g, "dump_small_expected.npz"))
+    D, P, C1, C2, W, LP = (int(v) for v in exp["cfg"])
+    bv, bb = (int(v) for v in exp["bv_bb"])
+    from oracle import Oracle
+    o = Oracle(D, P, C1, C2, W, LP, heur_keep=bb)
+    o.load_tree(os.path.join(g, "dump_small.tree"))
+    o.load_bins(os.path.join(g, "dump_small.bins"))
+    o.set_sort_mode(1)
+    off = 0
+    for i, q in enumerate(exp["queries"]):
+        ids, d = o.query(q, bv, bb)
+        n = int(exp["n_each"][i])
+        assert len(ids) == n
+        assert np.array_equal(ids, exp["ids"][off:off + n]) and np.array_equal(d.view(np.uint32), exp["dist"][off:off + n].view(np.uint32))
+        off += n
