@@ -85,7 +85,7 @@ struct pqt_index {
   uint32_t evMask[kRing][kMaxChunks]{};      // which events of a ring slot were recorded (an event record costs ~5 us of stream time)
   int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; bool noShape = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -444,6 +444,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true>, lTrav))) return rc;
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, true>, lTrav))) return rc;
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 1>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 1>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 2>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 2>, lTrav))) return rc;
   }
   // fused rerank+select (wave per query) whenever the result list fits the in-register selector
   bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
@@ -481,13 +485,18 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
                               idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
-                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 255u};
+                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 1u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
                                 else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
-      if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
+      const int shape = idx->noShape ? 0 : pqt_shape_of(d);  // the two BASELINE shapes run compile-time-shape instantiations
+      if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);
+                        else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave); }
+      else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);
+                             else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave); }
+      else if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
 #undef PQT_LAUNCH_TR
 #undef PQT_LAUNCH_TR1
       if (travWide) {
@@ -674,6 +683,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
+  if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }

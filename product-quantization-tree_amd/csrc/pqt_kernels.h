@@ -966,12 +966,27 @@ struct PqtTravArgs {
   float* segDOut; uint32_t* segBOut;    // [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over)
   uint32_t* ovList; uint32_t* ovCount;  // queries handed to pqt_k_bins (He > 512 and > 512 populated rows)
   const uint32_t* filter; uint32_t filterBits;  // presence bitmap over the bin keys, or null
-  uint32_t tdbg;  // debug/test bits: 1 = order all rows, not just the populated ones; 2/4/8 = ablations (wrong results)
+  uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
 };
 
 // the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
+// SHAPE: 0 = run-time shape; 1 / 2 = the two BASELINE shapes at compile time (1: d=128 p=4 c1=c2=32 w=2 lineparts=16 --
+// configs[0]/[1]; 2: d=128 p=4 c1=c2=64 w=1 lineparts=32 -- configs[2]/[3]).  With the trip counts known the compiler
+// unrolls the per-dimension loops and issues the centroid reads of a lane's accumulators together; with run-time SS it
+// emitted a remainder loop of one 4-byte load + s_waitcnt per dimension (cfg3 shape: 128 serialized round trips per
+// query in a1 alone, 56 k of the 228 k clocks of a traversal).
+template <int SHAPE> struct PqtShape { static constexpr uint32_t D = 0, P = 0, C1 = 0, C2 = 0, W = 0, LP = 0; };
+template <> struct PqtShape<1> { static constexpr uint32_t D = 128, P = 4, C1 = 32, C2 = 32, W = 2, LP = 16; };
+template <> struct PqtShape<2> { static constexpr uint32_t D = 128, P = 4, C1 = 64, C2 = 64, W = 1, LP = 32; };
+__host__ __device__ inline int pqt_shape_of(const PqtDevParams& d) {
+  if (d.D == 128 && d.P == 4 && d.C1 == 32 && d.C2 == 32 && d.W == 2 && d.LP == 16) return 1;
+  if (d.D == 128 && d.P == 4 && d.C1 == 64 && d.C2 == 64 && d.W == 1 && d.LP == 32) return 2;
+  return 0;
+}
+
 template <int WCR, bool SHARDED, bool P2 /* C1, C2, W, LP, D, S, SS, R all powers of two: shifts and masks instead of
-                                            runtime integer divisions (~25 VALU each) and quarter-rate multiplies */>
+                                            runtime integer divisions (~25 VALU each) and quarter-rate multiplies */,
+          int SHAPE = 0>
 __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const uint32_t q, unsigned char* const base, const uint32_t perWaveBytes) {
   const float* __restrict__ Q = A.Q; const float* __restrict__ cb1 = A.cb1; const float* __restrict__ cb2 = A.cb2;
   const float4* __restrict__ cb2T = A.cb2T; const PqtDevParams& prm = A.prm; const uint4* __restrict__ heur8 = A.heur8;
@@ -986,8 +1001,11 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   (void)lower; (void)candPos;
   const uint32_t forceFullOrder = tdbg & 1u;
 #define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
-  const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, W = prm.W, LP = prm.LP, S = prm.S, SS = prm.SS,
-                 R = prm.R, WC = prm.WC;
+  using SH = PqtShape<SHAPE>;
+  static_assert(SHAPE == 0 || (P2 && WCR == 1), "compile-time shapes are power-of-two shapes with W*C2 == 64");
+  const uint32_t D = SHAPE ? SH::D : prm.D, P = SHAPE ? SH::P : prm.P, C1 = SHAPE ? SH::C1 : prm.C1, C2 = SHAPE ? SH::C2 : prm.C2,
+                 W = SHAPE ? SH::W : prm.W, LP = SHAPE ? SH::LP : prm.LP, S = SHAPE ? SH::D / SH::P : prm.S,
+                 SS = SHAPE ? SH::D / SH::LP : prm.SS, R = SHAPE ? SH::LP / SH::P : prm.R, WC = SHAPE ? SH::W * SH::C2 : prm.WC;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t shC1 = P2 ? (uint32_t)__builtin_ctz(C1) : 0u, shC2 = P2 ? (uint32_t)__builtin_ctz(C2) : 0u, shLP = P2 ? (uint32_t)__builtin_ctz(LP) : 0u,
                  shWC = P2 ? (uint32_t)__builtin_ctz(WC) : 0u, shW = P2 ? (uint32_t)__builtin_ctz(W) : 0u, shD = P2 ? (uint32_t)__builtin_ctz(D) : 0u,
@@ -1016,16 +1034,31 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t t = t0 + 64 * u;
-      const uint32_t tt = t < C1 * LP ? t : t0;
+      constexpr bool kFull = SHAPE != 0;  // compile-time shapes: C1*LP is a multiple of 256, every t is in range
+      const uint32_t tt = (kFull || t < C1 * LP) ? t : t0;
       const uint32_t c = PQT_DIV(tt, LP, shLP), lp = PQT_MOD(tt, LP);
       const float* cen = cb1 + (size_t)PQT_MUL(c, D, shD) + PQT_MUL(lp, SS, shSS);
       const float* qq = sQ + PQT_MUL(lp, SS, shSS);
       float s = 0.f;
-      if (tdbg & 8u) { for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - (float)(c + d); s = s + df * df; } }
-      else
-      for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      if constexpr (SHAPE != 0) {
+        // SS = 4 or 8 dims = one or two 16-byte reads, requested for all 4 accumulators before the first is consumed
+        constexpr uint32_t V = SH::D / SH::LP / 4;
+        float4 cv[V];
+#pragma unroll
+        for (uint32_t v = 0; v < V; ++v) cv[v] = reinterpret_cast<const float4*>(cen)[v];
+#pragma unroll
+        for (uint32_t v = 0; v < V; ++v) {
+          const float4 qv = reinterpret_cast<const float4*>(qq)[v];
+          float df = qv.x - cv[v].x; s = s + df * df;
+          df = qv.y - cv[v].y; s = s + df * df;
+          df = qv.z - cv[v].z; s = s + df * df;
+          df = qv.w - cv[v].w; s = s + df * df;
+        }
+      } else {
+        for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      }
       acc[u] = s;
-      dst[u] = t < C1 * LP ? PQT_MUL(lp, C1, shC1) + c : 0xffffffffu;
+      dst[u] = (kFull || t < C1 * LP) ? PQT_MUL(lp, C1, shC1) + c : 0xffffffffu;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) if (dst[u] != 0xffffffffu) sVirt[dst[u]] = acc[u];
@@ -1075,7 +1108,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const uint32_t t = t0 + 64 * u;
-      const uint32_t tt = t < P * WC ? t : t0;
+      const uint32_t tt = (SHAPE != 0 || t < P * WC) ? t : t0;  // compile-time shapes: P*WC = 256, every t is in range
       const uint32_t p = PQT_DIV(tt, WC, shWC), pos = PQT_MOD(tt, WC), h1 = PQT_DIV(pos, C2, shC2), h2 = PQT_MOD(pos, C2);
       const uint32_t c1 = sOrd[PQT_MUL(p, W, shW) + h1];
       const float* qq = sQ + PQT_MUL(p, S, shS);
@@ -1093,7 +1126,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
           for (int e = 0; e < 8; ++e) {
             const uint32_t v = v0 + e;
             c[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < S / 4) c[e] = (tdbg & 4u) ? make_float4((float)v, (float)h2, (float)c1, 1.f) : cen4[PQT_MUL((size_t)v, C2, shC2)];
+            if (v < S / 4) c[e] = cen4[PQT_MUL((size_t)v, C2, shC2)];
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -1113,7 +1146,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       acc[u] = s;
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) if (t0 + 64 * u < P * WC) sD2[t0 + 64 * u] = acc[u];
+    for (int u = 0; u < 2; ++u) if (SHAPE != 0 || t0 + 64 * u < P * WC) sD2[t0 + 64 * u] = acc[u];
   }
   __builtin_amdgcn_wave_barrier();
   PQT_TS(3);
@@ -1208,9 +1241,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       const uint32_t h = hb + lane + 64 * r;
       uint32_t slot = 0;
       uint4 x = make_uint4(0, 0, 0, 0);
-      if (!((maybe >> r) & 1u)) { }
-      else if (!(tdbg & 2u)) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
-      else if ((glob[r] & 15u) == 0) x = make_uint4(glob[r], 15u, (glob[r] >> 4) & 0xffffu, 15u);
+      if ((maybe >> r) & 1u) x = pqt_table_lookup(table4, glob[r], tableBits, prm.tableSeed, &slot);
       recG[r] = h < He ? x.y : 0u;
       recL[r] = SHARDED ? slot : x.z;  // sharded: keep the slot, resolve the local fields after the cut
     }
@@ -1271,6 +1302,24 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; }
       PQT_TS(7);
+      uint32_t* const out = cand + (size_t)q * stride;
+      if (totCand >= 32u * m) {
+        // long bins (BASELINE configs[2]/[3]: hundreds of members each): the wave walks the listed bins and writes each
+        // one's consecutive store positions with coalesced stores -- no search (the per-candidate binary search below was
+        // 86 k of the 228 k clocks of a cfg3-shape traversal)
+        for (uint32_t b0 = 0; b0 < m; b0 += 64) {
+          const uint64_t mine = (b0 + lane < m) ? sBin[b0 + lane] : 0ull;
+          const uint32_t st = (uint32_t)mine, ls = (uint32_t)(mine >> 32);
+          const uint32_t nx = __shfl_down(st, 1, 64);
+          const uint32_t en = (b0 + lane + 1 < m) ? (lane < 63 ? nx : (uint32_t)sBin[b0 + 64]) : totCand;
+          const uint32_t nb = (m - b0 < 64u) ? m - b0 : 64u;
+          for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)b), l0 = (uint32_t)__builtin_amdgcn_readlane((int)ls, (int)b),
+                           e0 = (uint32_t)__builtin_amdgcn_readlane((int)en, (int)b);
+            for (uint32_t j = s0 + lane; j < e0; j += 64) out[j] = l0 + (j - s0);
+          }
+        }
+      } else
       for (uint32_t j = lane; j < totCand; j += 64) {
         uint32_t lo = 0, hi = m;  // last entry with start <= j
         while (hi - lo > 1) {
@@ -1278,7 +1327,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
           if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
         }
         const uint64_t b = sBin[lo];
-        cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
+        out[j] = (uint32_t)(b >> 32) + (j - (uint32_t)b);  // position in the bin-ordered line store
       }
     } else {
       // range shard: the cut above used the GLOBAL populations; now resolve what this device holds of the included bins
@@ -1312,6 +1361,22 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; }
       PQT_TS(7);
+      uint32_t* const out = cand + (size_t)q * stride;
+      uint32_t* const outP = candPos + (size_t)q * stride;
+      if (totLocal >= 32u * m) {  // long bins: walk the listed bins, coalesced stores, no search (see the unsharded branch)
+        for (uint32_t b0 = 0; b0 < m; b0 += 64) {
+          const uint64_t mine = (b0 + lane < m) ? sBin[b0 + lane] : 0ull;
+          const uint32_t st = (uint32_t)mine, ls = (uint32_t)(mine >> 32), gp = (b0 + lane < m) ? sGpos[b0 + lane] : 0u;
+          const uint32_t nx = __shfl_down(st, 1, 64);
+          const uint32_t en = (b0 + lane + 1 < m) ? (lane < 63 ? nx : (uint32_t)sBin[b0 + 64]) : totLocal;
+          const uint32_t nb = (m - b0 < 64u) ? m - b0 : 64u;
+          for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)b), l0 = (uint32_t)__builtin_amdgcn_readlane((int)ls, (int)b),
+                           e0 = (uint32_t)__builtin_amdgcn_readlane((int)en, (int)b), g0 = (uint32_t)__builtin_amdgcn_readlane((int)gp, (int)b);
+            for (uint32_t j = s0 + lane; j < e0; j += 64) { out[j] = l0 + (j - s0); outP[j] = g0 + (j - s0); }
+          }
+        }
+      } else
       for (uint32_t j = lane; j < totLocal; j += 64) {
         uint32_t lo = 0, hi = m;
         while (hi - lo > 1) {
@@ -1320,8 +1385,8 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         }
         const uint64_t b = sBin[lo];
         const uint32_t off = j - (uint32_t)b;
-        cand[(size_t)q * stride + j] = (uint32_t)(b >> 32) + off;
-        candPos[(size_t)q * stride + j] = sGpos[lo] + off;
+        out[j] = (uint32_t)(b >> 32) + off;
+        outP[j] = sGpos[lo] + off;
       }
     }
     return totNe;
@@ -1431,13 +1496,13 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
 #ifndef PQT_TR_WPS
 #define PQT_TR_WPS 5   // waves per SIMD the register allocator must leave room for
 #endif
-template <int NW, int WCR, bool SHARDED, bool P2>
+template <int NW, int WCR, bool SHARDED, bool P2, int SHAPE = 0>
 __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtTravArgs A /* kernel-argument segment: scalar loads */, uint32_t perWaveBytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t q = blockIdx.x * NW + wave;
   if (q >= A.qn) return;
-  pqt_traverse_query<WCR, SHARDED, P2>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
+  pqt_traverse_query<WCR, SHARDED, P2, SHAPE>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
 }
 
 // ---------------------------------------------------------------------------------------------------

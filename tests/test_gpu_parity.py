@@ -405,7 +405,7 @@ def test_small_scratch_budget_chunks_the_batch():
         idx.close()
 
 
-@pytest.mark.parametrize("name", ["tools_default", "ties", "cfg2_small"])
+@pytest.mark.parametrize("name", ["tools_default", "ties", "cfg2_small", "cfg3_small"])
 def test_schedule_and_ordering_variants_change_nothing(name):
     """A batch large enough that every wavefront slot of the fused rerank gets several queries (the balancing order and
     the LDS tickets are active): identical results with the schedule off, with all rows ordered in the traversal, and
@@ -423,14 +423,15 @@ def test_schedule_and_ordering_variants_change_nothing(name):
             assert np.array_equal(ref[0][r * n:(r + 1) * n], small[0]) and np.array_equal(bits(ref[1][r * n:(r + 1) * n]), bits(small[1]))
             assert np.array_equal(ref[2][r * n:(r + 1) * n], small[2])
         st_ref = idx.stats()
-        for opt in ("balance", "order_all_rows"):
-            idx.set_option(opt, 0 if opt == "balance" else 1)
+        # "static_shapes" 0: the run-time-shape traversal instead of the compile-time instantiation of the two BASELINE shapes
+        for opt in ("balance", "order_all_rows", "static_shapes"):
+            idx.set_option(opt, 1 if opt == "order_all_rows" else 0)
             got = idx.query(big_q, bv, bb, 50)
             assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
             st = idx.stats()
             for key in ("candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_final"):
                 assert st[key] == st_ref[key], key
-            idx.set_option(opt, 1 if opt == "balance" else 0)
+            idx.set_option(opt, 0 if opt == "order_all_rows" else 1)
     finally:
         idx.close()
 
