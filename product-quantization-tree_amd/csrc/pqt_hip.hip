@@ -64,6 +64,7 @@ struct pqt_index {
   // line codes (a7)
   uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
   uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
+  float* d_bias = nullptr; bool biasReady = false; bool adcBias = false;  // opt-in adc_bias mode: per-row query-independent part of the ADC sum
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
@@ -259,7 +260,8 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8};
+                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8,
+                        nullptr, 0, nullptr};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -301,6 +303,7 @@ int reorderLines(pqt_index* idx) {
   if (nbad) return fail(PQT_ERR_STATE, "bin members reference vector ids outside the line store [id_base, id_base + nvec)");
   if (idx->codesOwned && idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; idx->codesOwned = false; idx->linesDropped = true; }
   if (idx->d_codesGrp) { (void)hipFree(idx->d_codesGrp); idx->d_codesGrp = nullptr; idx->grpG = 0; }
+  idx->biasReady = false;
   idx->binOrdered = true;
   return PQT_OK;
 }
@@ -315,6 +318,36 @@ int ensureGroupMajor(pqt_index* idx, int G) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(idx->stream));
   idx->grpG = G;
+  return PQT_OK;
+}
+
+// opt-in adc_bias mode: bias[pos] of every row of the bin-ordered store (once per index / line store)
+int ensureBias(pqt_index* idx) {
+  if (idx->biasReady) return PQT_OK;
+  int rc;
+  if ((rc = devAlloc(&idx->d_bias, (size_t)idx->nIds))) return rc;
+  if (idx->nIds) hipLaunchKernelGGL(pqt_k_adc_bias, dim3((unsigned)((idx->nIds + 255) / 256)), dim3(256), 0, idx->stream, idx->d_codesBin, (uint64_t)idx->nIds,
+                                    idx->d_coarse, idx->dp, idx->d_bias);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  idx->biasReady = true;
+  return PQT_OK;
+}
+
+// fused rerank+select in adc_bias mode (pqt_rs_query MODE 1): no coarse table, group-major code words, NW wavefronts per workgroup
+template <int NW, int LPV, bool SH>
+int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
+                 uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  constexpr int UV = LPV >= 8 ? 2 : 4;
+  const uint32_t c1 = idx->dp.C1;
+  auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, 1> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, 1>
+                                                                                      : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, 1>;
+  int rc = allowLds(kern, lds);
+  if (rc) return rc;
+  PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+                  idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
+                  (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias};
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
 
@@ -454,7 +487,16 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
   const bool coarseLds = coarseBytes <= 64 * 1024;
   const size_t lFused = (coarseLds ? coarseBytes : 0) + (size_t)kFusedWaves * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
-  int wgG = (fused && !coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
+  // adc_bias mode: wave-per-query kernel without the coarse table; NW = 12 or 6 wavefronts around per-wave L1virt copies
+  const size_t lBias12 = (size_t)12 * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
+  const size_t lBias6 = (size_t)6 * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
+  const bool useBias = idx->adcBias && fused && k <= PQT_RS_BEST && lBias6 <= kMaxLds;
+  const int biasNW = lBias12 <= kMaxLds ? 12 : 6;
+  if (useBias) {
+    if ((rc = ensureGroupMajor(idx, 4))) return rc;
+    if ((rc = ensureBias(idx))) return rc;
+  }
+  int wgG = (fused && !useBias && !coarseLds && idx->useWgRerank) ? rswgGroup(d) : 0;
   if (wgG && (size_t)wgG * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8 > kMaxLds) wgG = 0;
   // a shape whose fused kernel does not fit the LDS (e.g. C1 = 256 with >= 16 line parts) runs the staged rerank/select,
   // which needs LP*C1*4 bytes only
@@ -539,8 +581,9 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     }
     // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query
-    const uint32_t rsGrid = std::min<uint32_t>((nq + kFusedWaves - 1) / kFusedWaves, (uint32_t)idx->numCUs);
-    idx->curDynamic = fused && !idx->noOrder && nq > rsGrid * (uint32_t)kFusedWaves;
+    const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
+    const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
+    idx->curDynamic = fused && !idx->noOrder && nq > rsGrid * rsNW;
     idx->curZero8 = nullptr;
     idx->lev0 = idx->lev1 = nullptr;
     if (leanEvents) {
@@ -552,7 +595,17 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (fused) {
       // a7 + a8 in one launch, one wavefront per query (distances stay on chip)
       const uint32_t grid = rsGrid;
-      if (wgG) {
+      if (useBias) {
+        idx->curZero8 = nextCtr;
+        nextZeroed = true;
+        const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
+        const uint32_t* nl = idx->d_nLocal + q0;
+#define PQT_LAUNCH_BIAS(NWV, LPVV) (idx->sharded ? launchRSBias<NWV, LPVV, true>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
+                                                 : launchRSBias<NWV, LPVV, false>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
+        rc = d.LP == 16 ? (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 4) : PQT_LAUNCH_BIAS(6, 4)) : (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 8) : PQT_LAUNCH_BIAS(6, 8));
+#undef PQT_LAUNCH_BIAS
+        if (rc) return rc;
+      } else if (wgG) {
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         rc = wgG == 4 ? launchRSWG<4>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
            : wgG == 2 ? launchRSWG<2>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
@@ -665,7 +718,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
-                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
+                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
@@ -683,6 +736,14 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (!idx || !name) return fail(PQT_ERR_INVALID, "null argument");
   if (strcmp(name, "fused") == 0) { idx->forceUnfused = (value == 0); return PQT_OK; }
   if (strcmp(name, "wg_rerank") == 0) { idx->useWgRerank = (value != 0); return PQT_OK; }
+  if (strcmp(name, "adc_bias") == 0) {
+    // opt-in: ADC distance as sum_p (b + l*(a-b)) + bias[row] (SURVEY App. C "E-alt"): same candidate sets, distances
+    // rounded differently from the reference's association (the default keeps the reference's)
+    if (value && !(idx->dp.LP == 16 || idx->dp.LP == 32)) return fail(PQT_ERR_LIMIT, "adc_bias needs 16 or 32 line parts");
+    if (value && (idx->dp.C1 & (idx->dp.C1 - 1))) return fail(PQT_ERR_LIMIT, "adc_bias needs a power-of-two C1");
+    idx->adcBias = (value != 0);
+    return PQT_OK;
+  }
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results

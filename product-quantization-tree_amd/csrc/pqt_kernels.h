@@ -655,6 +655,12 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #ifndef PQT_RS_PEND
 #define PQT_RS_PEND 384
 #endif
+#ifndef PQT_RS_QUAD
+#define PQT_RS_QUAD 0     // 1: 64-byte rows are fetched by the 4 lanes of a quad (one access per row) and transposed in registers.
+                          // Measured r02 (sift1m bench, parity suite green): rerank+select 0.156 -> 0.163 ms, the per-query wait for
+                          // rows unchanged (12.6 k clocks) -- the wait is the id -> row dependent round trips, not the number of L1
+                          // accesses per row -- so the variant stays off.
+#endif
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
 // arguments of the fused rerank + select (kernel-argument segment)
@@ -666,12 +672,22 @@ struct PqtRsArgs {
   unsigned long long* counters; uint32_t dbg; unsigned long long* tstamp;
   uint32_t dynamic;          // 1: workgroup-local dynamic schedule (several queries per wavefront), 0: static round-robin
   unsigned long long* zero8; // statistics block of the next call, zeroed here (saves a memset launch)
+  // opt-in "adc_bias" mode (MODE 1 of pqt_rs_query): group-major copy of the line store [LP/4][nIds] 16-byte pieces, rows in
+  // it, and the per-row query-independent part of the ADC sum
+  const uint4* codesGrp4; uint64_t nIds; const float* bias;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
 // sVirt: its LP*C1 floats (loaded here), cz: the coarse table (LDS copy at offset 0 of the dynamic LDS, or global).
 // qN / nN: the wavefront's next query; a count still unknown (0xffffffff) is fetched under the final select + sort.
-template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M>
+// MODE 0: the reference's association, term by term (bit-exact, the default).
+// MODE 1 ("adc_bias", opt-in, SURVEY App. C "E-alt"): extractDistance(a, b, c, l) = b + l*(a - b) - l*(1 - l)*c, and the
+//   last part does not depend on the query: bias[row] = sum_p (l*l*c - l*c) is computed once per index (pqt_k_adc_bias),
+//   a term is b + l*(a - b) -- two LDS look-ups into the query's L1virt, no coarse[LP][C1][C1] table at all -- and the
+//   distance is sum_p term_p + bias[row].  Same real number, different rounding: candidate SETS are untouched (they are
+//   fixed before this stage), distances differ from MODE 0 in the last bits, so the top-k can differ among near-equal
+//   distances.  The code words come from the group-major copy of the store (consecutive candidates = contiguous bytes).
+template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -757,11 +773,61 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
       }
       uint4 rows[U][LPV];
+      float rbias[U];
+      (void)rbias;
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) rows[u][v] = A.codesGrp4[(size_t)v * A.nIds + id[u]];
+          rbias[u] = A.bias[id[u]];
+        }
+      } else if constexpr (LPV == 4 && PQT_RS_QUAD) {
+        // 64-byte rows, ONE access per row: the 4 lanes of a quad read the 4 consecutive 16-byte pieces of one row per
+        // instruction (instruction i fetches the row of the quad's lane i), so a wave instruction touches 16 rows once
+        // instead of 64 rows a quarter each -- with one lane per row every row was requested four times, three of them
+        // hits on a line whose fill was still pending (r01: TCP_PENDING_STALL 49 % of cycles, 15.3 M L1 accesses for
+        // 2.67 M L2 requests).  A 4x4 transpose inside the quad (two butterfly steps of DPP quad_perm moves) then gives
+        // every lane the 4 pieces of its own row.
+        const uint32_t c = lane & 3u;
+        const bool odd = (c & 1u) != 0, hi2 = (c & 2u) != 0;
+        auto qbcast = [](uint32_t v, const int i) -> uint32_t {
+          return i == 0 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true) : i == 1 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true)
+               : i == 2 ? (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true) : (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true);
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t idi = qbcast(id[u], i);
+            rows[u][i] = reinterpret_cast<const uint4*>(codes + (size_t)idi * LP)[c];  // piece c of the row of quad lane i
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // T[c][i] = rows[u][i] at lane c  ->  want T[i][c].  Step A exchanges with lane^1 the elements with (i&1) != (c&1),
+          // step B with lane^2 those with (i>>1) != (c>>1).
+          auto xchg = [&](uint4& a, uint4& b, const bool upper, auto lx) {
+            // the lower lane of the pair keeps a and receives the partner's a into b; the upper lane keeps b and receives
+            // the partner's b into a
+            const uint4 send = upper ? a : b;
+            const uint4 recv = make_uint4(lx(send.x), lx(send.y), lx(send.z), lx(send.w));
+            if (upper) a = recv; else b = recv;
+          };
+          auto x1 = [](uint32_t v) { return pqt_lane_xor_u32<1>(v); };
+          auto x2 = [](uint32_t v) { return pqt_lane_xor_u32<2>(v); };
+          xchg(rows[u][0], rows[u][1], odd, x1);
+          xchg(rows[u][2], rows[u][3], odd, x1);
+          xchg(rows[u][0], rows[u][2], hi2, x2);
+          xchg(rows[u][1], rows[u][3], hi2, x2);
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)id[u] * LP);
 #pragma unroll
         for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
+      }
       }
       if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
 #pragma unroll
@@ -784,7 +850,13 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
             const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
             float sb, sa, sc;
-            if constexpr (C1M >= 2 && COARSE_LDS) {
+            if constexpr (MODE == 1) {
+              const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+              sb = sVirt[pv + A];
+              sa = sVirt[pv + B];
+              acc = acc + (sb + lam * (sa - sb));
+              continue;
+            } else if constexpr (C1M >= 2 && COARSE_LDS) {
               // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
               // the part offsets go into the instructions' immediate fields
               const uint32_t B4 = B << 2;
@@ -800,6 +872,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             acc = acc + pqt_extract_distance(sa, sb, sc, lam);
           }
         }
+        if constexpr (MODE == 1) acc = acc + rbias[u];
         // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
         const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
         const bool pass = valid && key < tau;
@@ -849,7 +922,8 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   }
 }
 
-template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */>
+template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
+          int MODE = 0>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A) {
   const float* __restrict__ coarse = A.coarse; const uint32_t* __restrict__ nLocal = A.nLocal; const uint32_t qn = A.qn;
   const PqtDevParams& prm = A.prm; const uint32_t dbg = A.dbg; const uint32_t dynamic = A.dynamic; unsigned long long* __restrict__ zero8 = A.zero8;
@@ -932,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
     // the next query is chosen now; a count that is not in the LDS list is fetched under the final select + sort below
     uint32_t nN = 0;
     const uint32_t qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M>(A, q, n, sKeys, sVirt, cz, qN, nN, slot);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE>(A, q, n, sKeys, sVirt, cz, qN, nN, slot);
     q = qN;
     n = nN;
   }
@@ -1863,6 +1937,24 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
   }
 }
 
+
+// opt-in "adc_bias" mode: bias[pos] = sum_p (l*l*c - l*c), c = coarse[p][A][B], of the row at position pos of the
+// bin-ordered store, summed in p order (f32, separate multiply and add).  lane = one row.
+__global__ __launch_bounds__(256) void pqt_k_adc_bias(const uint32_t* __restrict__ codesBin, uint64_t nIds, const float* __restrict__ coarse,
+                                                       PqtDevParams prm, float* __restrict__ bias) {
+  const uint64_t pos = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= nIds) return;
+  const uint32_t* row = codesBin + pos * prm.LP;
+  float s = 0.f;
+  for (uint32_t p = 0; p < prm.LP; ++p) {
+    const uint32_t w = row[p];
+    const uint32_t A = w & 0xffu, B = (w >> 8) & 0xffu;
+    const float l = pqt_lambda_decode(w >> 16);
+    const float c = coarse[((size_t)p * prm.C1 + A) * prm.C1 + B];
+    s = s + (l * l * c - l * c);
+  }
+  bias[pos] = s;
+}
 
 // group-major copy of the bin-ordered line store for pqt_k_rerank_select_wg: out[g][pos][x] = in[pos][g*G + x]
 __global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restrict__ in, uint64_t nIds, uint32_t LP, uint32_t G,

@@ -579,3 +579,64 @@ def test_improving_candidates_fill_the_pending_buffer(LP):
     finally:
         o.set_sort_mode(0)
         idx.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "big_coarse"])
+def test_adc_bias_mode_same_sets_distances_by_its_own_formula(name):
+    """Opt-in pqt_index_set_option("adc_bias", 1) (SURVEY App. C "E-alt"): distance = sum_p (b + l*(a-b)) + bias[row] with
+    bias[row] = sum_p (l*l*c - l*c) precomputed per database row.  Contract: candidate SETS (counts, membership) identical to the
+    default mode; the distances are bit-identical to a numpy f32 restatement of that formula on the oracle's candidates
+    and agree with the reference-association distances to f32 rounding; the top-k differs from the default only among
+    near-equal distances."""
+    f = fixture(name)
+    bv, bb = BV_BB[name]
+    k = 100
+    o = f.oracle
+    coarse = o.coarse()
+    idx = f.hip_index()
+    try:
+        ex_ids, ex_d, ex_c = idx.query(f.queries, bv, bb, k)
+        idx.set_option("adc_bias", 1)
+        ids, dist, cnt = idx.query(f.queries, bv, bb, k)
+        assert np.array_equal(cnt, ex_c)
+        o.set_sort_mode(1)
+        overlap = []
+        for qi, q in enumerate(f.queries):
+            u_ids, u_d = o.query_unsorted(q, bv, bb)
+            n = len(u_ids)
+            assert int(cnt[qi]) == n
+            if n == 0:
+                continue
+            virt = o.stage_l1(q)[0].reshape(o.LP, o.C1)
+            w = f.codes[u_ids]  # [n][LP]
+            A, B = (w & 0xff).astype(np.int64), ((w >> 8) & 0xff).astype(np.int64)
+            lam = (w >> 16).astype(np.float32) * np.float32(8.0 / 65536.0) - np.float32(4.0)
+            acc = np.zeros(n, np.float32)
+            bias = np.zeros(n, np.float32)
+            for p in range(o.LP):
+                sb, sa = virt[p, A[:, p]], virt[p, B[:, p]]
+                l = lam[:, p]
+                acc = acc + (sb + l * (sa - sb))
+                c = coarse[p, A[:, p], B[:, p]]
+                bias = bias + (l * l * c - l * c)
+            d = acc + bias
+            assert np.allclose(d, u_d, rtol=2e-5, atol=2e-2), "bias-mode distances drifted from the reference association"
+            order = np.lexsort((np.arange(n), d))[:k]
+            kk = len(order)
+            assert np.array_equal(bits(dist[qi, :kk]), bits(d[order])), qi
+            assert np.array_equal(ids[qi, :kk], u_ids[order]), qi
+            assert np.all(ids[qi, kk:] == 0xffffffff)
+            from collections import Counter  # multisets: an aliased (wrapped) bin is visited twice and repeats its ids
+            overlap.append(sum((Counter(ids[qi, :kk].tolist()) & Counter(ex_ids[qi, :kk].tolist())).values()) / kk)
+            # an id that left the top-k sits within rounding distance of the k-th
+            kth = float(ex_d[qi, kk - 1])
+            exact_of = dict(zip(u_ids.tolist(), u_d.tolist()))
+            for v in ids[qi, :kk].tolist():
+                assert exact_of[v] <= kth * (1 + 1e-4) + 1e-2
+        assert np.mean(overlap) > 0.98
+        idx.set_option("adc_bias", 0)
+        ids2, dist2, _ = idx.query(f.queries, bv, bb, k)
+        assert np.array_equal(ids2, ex_ids) and np.array_equal(bits(dist2), bits(ex_d))
+    finally:
+        o.set_sort_mode(0)
+        idx.close()
