@@ -593,9 +593,14 @@ def main():
             leg, _, _ = side_leg(4096, 4096, k)
             leg["launch_structure"] = "fused traversal in wide mode (boundBins > 512: rows in blocks of 512, populated rows listed) + fused rerank/select"
             out["config"]["knobs_4096_4096"] = leg
-            if os.environ.get("PQT_BENCH_K4096"):
-                leg, _, _ = side_leg(4096, 4096, 4096, reps=3)  # the reference front-end's own call: queryKNN(..., 4096) (tool_query.cpp:155)
-                out["config"]["knobs_4096_4096_k4096"] = leg
+            leg, _, _ = side_leg(4096, 4096, 4096, reps=3)  # the reference front-end's own call: queryKNN(..., 4096) (tool_query.cpp:155)
+            leg["launch_structure"] = "fused traversal (wide mode) + workgroup-per-query fused rerank/select for 128 < k <= 4096 (distances stay on chip)"
+            out["config"]["knobs_4096_4096_k4096"] = leg
+            idx.set_option("fused", 0)
+            leg, _, _ = side_leg(4096, 4096, 4096, reps=3)
+            idx.set_option("fused", 1)
+            leg["launch_structure"] = "staged kernels (tables, bins, rerank -> candDist in HBM, select)"
+            out["config"]["knobs_4096_4096_k4096_staged"] = leg
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)  # restore the headline outputs
             torch.cuda.synchronize(dev)
         except Exception as e:

@@ -501,12 +501,19 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   // a shape whose fused kernel does not fit the LDS (e.g. C1 = 256 with >= 16 line parts) runs the staged rerank/select,
   // which needs LP*C1*4 bytes only
   if (fused && !wgG && lFused > kMaxLds) fused = false;
+  // 128 < k <= 4096 (queryKNN(.., 4096) of the reference front-end): workgroup-per-query fused rerank+select, distances on chip
+  const uint32_t kcap = std::max<uint32_t>(2 * kP2, 1024);
+  const size_t lBigBase = (size_t)d.LP * d.C1 * 4 + (size_t)kcap * 8 + 256 * 4 + 4 * 8 + 16;
+  bool bigK = !idx->forceUnfused && !fullSort && k > PQT_RS_BEST && (d.LP * d.C1) % 4 == 0 && kcap <= 8192;
+  const bool bigCL = coarseLds && coarseBytes + lBigBase <= kMaxLds;
+  if (bigK && !bigCL && lBigBase > kMaxLds) bigK = false;
+  const size_t lBig = lBigBase + (bigCL ? coarseBytes : 0);
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
   idx->calls++;
   // the two fused launches are bracketed by three events; the staged path keeps one event per stage
-  const bool leanEvents = travFused && fused;
+  const bool leanEvents = travFused && (fused || bigK);
 #define PQT_REC(e) do { HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][e], st)); idx->evMask[idx->ringPos][c] |= 1u << (e); } while (0)
   for (int c = 0; c < nChunks; ++c) {
     const uint32_t q0 = (uint32_t)c * qChunk;
@@ -618,6 +625,24 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                                      stride, k, nq, oI, oD, oP))) return rc;
       }
       if (!leanEvents) PQT_REC(EV_RERANK);
+    } else if (bigK) {
+      const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
+#define PQT_LAUNCH_BIG(CL, SH, VEC)                                                                                         \
+      do { auto kern = pqt_k_rerank_select_big<CL, SH, VEC>;                                                                 \
+           if ((rc = allowLds(kern, lBig))) return rc;                                                                       \
+           const uint32_t wgPerCu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, kMaxLds / lBig));                              \
+           hipExtLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)idx->numCUs * wgPerCu)), dim3(PQT_RSB_NT), (uint32_t)lBig, st, idx->lev0, idx->lev1, 0u, \
+                                 idx->d_codesBin, idx->d_ids, v, idx->d_coarse, idx->d_cand, idx->d_candPos, idx->d_nLocal + q0, stride, k, kP2, kcap, nq, d, \
+                                 oI, oD, oP, idx->ctr); } while (0)
+      if (d.LP % 4 == 0) {
+        if (bigCL) { if (idx->sharded) PQT_LAUNCH_BIG(true, true, 4); else PQT_LAUNCH_BIG(true, false, 4); }
+        else { if (idx->sharded) PQT_LAUNCH_BIG(false, true, 4); else PQT_LAUNCH_BIG(false, false, 4); }
+      } else {
+        if (bigCL) { if (idx->sharded) PQT_LAUNCH_BIG(true, true, 1); else PQT_LAUNCH_BIG(true, false, 1); }
+        else { if (idx->sharded) PQT_LAUNCH_BIG(false, true, 1); else PQT_LAUNCH_BIG(false, false, 1); }
+      }
+#undef PQT_LAUNCH_BIG
+      if (!leanEvents) PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)
       hipLaunchKernelGGL(pqt_k_rerank<4>, dim3(nq), dim3(PQT_BLOCK), lRer, st, idx->d_codesBin,
@@ -653,7 +678,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
-  idx->lastDistKept = !fused;                 // the fused rerank never writes candDist
+  idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
 }

@@ -1938,6 +1938,178 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
 }
 
 
+// ===================================================================================================
+// Fused stage a7 + a8 for 128 < k <= 4096 (the reference front-end's own call is queryKNN(.., 4096): tool_query.cpp:155,
+// PerturbationProTree.cu:8187-8218): one WORKGROUP (8 wavefronts) per query, the distances never leave the chip.
+//   lane = one candidate (reference association, p ascending: bit-exact like pqt_rs_query); a key (f32 key << 32 | visiting
+//   position) that beats tau is appended to ONE key array in LDS (capacity kcap >= 2k); when the array could overflow, an
+//   exact block-wide radix select (range-adaptive 8-bit digits over the unique u64 keys, as pqt_wave_kth_u64) finds the k-th
+//   key, the array is compacted to the k smallest and tau drops to it; at the end the <= k survivors are sorted by the block
+//   bitonic network in LDS.  Replaces the staged pqt_k_rerank -> candDist in HBM -> pqt_k_select pair for these k.
+// LDS: [coarse LP*C1*C1*4 when it fits] + LP*C1*4 + kcap*8 + 1088 bytes.
+// ===================================================================================================
+#define PQT_RSB_NT 512
+template <int NT>
+__device__ __forceinline__ uint64_t pqt_block_kth_u64(const uint64_t* keys, uint32_t cnt, uint32_t kth, uint32_t* hist /*256*/,
+                                                       unsigned long long* slot /*4, 8-byte aligned*/) {
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) { slot[0] = ~0ull; slot[1] = 0; }
+  __syncthreads();
+  uint64_t mn = ~0ull, mx = 0;
+  for (uint32_t i = tid; i < cnt; i += NT) { const uint64_t v = keys[i]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+  if (mn != ~0ull || mx != 0) { atomicMin(&slot[0], (unsigned long long)mn); atomicMax(&slot[1], (unsigned long long)mx); }
+  __syncthreads();
+  uint64_t lo = slot[0], hi = slot[1];
+  uint64_t tau = lo;
+  for (int pass = 0; pass < 9; ++pass) {
+    const uint64_t range = hi - lo;
+    if (range == 0) { tau = lo; break; }
+    const int msb = 63 - __builtin_clzll(range);
+    const uint32_t sh = msb > 7 ? (uint32_t)(msb - 7) : 0u;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += NT) {
+      const uint64_t v = keys[i];
+      if (v >= lo && v <= hi) atomicAdd(&hist[(uint32_t)((v - lo) >> sh)], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // wavefront 0: 4 counters per lane + one wave scan, as in pqt_wave_kth_u64
+      const uint4 h = reinterpret_cast<const uint4*>(hist)[tid];
+      const uint32_t sum = h.x + h.y + h.z + h.w;
+      const uint32_t incl = pqt_wave_incl_scan(sum);
+      uint32_t before = incl - sum;
+      if (before < kth && kth <= incl) {
+        uint32_t b = tid * 4, m = h.x;
+        if (before + h.x < kth) { before += h.x; b += 1; m = h.y;
+          if (before + h.y < kth) { before += h.y; b += 1; m = h.z;
+            if (before + h.z < kth) { before += h.z; b += 1; m = h.w; } } }
+        slot[2] = ((unsigned long long)b << 32) | m;
+        slot[3] = before;
+      }
+    }
+    __syncthreads();
+    const uint32_t b = (uint32_t)(slot[2] >> 32), m = (uint32_t)slot[2];
+    kth -= (uint32_t)slot[3];
+    lo = lo + ((uint64_t)b << sh);
+    const uint64_t top = lo + ((1ull << sh) - 1ull);
+    hi = top < hi ? top : hi;
+    __syncthreads();
+    if (m == 1) {
+      for (uint32_t i = tid; i < cnt; i += NT) { const uint64_t v = keys[i]; if (v >= lo && v <= hi) slot[2] = v; }
+      __syncthreads();
+      tau = slot[2];
+      break;
+    }
+  }
+  __syncthreads();
+  return tau;
+}
+
+template <bool COARSE_LDS, bool SHARDED, int VEC /* 4: 16-byte code reads (LP % 4 == 0), 1: scalar */>
+__global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
+    const uint32_t* __restrict__ codes /* bin-ordered */, const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
+    const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
+    const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t kP2, uint32_t kcap, uint32_t nq, PqtDevParams prm,
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos, unsigned long long* __restrict__ counters) {
+  constexpr int NT = PQT_RSB_NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t C1 = prm.C1, LP = prm.LP;
+  const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
+  float* sCoarse = (float*)smem_raw;
+  float* sVirt = sCoarse + nCoarse;
+  uint64_t* sKeys = (uint64_t*)(sVirt + LP * C1);  // LP*C1 is even for every accepted shape (8-byte alignment)
+  uint32_t* sHist = (uint32_t*)(sKeys + kcap);
+  unsigned long long* sSlot = (unsigned long long*)(sHist + 256);
+  uint32_t* sCnt = (uint32_t*)(sSlot + 4);
+  const uint32_t tid = threadIdx.x;
+  (void)kP2;
+  // persistent workgroups: the LDS copy of the coarse table is loaded once and serves every query of this workgroup
+  if (COARSE_LDS) for (uint32_t t = tid; t < nCoarse; t += NT) sCoarse[t] = coarse[t];
+  const float* cz = COARSE_LDS ? sCoarse : coarse;
+  for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+  const uint32_t n = nLocal[q];
+  const uint32_t* cid = cand + (size_t)q * stride;
+  __syncthreads();  // the previous query's readers of sVirt / sKeys are done
+  for (uint32_t t = tid; t < LP * C1; t += NT) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
+  if (tid == 0) { sCnt[0] = 0; sCnt[1] = 0; }
+  __syncthreads();
+  uint64_t tau = ~0ull;
+  // keep the k smallest of the sCnt[0] keys held, tau = the k-th (block-wide, exact)
+  auto shrink = [&]() {
+    const uint32_t cnt = sCnt[0];
+    tau = pqt_block_kth_u64<NT>(sKeys, cnt, k, sHist, sSlot);
+    constexpr int PER = 16;  // kcap <= 8192 = NT * 16
+    uint64_t mine[PER];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { const uint32_t i = tid + NT * r; mine[r] = i < cnt ? sKeys[i] : ~0ull; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PER; ++r) if (mine[r] <= tau) sKeys[atomicAdd(&sCnt[1], 1u)] = mine[r];
+    __syncthreads();
+    if (tid == 0) { sCnt[0] = sCnt[1]; sCnt[1] = 0; }
+    __syncthreads();
+  };
+  for (uint32_t base = 0; base < n; base += NT) {
+    const uint32_t j = base + tid;
+    if (j < n) {
+      const uint32_t pos = cid[j];
+      const uint32_t* row = codes + (size_t)pos * LP;
+      float acc = 0.f;
+      if (VEC == 4) {
+        const uint4* row4 = reinterpret_cast<const uint4*>(row);
+        for (uint32_t p4 = 0; p4 < LP / 4; ++p4) {
+          const uint4 v = row4[p4];
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t p = p4 * 4 + u;
+            const uint32_t A = w[u] & 0xffu, B = (w[u] >> 8) & 0xffu;
+            const float lam = pqt_lambda_decode(w[u] >> 16);
+            acc = acc + pqt_extract_distance(sVirt[p * C1 + B], sVirt[p * C1 + A], cz[((size_t)p * C1 + A) * C1 + B], lam);
+          }
+        }
+      } else {
+        for (uint32_t p = 0; p < LP; ++p) {
+          const uint32_t w = row[p];
+          const uint32_t A = w & 0xffu, B = (w >> 8) & 0xffu;
+          const float lam = pqt_lambda_decode(w >> 16);
+          acc = acc + pqt_extract_distance(sVirt[p * C1 + B], sVirt[p * C1 + A], cz[((size_t)p * C1 + A) * C1 + B], lam);
+        }
+      }
+      const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
+      if (key < tau) sKeys[atomicAdd(&sCnt[0], 1u)] = key;
+    }
+    __syncthreads();
+    if (sCnt[0] + NT > kcap) shrink();  // uniform: sCnt[0] is read after the barrier by every thread
+  }
+  if (sCnt[0] > k) shrink();
+  const uint32_t have = sCnt[0];
+  uint32_t sortN = 2;  // the network runs over the keys really held (lists are often far shorter than k)
+  while (sortN < have) sortN <<= 1;
+  for (uint32_t i = have + tid; i < sortN; i += NT) sKeys[i] = ~0ull;
+  __syncthreads();
+  pqt_bitonic_sort_u64<NT>(sKeys, sortN);
+  const uint32_t kk = n < k ? n : k;
+  uint32_t ties = 0;
+  for (uint32_t i = tid; i < k; i += NT) {
+    const size_t o = (size_t)q * k + i;
+    if (i < kk) {
+      const uint64_t key = sKeys[i];
+      const uint32_t j = (uint32_t)key;
+      outIdx[o] = ids[cid[j]];
+      outDist[o] = pqt_key2f((uint32_t)(key >> 32));
+      if (SHARDED) outPos[o] = candPos[(size_t)q * stride + j];
+      if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
+    } else {
+      outIdx[o] = 0xffffffffu;
+      outDist[o] = __uint_as_float(0x7f800000u);
+      if (SHARDED) outPos[o] = 0xffffffffu;
+    }
+  }
+  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  }
+}
+
 // opt-in "adc_bias" mode: bias[pos] = sum_p (l*l*c - l*c), c = coarse[p][A][B], of the row at position pos of the
 // bin-ordered store, summed in p order (f32, separate multiply and add).  lane = one row.
 __global__ __launch_bounds__(256) void pqt_k_adc_bias(const uint32_t* __restrict__ codesBin, uint64_t nIds, const float* __restrict__ coarse,

@@ -127,7 +127,7 @@ def test_candidates_and_full_sorted_list(pair):
     assert st["candidates"] == total
 
 
-@pytest.mark.parametrize("k", [1, 10, 100, 1000])
+@pytest.mark.parametrize("k", [1, 10, 100, 129, 1000, 4096])
 def test_topk_select_path(pair, k):
     name, f, idx = pair
     Bv, Bb = BV_BB[name]
@@ -639,4 +639,36 @@ def test_adc_bias_mode_same_sets_distances_by_its_own_formula(name):
         assert np.array_equal(ids2, ex_ids) and np.array_equal(bits(dist2), bits(ex_d))
     finally:
         o.set_sort_mode(0)
+        idx.close()
+
+
+@pytest.mark.parametrize("k", [130, 300, 2048, 4096])
+def test_fused_big_k_select_shrinks_and_matches_oracle(k):
+    """128 < k <= 4096 (queryKNN(.., 4096) of the reference front-end): workgroup-per-query fused rerank+select.  A dense
+    database gives every query ~30 k candidates, i.e. several times the LDS key array (2*NP2(k) keys), so the exact
+    block-wide radix select + compaction runs repeatedly; the first candidates are also the worst ones for it when
+    distances decrease.  Results == oracle, and == the staged kernels."""
+    from common import Fixture
+
+    def uniform(n, D, seed):
+        return np.random.default_rng(seed).integers(0, 256, (n, D)).astype(np.float32)
+
+    f = Fixture(D=16, P=2, C1=8, C2=6, W=8, LP=4, n_base=30000, n_query=6, seed=92, heur_rows=2304, train=3000, data=uniform)
+    idx = f.hip_index()
+    try:
+        ids, dist, cnt = idx.query(f.queries, 10 ** 6, 2304, k)
+        assert int(cnt.min()) > 2 * 4096
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, 10 ** 6, 2304)
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(bits(dist[qi]), bits(s_d[:k])), (k, qi)
+                assert np.array_equal(ids[qi], s_ids[:k]), (k, qi)
+        finally:
+            f.oracle.set_sort_mode(0)
+        idx.set_option("fused", 0)
+        ids_s, dist_s, cnt_s = idx.query(f.queries, 10 ** 6, 2304, k)
+        assert np.array_equal(ids_s, ids) and np.array_equal(bits(dist_s), bits(dist)) and np.array_equal(cnt_s, cnt)
+    finally:
         idx.close()
