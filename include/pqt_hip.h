@@ -190,6 +190,18 @@ int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_ve
 int pqt_query_host(pqt_index* idx, const float* q_host, uint32_t qn, uint32_t bound_vectors,
                    uint32_t bound_bins, uint32_t k, uint32_t* out_idx_host, float* out_dist_host,
                    uint32_t* out_count_host);
+/* Oracle-parity entry: the reference's WHOLE sorted candidate list, treequantizer::query(boundVectors,
+ * boundBins, vec, out) (treequantizer.hpp:323-350) for a batch -- row q of out_idx_dev / out_dist_dev [QN][cap] holds the
+ * list of query q, out_count_dev[QN] (required) its true length; a list longer than `cap` is cut after its first cap
+ * entries (call again with a larger cap).  Device pointers. */
+int pqt_query_candidates(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins,
+                         uint32_t cap, uint32_t* out_idx_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                         void* hip_stream, int sync);
+/* replaces: PerturbationProTree::getDBIdx() / getLine() (PerturbationProTree.hh:99-103), which hand out the DEVICE arrays
+ * of the loaded database: ids_dev[n_local] = vector ids grouped by bin (the order the bins were handed over), and
+ * codes_bin_dev[n_local][LP] = the line codes in the same order (row i = code of ids_dev[i]).  Owned by the handle, valid
+ * until the bins / lines are replaced.  Each out pointer may be NULL. */
+int pqt_index_device_arrays(const pqt_index* idx, const uint32_t** ids_dev, const uint32_t** codes_bin_dev, uint64_t* n_local);
 /* Multi-GPU merge helper: out of `nshards` per-shard results (as gathered by an all-gather of pqt_query_shard
  * outputs) produce the global first-k per query.  Each of idx/dist/pos points at shard 0's [QN][k] block; the block of
  * shard s starts shard_stride 32-bit words later (0 = QN*k, i.e. [shard][QN][k]; 3*QN*k when the three arrays of a

@@ -46,7 +46,7 @@ EXPORTS = [
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
-    "pqt_merge_topk", "pqt_query_shard", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
+    "pqt_merge_topk", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
     "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle",
 ]
 
@@ -92,6 +92,9 @@ def lib():
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_query_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_query_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_index_device_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pqt_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.pqt_merge_topk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -206,6 +209,11 @@ class PqtIndex:
     def query_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_count=None, stream=None, sync=False):
         _chk(self.L.pqt_query(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
                               out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
+
+    def query_candidates_dev(self, q, Bv, Bb, cap, out_idx, out_dist, out_count, stream=None, sync=False):
+        """The reference's whole sorted candidate list per query (treequantizer::query output), cap entries per row."""
+        _chk(self.L.pqt_query_candidates(self.h, q.data_ptr(), q.shape[0], Bv, Bb, cap, out_idx.data_ptr(), out_dist.data_ptr(),
+                                         out_count.data_ptr(), stream, int(sync)))
 
     def query_shard_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_pos, out_count=None, stream=None, sync=False):
         _chk(self.L.pqt_query_shard(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),

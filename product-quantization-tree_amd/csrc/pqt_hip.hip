@@ -86,6 +86,8 @@ struct pqt_index {
   uint32_t evMask[kRing][kMaxChunks]{};      // which events of a ring slot were recorded (an event record costs ~5 us of stream time)
   int nChunks = 0; bool evCreated = false;
   size_t scratchBudget = (size_t)24 << 30;
+  // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
+  float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
   int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; bool noShape = false; uint32_t dbg = 0;
 };
 
@@ -744,7 +746,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1055,24 +1057,45 @@ int pqt_query_host(pqt_index* idx, const float* q, uint32_t qn, uint32_t Bv, uin
   if (!idx || !q || !outIdx || !outDist) return fail(PQT_ERR_INVALID, "null argument");
   int rc = setDevice(idx);
   if (rc) return rc;
-  float* dq = nullptr; uint32_t* dI = nullptr; float* dD = nullptr; uint32_t* dC = nullptr;
+  // staging buffers live in the handle and only grow: a caller looping over single vectors (treequantizer::query style)
+  // pays two copies per call, not four allocations
   const size_t nq = (size_t)qn * idx->dp.D, nk = (size_t)qn * k;
-  if ((rc = devAlloc(&dq, nq)) || (rc = devAlloc(&dI, nk)) || (rc = devAlloc(&dD, nk)) || (rc = devAlloc(&dC, (size_t)qn))) {
-    if (dq) (void)hipFree(dq); if (dI) (void)hipFree(dI); if (dD) (void)hipFree(dD); if (dC) (void)hipFree(dC);
-    return rc;
+  if (nq > idx->h2dQCap) { if ((rc = devAlloc(&idx->h2dQ, nq))) { idx->h2dQCap = 0; return rc; } idx->h2dQCap = nq; }
+  if (nk > idx->h2dKCap) {
+    idx->h2dKCap = 0;
+    if ((rc = devAlloc(&idx->h2dI, nk)) || (rc = devAlloc(&idx->h2dD, nk))) return rc;
+    idx->h2dKCap = nk;
   }
-  hipError_t e = hipMemcpy(dq, q, nq * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    rc = pqt_query(idx, dq, qn, Bv, Bb, k, dI, dD, dC, nullptr, 1);
-    if (rc == PQT_OK) {
-      e = hipMemcpy(outIdx, dI, nk * 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(outDist, dD, nk * 4, hipMemcpyDeviceToHost);
-      if (e == hipSuccess && outCount) e = hipMemcpy(outCount, dC, (size_t)qn * 4, hipMemcpyDeviceToHost);
+  if (qn > idx->h2dCCap) { if ((rc = devAlloc(&idx->h2dC, (size_t)qn))) { idx->h2dCCap = 0; return rc; } idx->h2dCCap = qn; }
+  HIPCHK(hipMemcpyAsync(idx->h2dQ, q, nq * 4, hipMemcpyHostToDevice, idx->stream));
+  if ((rc = pqt_query(idx, idx->h2dQ, qn, Bv, Bb, k, idx->h2dI, idx->h2dD, idx->h2dC, idx->stream, 0))) return rc;
+  HIPCHK(hipMemcpyAsync(outIdx, idx->h2dI, nk * 4, hipMemcpyDeviceToHost, idx->stream));
+  HIPCHK(hipMemcpyAsync(outDist, idx->h2dD, nk * 4, hipMemcpyDeviceToHost, idx->stream));
+  if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->h2dC, (size_t)qn * 4, hipMemcpyDeviceToHost, idx->stream));
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  return PQT_OK;
+}
+
+int pqt_query_candidates(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t cap, uint32_t* outIdx,
+                         float* outDist, uint32_t* outCount, void* stream, int sync) {
+  if (!outCount) return fail(PQT_ERR_INVALID, "pqt_query_candidates needs out_count_dev (a list longer than cap is truncated to its first cap entries)");
+  return pqt_query(idx, q_dev, qn, Bv, Bb, cap, outIdx, outDist, outCount, stream, sync);
+}
+
+int pqt_index_device_arrays(const pqt_index* idx, const uint32_t** ids_dev, const uint32_t** codes_bin_dev, uint64_t* n_local) {
+  if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  if (!idx->haveBins) return fail(PQT_ERR_STATE, "no bins loaded");
+  if (codes_bin_dev) {
+    if (!idx->binOrdered) {
+      if (!idx->d_codes) return fail(PQT_ERR_STATE, "no line codes loaded");
+      int rc = reorderLines(const_cast<pqt_index*>(idx));
+      if (rc) return rc;
     }
+    *codes_bin_dev = idx->d_codesBin;
   }
-  (void)hipFree(dq); (void)hipFree(dI); (void)hipFree(dD); (void)hipFree(dC);
-  if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
-  return rc;
+  if (ids_dev) *ids_dev = idx->d_ids;
+  if (n_local) *n_local = idx->nIds;
+  return PQT_OK;
 }
 
 int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const uint32_t* inIdx, const float* inDist,

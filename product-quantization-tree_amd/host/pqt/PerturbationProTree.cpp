@@ -21,10 +21,35 @@ void ProTree::prepareDistSequence(uint _rows) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
+      d_hashCounts(nullptr), d_hashSizeHeld(0), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
 
-PerturbationProTree::~PerturbationProTree() { if (d_idx) pqt_index_destroy(d_idx); }
+void PerturbationProTree::releaseDeviceScratch() {
+  if (d_resIdx) (void)hipFree(d_resIdx);
+  if (d_resDist) (void)hipFree(d_resDist);
+  if (d_hashPrefix) (void)hipFree(d_hashPrefix);
+  if (d_hashCounts) (void)hipFree(d_hashCounts);
+  d_resIdx = nullptr; d_resDist = nullptr; d_resCap = 0; d_hashPrefix = d_hashCounts = nullptr; d_hashSizeHeld = 0;
+}
+
+PerturbationProTree::~PerturbationProTree() {
+  (void)hipSetDevice(d_device);
+  releaseDeviceScratch();
+  if (d_idx) pqt_index_destroy(d_idx);
+}
+
+// result buffers of queryKNN live as long as the object and only grow (the reference allocates and frees all scratch per
+// batch, PerturbationProTree.cu:8201-8238,8315-8321 -- the overhead SURVEY App. C lists first)
+void PerturbationProTree::ensureResultBuffers(size_t _n) {
+  if (_n <= d_resCap) return;
+  if (d_resIdx) (void)hipFree(d_resIdx);
+  if (d_resDist) (void)hipFree(d_resDist);
+  d_resIdx = nullptr; d_resDist = nullptr; d_resCap = 0;
+  if (hipMalloc((void**)&d_resIdx, _n * 4) != hipSuccess || hipMalloc((void**)&d_resDist, _n * 4) != hipSuccess)
+    throw std::runtime_error("device allocation failed");
+  d_resCap = _n;
+}
 
 void PerturbationProTree::check(int rc, const char* what) {
   if (rc != PQT_OK) throw std::runtime_error(std::string(what) + ": " + pqt_last_error());
@@ -76,12 +101,17 @@ struct SplitKMeans {
 };
 }  // namespace
 
-void PerturbationProTree::createTree(uint _k, uint _k2, const float* _A, uint _N) {
+void PerturbationProTree::createTree(uint _k, uint _k2, const float* _Ain, uint _N, MemSpace _space) {
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
   const uint D = d_dim, P = d_p, S = D / P, C1 = _k, C2 = _k2;
   if (!C1 || (C1 & 1) || C1 > 256 || !C2 || (C2 > 1 && (C2 & 1)) || C2 > 256) throw std::runtime_error("createTree: cluster counts must be even (or C2 == 1) and <= 256");
-  DevBuf<float> dX((size_t)_N * D);
-  h2d(dX.p, _A, (size_t)_N * D * 4);
+  // the E step reads the vectors on the device, the sequential M step on the host: one copy in the missing direction
+  DevBuf<float> dX(_space == HOST_PTR ? (size_t)_N * D : 0);
+  std::vector<float> hostCopy;
+  const float* _A = _Ain;
+  if (_space == HOST_PTR) h2d(dX.p, _Ain, (size_t)_N * D * 4);
+  else { hostCopy.resize((size_t)_N * D); d2h(hostCopy.data(), _Ain, hostCopy.size() * 4); _A = hostCopy.data(); }
+  const float* const xDev = _space == HOST_PTR ? dX.p : _Ain;
   DevBuf<float> dCen((size_t)256 * std::max(S, 1u));
   DevBuf<uint32_t> dAsg(_N); DevBuf<float> dDist(_N); DevBuf<uint32_t> dRows(_N);
   std::vector<float> cb1((size_t)C1 * D, 0.f), cb2((size_t)P * C1 * C2 * S, 0.f);
@@ -114,7 +144,7 @@ void PerturbationProTree::createTree(uint _k, uint _k2, const float* _A, uint _N
       do {
         last = cur;
         for (uint p = 0; p < P; ++p) {
-          SplitKMeans km{d_device, dX.p, _A, D, S, p * S, {}, nullptr, _N};
+          SplitKMeans km{d_device, xDev, _A, D, S, p * S, {}, nullptr, _N};
           km.estep(cen[p], step, a[p], dd[p], dCen, dAsg, dDist);  // getAssignment (:40-66)
           // updateCentroids (:74-91): zero everything, sequential sums in vector order, divide non-empty
           std::fill(cen[p].begin(), cen[p].end(), 0.f);
@@ -141,7 +171,7 @@ void PerturbationProTree::createTree(uint _k, uint _k2, const float* _A, uint _N
   // ---- level 2: one vectorquantizer per (part, cell) on the segments grouped into that cell (treequantizer.hpp:163-172)
   for (uint p = 0; p < P; ++p)
     for (uint c = 0; c < C1; ++c) {
-      SplitKMeans km{d_device, dX.p, _A, D, S, p * S, {}, nullptr, 0};
+      SplitKMeans km{d_device, xDev, _A, D, S, p * S, {}, nullptr, 0};
       for (uint i = 0; i < _N; ++i) if (assign1[p][i] == c) km.rows.push_back(i);
       km.n = km.rows.size();
       h2d(dRows.p, km.rows.data(), km.n * 4);
@@ -239,6 +269,7 @@ void PerturbationProTree::setBins(size_t _nbins, const uint* _ids, const uint* _
   for (size_t b = 0; b < _nbins; ++b) n += _sizes[b];
   h_binIds.assign(_ids, _ids + _nbins); h_binSizes.assign(_sizes, _sizes + _nbins); h_members.assign(_members, _members + n);
   d_N = n;
+  d_hashSizeHeld = 0;  // the dense hashed getters are rebuilt on demand
   check(pqt_index_set_bins(handle(), _nbins, _ids, _sizes, _members), "pqt_index_set_bins");
 }
 
@@ -305,28 +336,132 @@ void PerturbationProTree::saveBins(const std::string& _name) {
   f.write((const char*)h_lines.data(), h_lines.size() * 4);
 }
 
-void PerturbationProTree::buildKBestDB(const float* _A, uint _N) {
+void PerturbationProTree::buildKBestDBChunk(const float* _A, uint _N, uint _idOffset, MemSpace _space) {
   pqt_index* h = handle();
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-  float* dA = nullptr; uint32_t* dBin = nullptr; uint32_t* dCodes = nullptr;
-  auto cleanup = [&]() { if (dA) (void)hipFree(dA); if (dBin) (void)hipFree(dBin); if (dCodes) (void)hipFree(dCodes); };
-  if (hipMalloc((void**)&dA, (size_t)_N * d_dim * 4) != hipSuccess || hipMalloc((void**)&dBin, (size_t)_N * 4) != hipSuccess ||
-      hipMalloc((void**)&dCodes, (size_t)_N * d_lineParts * 4) != hipSuccess) { cleanup(); throw std::runtime_error("device allocation failed"); }
-  std::vector<uint> bin(_N);
-  h_lines.resize((size_t)_N * d_lineParts);
-  bool ok = hipMemcpy(dA, _A, (size_t)_N * d_dim * 4, hipMemcpyHostToDevice) == hipSuccess;
-  int rc = ok ? pqt_build_assign_encode(h, dA, _N, dBin, dCodes, nullptr) : PQT_ERR_DEVICE;
-  ok = ok && rc == PQT_OK && hipMemcpy(bin.data(), dBin, (size_t)_N * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-       hipMemcpy(h_lines.data(), dCodes, h_lines.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
-  cleanup();
-  if (!ok) throw std::runtime_error(std::string("buildKBestDB failed: ") + pqt_last_error());
-  // bins in ascending id order, members in insertion (= id) order: exactly what the reference's std::map holds
+  if (h_binOfVec.size() < (size_t)_idOffset + _N) h_binOfVec.resize((size_t)_idOffset + _N, 0);
+  if (h_lines.size() < ((size_t)_idOffset + _N) * d_lineParts) h_lines.resize(((size_t)_idOffset + _N) * d_lineParts, lineDescr{0, 0, 0});
+  if (!_N) return;
+  DevBuf<float> dA(_space == HOST_PTR ? (size_t)_N * d_dim : 0);
+  DevBuf<uint32_t> dBin(_N), dCodes((size_t)_N * d_lineParts);
+  if (_space == HOST_PTR) h2d(dA.p, _A, (size_t)_N * d_dim * 4);
+  check(pqt_build_assign_encode(h, _space == HOST_PTR ? dA.p : _A, _N, dBin.p, dCodes.p, nullptr), "pqt_build_assign_encode");
+  d2h(h_binOfVec.data() + _idOffset, dBin.p, (size_t)_N * 4);
+  d2h(h_lines.data() + (size_t)_idOffset * d_lineParts, dCodes.p, (size_t)_N * d_lineParts * 4);
+}
+
+void PerturbationProTree::finishDB() {
+  pqt_index* h = handle();
+  const size_t n = h_binOfVec.size();
+  // bins in ascending id order, members in insertion (= id) order: exactly what the reference's std::map holds after
+  // insert() over the whole dataset (treequantizer.hpp:212-217), whatever the chunking was
   std::map<uint, std::vector<uint> > bins;
-  for (uint i = 0; i < _N; ++i) bins[bin[i]].push_back(i);
+  for (size_t i = 0; i < n; ++i) bins[h_binOfVec[i]].push_back((uint)i);
   std::vector<uint> ids, sizes, members;
+  members.reserve(n);
   for (auto& kv : bins) { ids.push_back(kv.first); sizes.push_back((uint)kv.second.size()); members.insert(members.end(), kv.second.begin(), kv.second.end()); }
   setBins(ids.size(), ids.data(), sizes.data(), members.data());
-  check(pqt_index_set_lines_host(h, reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
+  check(pqt_index_set_lines_host(h, reinterpret_cast<const uint32_t*>(h_lines.data()), n, 0), "pqt_index_set_lines_host");
+  h_binOfVec.clear();
+  h_binOfVec.shrink_to_fit();
+}
+
+void PerturbationProTree::buildKBestDB(const float* _A, uint _N, MemSpace _space) {
+  h_binOfVec.clear();
+  h_lines.clear();
+  buildKBestDBChunk(_A, _N, 0, _space);
+  finishDB();
+}
+
+// ---- the CUDA library's dump family --------------------------------------------------------------------------------
+void PerturbationProTree::exportHashed(uint _hashSize, std::vector<uint>& _prefix, std::vector<uint>& _counts, std::vector<uint>& _dbIdx) const {
+  if (!_hashSize) throw std::runtime_error("hash size must be > 0");
+  _prefix.assign(_hashSize, 0); _counts.assign(_hashSize, 0); _dbIdx.clear(); _dbIdx.reserve(d_N);
+  // slot = bin id % hashSize (PerturbationProTree.cu:3479-3484); bins sharing a slot are concatenated in ascending id order
+  std::vector<size_t> start(h_binIds.size()), order(h_binIds.size());
+  size_t o = 0;
+  for (size_t b = 0; b < h_binIds.size(); ++b) { start[b] = o; o += h_binSizes[b]; order[b] = b; }
+  std::sort(order.begin(), order.end(), [&](size_t l, size_t r) {
+    const uint sl = h_binIds[l] % _hashSize, sr = h_binIds[r] % _hashSize;
+    return sl != sr ? sl < sr : h_binIds[l] < h_binIds[r];
+  });
+  for (size_t b : order) {
+    const uint slot = h_binIds[b] % _hashSize;
+    if (_counts[slot] == 0) _prefix[slot] = (uint)_dbIdx.size();
+    _counts[slot] += h_binSizes[b];
+    _dbIdx.insert(_dbIdx.end(), h_members.begin() + start[b], h_members.begin() + start[b] + h_binSizes[b]);
+  }
+}
+
+namespace {
+void writeRaw(const std::string& name, const void* p, size_t bytes) {
+  std::ofstream f(name.c_str(), std::ofstream::out | std::ofstream::binary);
+  if (!f.good()) throw std::runtime_error("cannot open file " + name);
+  f.write((const char*)p, bytes);
+  if (!f.good()) throw std::runtime_error("write error in " + name);
+}
+void readRaw(const std::string& name, void* p, size_t bytes) {
+  std::ifstream f(name.c_str(), std::ifstream::in | std::ifstream::binary);
+  if (!f.good()) throw std::runtime_error("cannot open file " + name);
+  f.read((char*)p, bytes);
+  if (!f.good()) throw std::runtime_error("short read in " + name);
+}
+}  // namespace
+
+void PerturbationProTree::saveHashedDB(const std::string& _pre, uint _hashSize) {
+  if (h_binIds.empty() || h_lines.size() != d_N * d_lineParts) throw std::runtime_error("saveHashedDB: no exact bins / line codes held");
+  std::vector<uint> prefix, counts, dbIdx;
+  exportHashed(_hashSize, prefix, counts, dbIdx);
+  writeRaw(_pre + "_" + std::to_string(d_lineParts) + ".lines", h_lines.data(), h_lines.size() * 4);
+  writeRaw(_pre + ".prefix", prefix.data(), prefix.size() * 4);
+  writeRaw(_pre + ".count", counts.data(), counts.size() * 4);
+  writeRaw(_pre + ".dbIdx", dbIdx.data(), dbIdx.size() * 4);
+}
+
+void PerturbationProTree::loadHashedDB(const std::string& _pre, uint _N, uint _hashSize) {
+  std::vector<uint> prefix(_hashSize), counts(_hashSize), dbIdx(_N);
+  readRaw(_pre + ".prefix", prefix.data(), prefix.size() * 4);
+  readRaw(_pre + ".count", counts.data(), counts.size() * 4);
+  readRaw(_pre + ".dbIdx", dbIdx.data(), dbIdx.size() * 4);
+  std::vector<lineDescr> lines((size_t)_N * d_lineParts);
+  readRaw(_pre + "_" + std::to_string(d_lineParts) + ".lines", lines.data(), lines.size() * 4);
+  h_binIds.clear(); h_binSizes.clear(); h_members.clear();  // the exact bin ids are not recoverable from the hashed form
+  setDB(_N, prefix.data(), counts.data(), dbIdx.data(), _hashSize);
+  setLines(lines.data(), _N);
+}
+
+const uint* PerturbationProTree::getDBIdx() {
+  const uint32_t* ids = nullptr;
+  check(pqt_index_device_arrays(handle(), &ids, nullptr, nullptr), "pqt_index_device_arrays");
+  return ids;
+}
+
+const lineDescr* PerturbationProTree::getLine() {
+  const uint32_t* codes = nullptr;
+  check(pqt_index_device_arrays(handle(), nullptr, &codes, nullptr), "pqt_index_device_arrays");
+  return reinterpret_cast<const lineDescr*>(codes);
+}
+
+const uint* PerturbationProTree::getBinPrefix(uint _hashSize) {
+  if (d_hashSizeHeld != _hashSize) {
+    if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+    std::vector<uint> prefix, counts, dbIdx;
+    exportHashed(_hashSize, prefix, counts, dbIdx);
+    if (d_hashPrefix) (void)hipFree(d_hashPrefix);
+    if (d_hashCounts) (void)hipFree(d_hashCounts);
+    d_hashPrefix = d_hashCounts = nullptr; d_hashSizeHeld = 0;
+    if (hipMalloc((void**)&d_hashPrefix, (size_t)_hashSize * 4) != hipSuccess || hipMalloc((void**)&d_hashCounts, (size_t)_hashSize * 4) != hipSuccess)
+      throw std::runtime_error("device allocation failed");
+    h2d(d_hashPrefix, prefix.data(), (size_t)_hashSize * 4);
+    h2d(d_hashCounts, counts.data(), (size_t)_hashSize * 4);
+    d_hashSizeHeld = _hashSize;
+  }
+  return d_hashPrefix;
+}
+
+const uint* PerturbationProTree::getBinCounts(uint _hashSize) {
+  (void)getBinPrefix(_hashSize);
+  return d_hashCounts;
 }
 
 void PerturbationProTree::ensureHeuristic(uint rows) {
@@ -340,16 +475,10 @@ void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float
   _resDist.resize((size_t)_QN * _nVec);
   if (!_QN) return;
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-  uint32_t* dI = nullptr; float* dD = nullptr;
-  if (hipMalloc((void**)&dI, _resIdx.size() * 4) != hipSuccess || hipMalloc((void**)&dD, _resDist.size() * 4) != hipSuccess) {
-    if (dI) (void)hipFree(dI);
-    throw std::runtime_error("device allocation failed");
-  }
-  int rc = pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, dI, dD, nullptr, nullptr, 1);
-  bool ok = rc == PQT_OK && hipMemcpy(_resIdx.data(), dI, _resIdx.size() * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-            hipMemcpy(_resDist.data(), dD, _resDist.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
-  (void)hipFree(dI); (void)hipFree(dD);
-  if (!ok) throw std::runtime_error(std::string("queryKNN failed: ") + pqt_last_error());
+  ensureResultBuffers(_resIdx.size());
+  check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1), "queryKNN");
+  d2h(_resIdx.data(), d_resIdx, _resIdx.size() * 4);
+  d2h(_resDist.data(), d_resDist, _resDist.size() * 4);
 }
 
 void PerturbationProTree::queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,

@@ -22,6 +22,10 @@ typedef unsigned int uint;
 
 namespace pqt {
 
+/** where a vector array lives: the reference's createTree / buildKBestDB take DEVICE pointers (ProTree.hh:82,
+ *  PerturbationProTree.hh:53); the tools of this tree read files into host memory, so both are accepted */
+enum MemSpace { HOST_PTR = 0, DEVICE_PTR = 1 };
+
 /** 4-byte line code, layout of the reference's lineDescr (PerturbationProTree.hh:21-25) / code_t (helper.hpp:39-90) */
 typedef struct {
   unsigned char p1;
@@ -83,10 +87,10 @@ class PerturbationProTree : public ProTree {
   /** produces a two-layer product quantization tree with _k / _k2 centroids per level from _N training vectors
    *  (ProTree.hh:82 createTree; algorithm = cpu_version: productquantizer::generate productquantizer.hpp:131-158,
    *  vectorquantizer::generate vectorquantizer.hpp:117-146, treequantizer::generate treequantizer.hpp:155-177:
-   *  k-means by centroid splitting).  _A is a HOST pointer here.  The E step (nearest centroid of every vector) runs on
-   *  the GPU (pqt_kmeans_assign), the M step (sequential sums) on the host, so the result does not depend on any
-   *  parallel reduction order. */
-  void createTree(uint _k, uint _k2, const float* _A, uint _N);
+   *  k-means by centroid splitting).  _A: host pointer, or device pointer like the reference with _space = DEVICE_PTR.
+   *  The E step (nearest centroid of every vector) runs on the GPU (pqt_kmeans_assign), the M step (sequential sums) on
+   *  the host, so the result does not depend on any parallel reduction order. */
+  void createTree(uint _k, uint _k2, const float* _A, uint _N, MemSpace _space = HOST_PTR);
   /** set the tree from host arrays cb1[C1][dim], cb2[p][C1][C2][dim/p] */
   void setTree(uint _c1, uint _c2, const float* _cb1, const float* _cb2);
 
@@ -102,9 +106,15 @@ class PerturbationProTree : public ProTree {
   void setLines(const lineDescr* _lines, size_t _N);
   uint getLineParts() const { return d_lineParts; }
 
-  /** insert = id() + prepareReranking for _N host vectors (treequantizer.hpp:212-217; CUDA buildKBestDB + lineDist):
-   *  fills the bin store and the line store of this object */
-  void buildKBestDB(const float* _A /* host */, uint _N);
+  /** insert = id() + prepareReranking for _N vectors (treequantizer.hpp:212-217; CUDA buildKBestDB + lineDist):
+   *  fills the bin store and the line store of this object.  _A: host pointer, or device pointer like the reference
+   *  (PerturbationProTree.hh:53) with _space = DEVICE_PTR. */
+  void buildKBestDB(const float* _A, uint _N, MemSpace _space = HOST_PTR);
+  /** chunked build (test/test1B.cpp:783-871: per-chunk buildKBestDB + lineDist, then the host-side CSR merge): vectors
+   *  [_idOffset, _idOffset + _N) are assigned and line-encoded; finishDB() merges all chunks into one bin store (bins in
+   *  ascending id order, members in id order = what one insert() pass over the whole dataset produces) and uploads it. */
+  void buildKBestDBChunk(const float* _A, uint _N, uint _idOffset, MemSpace _space = HOST_PTR);
+  void finishDB();
   void lineDist(const float* /*_DB*/, uint /*_N*/) {}  // line codes are produced by buildKBestDB in one pass
 
   /** _Q is a DEVICE pointer (like the reference), results are resized to _QN*_nVec (PerturbationProTree.cu:8182-8183).
@@ -116,6 +126,24 @@ class PerturbationProTree : public ProTree {
   /** host-pointer variant of treequantizer::query for one vector: sorted (id, distance) pairs */
   void query(uint _boundVectors, uint _boundBins, const float* _vecHost, std::vector<std::pair<uint, float> >& _out);
 
+  /** the CUDA library's dump family (tool_createdb.cpp:111-138, test/test1B.cpp:865-892): dense hashed CSR
+   *  <pre>.prefix / <pre>.count (hashSize u32 each, slot = bin id % hashSize; bins that share a slot are concatenated in
+   *  ascending id order), <pre>.dbIdx (N u32) and <pre>_<lineparts>.lines (N x lineparts 4-byte lineDescr, vector-id
+   *  order).  This is the .bins <-> triple translation: saveHashedDB writes it from the exact bins held, loadHashedDB
+   *  reads it back through setDB (bins that shared a slot stay merged, exactly like in the CUDA library). */
+  void saveHashedDB(const std::string& _pre, uint _hashSize = 400000000u);
+  void loadHashedDB(const std::string& _pre, uint _N, uint _hashSize = 400000000u);
+  void exportHashed(uint _hashSize, std::vector<uint>& _prefix, std::vector<uint>& _counts, std::vector<uint>& _dbIdx) const;
+
+  /** DEVICE pointers like the reference's getters (PerturbationProTree.hh:97-103).  getDBIdx(): vector ids grouped by
+   *  bin; getLine(): the line codes in the same order (row i belongs to getDBIdx()[i]); getBinPrefix()/getBinCounts():
+   *  the dense hashed arrays of _hashSize entries, materialised on the first call (the engine itself keeps a compact
+   *  two-choice table of the non-empty bins instead of these 2 x 1.6 GB). */
+  const uint* getDBIdx();
+  const lineDescr* getLine();
+  const uint* getBinPrefix(uint _hashSize = 400000000u);
+  const uint* getBinCounts(uint _hashSize = 400000000u);
+
   uint getNPerturbations() const { return 1; }
   pqt_stats lastStats();
   const std::vector<uint>& binIds() const { return h_binIds; }
@@ -125,7 +153,14 @@ class PerturbationProTree : public ProTree {
   void ensureHeuristic(uint rows);
   void check(int rc, const char* what);
 
+  void ensureResultBuffers(size_t _n);
+  void releaseDeviceScratch();
+
   pqt_index* d_idx;
+  // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
+  uint* d_resIdx; float* d_resDist; size_t d_resCap;
+  uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;
+  std::vector<uint> h_binOfVec;  // chunked build: bin id of every vector seen so far
   int d_device;
   uint d_w, d_lineParts, d_boundVectors, d_boundBins, d_heurRows;
   std::vector<uint> h_binIds, h_binSizes, h_members;

@@ -2,7 +2,7 @@
 // cpu_version tools use treequantizer: loadTree -> loadBins -> query(boundVectors, boundBins, vec, out) per vector,
 // saveTree/saveBins round trip, and the batch entry queryKNN.  Driven by tests/test_gpu_tools.py, which compares the
 // dumped results with the oracle.
-//   usage: test_classes <dim> <p> <lineparts> <w> <tree> <bins> <queries.fmem-like raw f32 file> <nq> <bv> <bb> <out.bin>
+//   usage: test_classes <dim> <p> <lineparts> <w> <tree> <bins> <queries.fmem-like raw f32 file> <nq> <bv> <bb> <out.bin> [<base.raw> <n> <hashsize>]
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +54,38 @@ int main(int argc, char** argv) {
     (void)hipFree(qd);
     fo.write((const char*)ri.data(), ri.size() * 4);
     fo.write((const char*)rd.data(), rd.size() * 4);
+    // optional: <base.raw f32> <n> <hashsize> -- the device-pointer overloads and the reference's device getters
+    if (argc >= 15) {
+      const std::string bfile = argv[12];
+      const uint n = atoi(argv[13]), hs = atoi(argv[14]);
+      std::vector<float> base((size_t)n * dim);
+      std::ifstream fb(bfile.c_str(), std::ios::binary);
+      fb.read((char*)base.data(), base.size() * 4);
+      if (!fb.good()) throw std::runtime_error("cannot read base vectors");
+      float* bd = nullptr;
+      if (hipMalloc((void**)&bd, base.size() * 4) != hipSuccess || hipMemcpy(bd, base.data(), base.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("upload failed");
+      PerturbationProTree t2(dim, p, p);
+      t2.setW(w);
+      t2.prepareEmptyLambda(0, lp);
+      t2.loadTree(tree);
+      t2.buildKBestDB(bd, n, DEVICE_PTR);  // device pointer, like the reference (PerturbationProTree.hh:53)
+      (void)hipFree(bd);
+      t2.saveBins(out + ".devbuild.bins");
+      t2.saveHashedDB(out + ".h", hs);
+      // getters hand out DEVICE arrays (PerturbationProTree.hh:97-103)
+      std::vector<uint> dbidx(n), prefix(hs), counts(hs), codes((size_t)n * lp);
+      if (hipMemcpy(dbidx.data(), t2.getDBIdx(), (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(codes.data(), t2.getLine(), codes.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(prefix.data(), t2.getBinPrefix(hs), (size_t)hs * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(counts.data(), t2.getBinCounts(hs), (size_t)hs * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        throw std::runtime_error("getter read-back failed");
+      std::ofstream g((out + ".getters").c_str(), std::ios::binary);
+      g.write((const char*)dbidx.data(), dbidx.size() * 4);
+      g.write((const char*)codes.data(), codes.size() * 4);
+      g.write((const char*)prefix.data(), prefix.size() * 4);
+      g.write((const char*)counts.data(), counts.size() * 4);
+    }
     std::cout << "ok " << t.getNClusters() << " " << t.getClusters2() << std::endl;
   } catch (const std::exception& e) {
     std::cerr << "test_classes: " << e.what() << std::endl;

@@ -1,9 +1,11 @@
 // tool_createdb -- front-end kept from the reference (tool_createdb.cpp): same flags and output file names.
-//   <basename>_<dim>_<p>_<c1>_<c2>.ppqt            tree (must exist: training is an offline "next" row; the
-//                                                   reference's createTree trains on uninitialised memory)
-//   ..._<lineparts>.lines / .prefix / .count / .dbIdx   the CUDA library's dumps (hashed CSR, 4-byte line codes)
-//   ....bins                                        the cpu_version dump (exact bins + codes), readable by tool_query
-// The database build (insert = id() + prepareReranking) runs on the GPU through the C-ABI.
+//   <basename>_<dim>_<p>_<c1>_<c2>.ppqt            tree: read if present, else trained on the first --train vectors
+//   ....bins                                        the cpu_version dump (exact bins + line codes, treequantizer::saveBins)
+//   ..._<lineparts>.lines / .prefix / .count / .dbIdx   the CUDA library's dumps (dense hashed CSR of --hashsize slots +
+//                                                   4-byte line codes in vector-id order; tool_createdb.cpp:111-138),
+//                                                   written unless --hashed 0
+// The WHOLE dataset is processed, --chunksize vectors at a time (per-chunk assign + line-encode on the GPU through the C-ABI,
+// then one host-side CSR merge: test/test1B.cpp:783-871); the reference's tool stops after its first chunk.
 #include <stdio.h>
 #include <sys/stat.h>
 #include <fstream>
@@ -28,6 +30,7 @@ int main(int argc, char* argv[]) {
   F.def("basename", "tmp", "prefix for generated data");
   F.def("dataset", "base.umem", "path to vector dataset");
   F.def("w", "2", "first-level cells expanded per part (treequantizer W)");
+  F.def("hashed", "1", "also write the CUDA library's dump family (.prefix/.count/.dbIdx/.lines)");
   F.def("train", "0", "if > 0 and no codebook exists: createTree on the first <train> vectors (the reference trains on 20000, tool_createdb.cpp:76)");
   if (!F.parse(argc, argv)) return 1;
   try {
@@ -53,12 +56,22 @@ int main(int argc, char* argv[]) {
       ppt.readTreeFromFile(cb);
     }
     if (ppt.getNClusters() != c1 || ppt.getClusters2() != c2) { std::cerr << "codebook c1/c2 differ from flags" << std::endl; return 1; }
-    const size_t n = std::min<size_t>(reader.num(), (size_t)F.num("chunksize"));
-    std::vector<float> data = reader.data(n);
-    ppt.buildKBestDB(data.data(), (uint)n);
+    const size_t n = reader.num(), chunk = std::max<size_t>(1, (size_t)F.num("chunksize"));
+    size_t nchunks = 0;
+    for (size_t off = 0; off < n; off += chunk, ++nchunks) {
+      const size_t m = std::min(chunk, n - off);
+      std::vector<float> data = reader.data(m, off);
+      ppt.buildKBestDBChunk(data.data(), (uint)m, (uint)off);
+    }
+    ppt.finishDB();
     ppt.saveBins(pre + ".bins");
     std::cout << "written " << pre << ".bins" << std::endl;
-    std::cout << "vectors " << n << "  bins " << ppt.binIds().size() << std::endl;
+    if (F.num("hashed")) {
+      ppt.saveHashedDB(pre, (uint)F.num("hashsize"));
+      std::cout << "written " << pre << "_" << lp << ".lines" << std::endl << "written " << pre << ".prefix" << std::endl
+                << "written " << pre << ".count" << std::endl << "written " << pre << ".dbIdx" << std::endl;
+    }
+    std::cout << "vectors " << n << "  chunks " << nchunks << "  bins " << ppt.binIds().size() << std::endl;
   } catch (const std::exception& e) {
     std::cerr << "tool_createdb: " << e.what() << std::endl;
     return 1;

@@ -31,6 +31,7 @@ int main(int argc, char* argv[]) {
   F.def("w", "2", "first-level cells expanded per part");
   F.def("boundvectors", "20000", "query(boundVectors, .)");
   F.def("boundbins", "500", "query(., boundBins)");
+  F.def("hashed", "0", "1: load the CUDA library's dump family even when a .bins dump exists");
   F.def("nvec", "4096", "results per query (queryKNN _nVec)");
   if (!F.parse(argc, argv)) return 1;
   try {
@@ -49,8 +50,18 @@ int main(int argc, char* argv[]) {
     if (!file_exists(cb)) { std::cout << "you need to generate a codebook first. No codebook found in " << cb << std::endl; return 1; }
     std::cout << "codebook exists, reading from " << cb << std::endl;
     ppt.readTreeFromFile(cb);
-    ppt.loadBins(pre + ".bins");
-    std::cout << "read " << pre << ".bins" << std::endl;
+    // database: the cpu_version dump if present, else the CUDA library's dump family (tool_query.cpp:104-147)
+    if (file_exists(pre + ".bins") && !F.num("hashed")) {
+      ppt.loadBins(pre + ".bins");
+      std::cout << "read " << pre << ".bins" << std::endl;
+    } else {
+      struct stat sb;
+      if (stat((pre + ".dbIdx").c_str(), &sb) != 0) { std::cout << "no database dump found (" << pre << ".bins or .prefix/.count/.dbIdx/.lines)" << std::endl; return 1; }
+      const uint nbase = (uint)(sb.st_size / 4);
+      ppt.loadHashedDB(pre, nbase, (uint)F.num("hashsize"));
+      std::cout << "read " << pre << ".prefix" << std::endl << "read " << pre << ".count" << std::endl << "read " << pre << ".dbIdx" << std::endl
+                << "read " << pre << "_" << lp << ".lines" << std::endl;
+    }
     if (hipSetDevice((int)F.num("device")) != hipSuccess) { std::cerr << "no device" << std::endl; return 1; }
     float* qd = nullptr;
     if (hipMalloc((void**)&qd, qh.size() * 4) != hipSuccess || hipMemcpy(qd, qh.data(), qh.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {

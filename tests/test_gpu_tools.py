@@ -174,3 +174,94 @@ def test_committed_dump_pair_loads_and_reproduces_expected_lists(tmp_path):
         assert np.array_equal(pairs[:, 1], exp["dist"][off:off + n].view(np.uint32)), i
         assert np.array_equal(pairs[:, 0], exp["ids"][off:off + n]), i
         off += n
+
+
+def _hashed_from_bins(bin_ids, bin_sizes, members, hs):
+    """Python restatement of the .bins -> (.prefix, .count, .dbIdx) translation: slot = bin id % hashsize, bins sharing a slot
+    concatenated in ascending id order (the dense hashed CSR of the CUDA library, PerturbationProTree.hh:11-12)."""
+    starts = np.concatenate([[0], np.cumsum(bin_sizes.astype(np.int64))])
+    order = sorted(range(len(bin_ids)), key=lambda b: (int(bin_ids[b]) % hs, int(bin_ids[b])))
+    prefix, counts, dbidx = np.zeros(hs, np.uint32), np.zeros(hs, np.uint32), []
+    for b in order:
+        slot = int(bin_ids[b]) % hs
+        if counts[slot] == 0:
+            prefix[slot] = len(dbidx)
+        counts[slot] += bin_sizes[b]
+        dbidx.extend(members[starts[b]:starts[b + 1]].tolist())
+    return prefix, counts, np.array(dbidx, np.uint32)
+
+
+def test_createdb_multi_chunk_and_both_dump_families(tmp_path):
+    """tool_createdb over the WHOLE dataset in 3 chunks == 1 chunk == the oracle's saveBins, byte for byte; the CUDA library's
+    dump family (.prefix/.count/.dbIdx/_<LP>.lines) is the documented translation of the exact bins, and tool_query answers
+    identically from either family when the hash does not alias."""
+    if not os.path.exists(os.path.join(HOST, "tool_query")):
+        subprocess.check_call(["make", "-C", HOST])
+    f = fixture("tools_default")
+    c = f.cfg
+    n = f.base.shape[0]
+    hs = 20011  # prime > (C1*C2)^P = 16384 possible bin ids: no two bins share a slot
+    outs = {}
+    for tag, chunk in (("one", n), ("three", (n + 2) // 3)):
+        d = tmp_path / tag
+        d.mkdir()
+        os.chdir(d)
+        pre = "t_%d_%d_%d_%d" % (c["D"], c["P"], c["C1"], c["C2"])
+        with open(pre + ".ppqt", "wb") as fh:
+            fh.write(("%d\n%d\n%d\n%d\n%d\n%d\n" % (c["D"], c["P"], c["P"], c["C1"], c["C2"], 1)).encode())
+            fh.write(f.cb1.tobytes())
+            fh.write(f.cb2.tobytes())
+        write_umem("base.umem", f.base, np.uint8)
+        args = ["--c1", str(c["C1"]), "--c2", str(c["C2"]), "--p", str(c["P"]), "--dim", str(c["D"]), "--lineparts", str(c["LP"]),
+                "--basename", "t", "--w", str(c["W"]), "--hashsize", str(hs)]
+        out = subprocess.run([os.path.join(HOST, "tool_createdb")] + args + ["--dataset", "base.umem", "--chunksize", str(chunk)],
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr + out.stdout
+        assert ("chunks %d" % (1 if tag == "one" else 3)) in out.stdout
+        outs[tag] = {ext: open(pre + ext, "rb").read() for ext in (".bins", ".prefix", ".count", ".dbIdx", "_%d.lines" % c["LP"])}
+    assert outs["one"] == outs["three"], "a 3-chunk build differs from the 1-chunk build"
+    f.oracle.save_bins(str(tmp_path / "oracle.bins"))
+    assert outs["one"][".bins"] == open(tmp_path / "oracle.bins", "rb").read()
+    prefix, counts, dbidx = _hashed_from_bins(f.bin_ids, f.bin_sizes, f.members, hs)
+    assert outs["one"][".prefix"] == prefix.tobytes() and outs["one"][".count"] == counts.tobytes() and outs["one"][".dbIdx"] == dbidx.tobytes()
+    assert outs["one"]["_%d.lines" % c["LP"]] == f.codes.tobytes()
+    # tool_query from the hashed family == from the .bins dump
+    write_umem("query.umem", f.queries, np.uint8)
+    gt = np.array([[int(f.oracle.query(q, 2000, 500)[0][0])] for q in f.queries], np.int32)
+    write_umem("gt.imem", gt, np.int32)
+    res = {}
+    for hashed in ("0", "1"):
+        out = subprocess.run([os.path.join(HOST, "tool_query")] + args + ["--queryset", "query.umem", "--groundtruth", "gt.imem", "--boundvectors", "2000",
+                             "--boundbins", "500", "--nvec", "64", "--hashed", hashed], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr + out.stdout
+        assert ("read t_%d_%d_%d_%d.prefix" % (c["D"], c["P"], c["C1"], c["C2"]) in out.stdout) == (hashed == "1")
+        res[hashed] = [l for l in out.stdout.splitlines() if l.startswith("@R")]
+    assert res["0"] == res["1"] and res["0"][0] == "@R1: 1"
+
+
+def test_class_surface_device_pointers_and_getters(tmp_path):
+    """buildKBestDB with a DEVICE pointer (the reference's signature) == the oracle's insert; getDBIdx / getLine /
+    getBinPrefix / getBinCounts hand out device arrays that agree with the dumps."""
+    if not os.path.exists(os.path.join(HOST, "test_classes")):
+        subprocess.check_call(["make", "-C", HOST])
+    f = fixture("tools_default")
+    c = f.cfg
+    n, hs = f.base.shape[0], 20011
+    os.chdir(tmp_path)
+    f.oracle.save_tree("o.tree")
+    f.oracle.save_bins("o.bins")
+    f.queries[:4].astype(np.float32).tofile("q.raw")
+    f.base.astype(np.float32).tofile("b.raw")
+    out = subprocess.run([os.path.join(HOST, "test_classes"), str(c["D"]), str(c["P"]), str(c["LP"]), str(c["W"]), "o.tree", "o.bins",
+                          "q.raw", "4", "1500", "400", "res.bin", "b.raw", str(n), str(hs)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert open("res.bin.devbuild.bins", "rb").read() == open("o.bins", "rb").read()
+    prefix, counts, dbidx = _hashed_from_bins(f.bin_ids, f.bin_sizes, f.members, hs)
+    assert open("res.bin.h.prefix", "rb").read() == prefix.tobytes() and open("res.bin.h.count", "rb").read() == counts.tobytes()
+    assert open("res.bin.h.dbIdx", "rb").read() == dbidx.tobytes()
+    g = np.fromfile("res.bin.getters", np.uint32)
+    g_dbidx, g_codes = g[:n], g[n:n + n * c["LP"]].reshape(n, c["LP"])
+    g_prefix, g_counts = g[n + n * c["LP"]:n + n * c["LP"] + hs], g[n + n * c["LP"] + hs:]
+    assert np.array_equal(g_dbidx, f.members)  # ids grouped by bin, bins in ascending id order (std::map order)
+    assert np.array_equal(g_codes, f.codes[f.members])  # row i = code of getDBIdx()[i]
+    assert np.array_equal(g_prefix, prefix) and np.array_equal(g_counts, counts)
