@@ -472,7 +472,9 @@ def main():
     LP, C1 = w["LP"], w["C1"]
     fused_rs = args.k <= 128
     kb = kernel_bytes(w, qn, k, He, cand_local, fused_rs)
-    rs_name = ("pqt_k_rerank_select_wg" if 4 * LP * C1 * C1 > 65536 else "pqt_k_rerank_select") if fused_rs else "pqt_k_rerank"
+    # big coarse tables: band-filtered exact rerank (pqt_k_rerank_select, MODE 2) unless --option exact_filter=0 (workgroup kernel)
+    rs_name = ("pqt_k_rerank_select_wg" if (4 * LP * C1 * C1 > 65536 and "exact_filter=0" in args.option) else "pqt_k_rerank_select") if fused_rs else \
+              ("pqt_k_rerank_select_big" if k <= 4096 else "pqt_k_rerank")
     kname = {"traverse": "pqt_k_traverse", "rerank_select": rs_name}
     dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
     rr_name = kname[dominant]
@@ -517,7 +519,7 @@ def main():
                    "global_batch": units,
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
                    "mean_candidates_this_rank": ncand_rank,
-                   "mean_bins_visited": He, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"],
+                   "mean_bins_visited": He, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"], "filter_fallbacks": st.get("filter_fallbacks"),
                    "exact_rerank_of_topk": exact,
                    "algorithmic_bytes_per_query": path_bytes_q,
                    "path_GBps": path_bytes_q * qn * args.steps / elapsed / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qn * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,

@@ -69,7 +69,7 @@ typedef struct {
   float ms_select;           /* final sort / top-k (a8)                                  */
   float ms_total;            /* whole batch on the device                                */
   uint32_t max_bin;          /* largest bin population in the index                      */
-  uint32_t reserved;
+  uint32_t filter_fallbacks; /* queries of the last call the band-filtered exact rerank (big coarse tables) handed to the plain exact kernel */
 } pqt_stats;
 
 const char* pqt_last_error(void);

@@ -33,10 +33,10 @@ class pqt_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("queries", "candidates", "bins_visited", "bins_nonempty", "ties_l1",
                                           "ties_l2", "ties_bins", "ties_final")] + \
                [(n, C.c_float) for n in ("ms_tables", "ms_bins", "ms_rerank", "ms_select", "ms_total")] + \
-               [("max_bin", C.c_uint32), ("reserved", C.c_uint32)]
+               [("max_bin", C.c_uint32), ("filter_fallbacks", C.c_uint32)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 # every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)

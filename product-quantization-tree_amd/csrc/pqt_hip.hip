@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <string>
@@ -64,7 +65,9 @@ struct pqt_index {
   // line codes (a7)
   uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
   uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
-  float* d_bias = nullptr; bool biasReady = false; bool adcBias = false;  // opt-in adc_bias mode: per-row query-independent part of the ADC sum
+  float* d_bias = nullptr; bool biasReady = false; bool adcBias = false; bool exactFilter = true; float coarseMax = 0.f;
+  uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
+   // opt-in adc_bias mode: per-row query-independent part of the ADC sum
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
@@ -118,6 +121,8 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_ovList, (size_t)qn))) return rc;
   if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
+  if ((rc = devAlloc(&idx->d_fbList, (size_t)qn))) return rc;
+  if (!idx->d_fbCount && (rc = devAlloc(&idx->d_fbCount, (size_t)2))) return rc;
   idx->qCap = qn;
   return PQT_OK;
 }
@@ -263,7 +268,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                         idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8,
-                        nullptr, 0, nullptr};
+                        nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -336,20 +341,39 @@ int ensureBias(pqt_index* idx) {
   return PQT_OK;
 }
 
-// fused rerank+select in adc_bias mode (pqt_rs_query MODE 1): no coarse table, group-major code words, NW wavefronts per workgroup
-template <int NW, int LPV, bool SH>
+// fused rerank+select without the coarse table in LDS (pqt_rs_query MODE 1 = opt-in adc_bias distances, MODE 2 = reference
+// distances through the MODE 1 filter): group-major code words, NW wavefronts per workgroup
+PqtRsArgs rsArgsFilter(pqt_index* idx, const float* qL1virt, const uint32_t* nLocal, uint64_t stride, uint32_t k, uint32_t nq,
+                       uint32_t* oI, float* oD, uint32_t* oP) {
+  const double lp = idx->dp.LP;
+  const float kappa = (float)(2.02 * (lp * lp + 8.0 * lp + 2.0) / 16777216.0);
+  return PqtRsArgs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+                   idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
+                   (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
+                   idx->d_fbList, idx->d_fbCount};
+}
+template <int NW, int LPV, bool SH, int MODE>
 int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
                  uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
   constexpr int UV = LPV >= 8 ? 2 : 4;
   const uint32_t c1 = idx->dp.C1;
-  auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, 1> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, 1>
-                                                                                      : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, 1>;
+  auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, MODE>
+                                                                                         : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, MODE>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
-  PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                  idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
-                  (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias};
+  const PqtRsArgs rargs = rsArgsFilter(idx, qL1virt, nLocal, stride, k, nq, oI, oD, oP);
+  if (MODE == 2) HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
+  if (MODE == 2) {
+    // queries whose near-tie band overflowed the wave's list (normally none): plain exact kernel on that list
+    constexpr int LNW = 4;
+    auto lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1>;
+    const size_t llds = (size_t)LNW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
+    if ((rc = allowLds(lk, llds))) return rc;
+    PqtRsArgs largs = rargs;
+    largs.tstamp = nullptr; largs.dynamic = 0; largs.zero8 = nullptr;
+    hipLaunchKernelGGL(lk, dim3(std::min<uint32_t>((nq + LNW - 1) / LNW, (uint32_t)idx->numCUs * 2)), dim3(LNW * 64), llds, st, largs);
+  }
   return PQT_OK;
 }
 
@@ -492,7 +516,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   // adc_bias mode: wave-per-query kernel without the coarse table; NW = 12 or 6 wavefronts around per-wave L1virt copies
   const size_t lBias12 = (size_t)12 * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
   const size_t lBias6 = (size_t)6 * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
-  const bool useBias = idx->adcBias && fused && k <= PQT_RS_BEST && lBias6 <= kMaxLds;
+  const bool biasShape = (d.LP == 16 || d.LP == 32) && (d.C1 & (d.C1 - 1)) == 0 && lBias6 <= kMaxLds;
+  // MODE 1: opt-in adc_bias distances.  MODE 2 (default when the coarse table does not fit the LDS): reference distances
+  // through the MODE 1 filter -- replaces the workgroup-per-query kernel with its staged table slices
+  const bool useFilter = !idx->adcBias && idx->exactFilter && !coarseLds && fused && biasShape && std::isfinite(idx->coarseMax);
+  const bool useBias = (idx->adcBias && fused && biasShape) || useFilter;
   const int biasNW = lBias12 <= kMaxLds ? 12 : 6;
   if (useBias) {
     if ((rc = ensureGroupMajor(idx, 4))) return rc;
@@ -609,9 +637,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         nextZeroed = true;
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         const uint32_t* nl = idx->d_nLocal + q0;
-#define PQT_LAUNCH_BIAS(NWV, LPVV) (idx->sharded ? launchRSBias<NWV, LPVV, true>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
-                                                 : launchRSBias<NWV, LPVV, false>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
+#define PQT_LAUNCH_BIAS1(NWV, LPVV, MD) (idx->sharded ? launchRSBias<NWV, LPVV, true, MD>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
+                                                      : launchRSBias<NWV, LPVV, false, MD>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
+#define PQT_LAUNCH_BIAS(NWV, LPVV) (useFilter ? PQT_LAUNCH_BIAS1(NWV, LPVV, 2) : PQT_LAUNCH_BIAS1(NWV, LPVV, 1))
         rc = d.LP == 16 ? (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 4) : PQT_LAUNCH_BIAS(6, 4)) : (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 8) : PQT_LAUNCH_BIAS(6, 8));
+#undef PQT_LAUNCH_BIAS1
 #undef PQT_LAUNCH_BIAS
         if (rc) return rc;
       } else if (wgG) {
@@ -680,6 +710,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
+  idx->lastFilter = useFilter;
   idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
@@ -746,7 +777,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -771,6 +802,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
     idx->adcBias = (value != 0);
     return PQT_OK;
   }
+  if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
@@ -804,6 +836,14 @@ int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) 
   hipLaunchKernelGGL(pqt_k_coarse, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, idx->stream, idx->d_cb1, idx->d_coarse, d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(idx->stream));
+  {  // largest coarse entry: bound of the MODE 2 error band (pqt_rs_query)
+    std::vector<float> hc(nc);
+    HIPCHK(hipMemcpy(hc.data(), idx->d_coarse, nc * 4, hipMemcpyDeviceToHost));
+    float m = 0.f;
+    for (float v : hc) if (v > m) m = v;  // NaN entries (none for finite codebooks) are skipped
+    idx->coarseMax = m;
+  }
+  idx->biasReady = false;
   idx->haveTree = true;
   return PQT_OK;
 }
@@ -1197,6 +1237,7 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   pqt_stats s{};
   s.queries = idx->lastQn; s.ties_l1 = c[0]; s.ties_l2 = c[1]; s.ties_bins = c[2]; s.ties_final = c[3];
   s.max_bin = idx->maxBin;
+  if (idx->lastFilter && idx->d_fbCount) { uint32_t fb = 0; HIPCHK(hipMemcpy(&fb, idx->d_fbCount, 4, hipMemcpyDeviceToHost)); s.filter_fallbacks = fb; }
   {
     std::vector<uint32_t> nl(idx->lastQn), ni(idx->lastQn);
     if (idx->lastQn) {

@@ -675,6 +675,11 @@ struct PqtRsArgs {
   // opt-in "adc_bias" mode (MODE 1 of pqt_rs_query): group-major copy of the line store [LP/4][nIds] 16-byte pieces, rows in
   // it, and the per-row query-independent part of the ADC sum
   const uint4* codesGrp4; uint64_t nIds; const float* bias;
+  // MODE 2 (exact results through the bias-mode filter): error-bound coefficients and the fallback list
+  float epsKappa;   // 2.02 * 2^-24 * (LP^2 + 8 LP + 2)
+  float cmax20;     // 20 * max coarse entry
+  uint32_t* fbList; uint32_t* fbCount;  // queries whose near-tie band did not fit the wave's list: redone by the plain exact kernel
+  const uint32_t* qlist; const uint32_t* qcount;  // pqt_k_rerank_select_list: the queries to process
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -687,6 +692,16 @@ struct PqtRsArgs {
 //   distance is sum_p term_p + bias[row].  Same real number, different rounding: candidate SETS are untouched (they are
 //   fixed before this stage), distances differ from MODE 0 in the last bits, so the top-k can differ among near-equal
 //   distances.  The code words come from the group-major copy of the store (consecutive candidates = contiguous bytes).
+// MODE 2 (default for first-level codebooks whose coarse table does not fit the LDS: BASELINE configs[2]/[3]): the
+//   REFERENCE result, bit for bit, at MODE 1's cost.  Both formulas evaluate the same real number D; with M = the largest
+//   entry of the query's L1virt table and Cmax = the largest coarse entry every intermediate of either formula is bounded
+//   by G = 5 M + 20 Cmax, a term costs <= 8 roundings and the sequential sum of LP terms <= LP roundings of partial sums
+//   <= LP*G, so |d0 - D| and |d1 - D| are each below u*G*(LP^2 + 8 LP + 2) (u = 2^-24) and |d0 - d1| <= eps =
+//   2.02*u*G*(LP^2 + 8 LP + 2).  Hence every member of the exact top-k has d1 <= d1_(k) + 2 eps (d1_(k) = k-th smallest MODE 1
+//   distance): the wave keeps the 256 smallest MODE 1 keys, re-evaluates the reference association only for the entries
+//   inside that band (coarse look-ups from L2, ~k + a few candidates per query instead of thousands), and sorts those by
+//   the exact key.  If the band reaches the end of a full list (a cluster of > 256 - k near-ties) the query is appended
+//   to fbList and redone by the plain exact kernel (pqt_k_rerank_select_list) -- never a wrong answer, rarely a slow one.
 template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot) {
@@ -718,6 +733,17 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   uint64_t tau = ~0ull;
   uint32_t npend = 0;  // pending keys sit at sKeys[off0 ..], off0 = size of the best list kept by the last flush
   uint32_t off0 = 0;
+  // best-list size: k normally; MODE 2 keeps the 256 smallest MODE 1 keys (the k-th plus a band of near-ties)
+  constexpr uint32_t BESTN = MODE == 2 ? 256u : (uint32_t)PQT_RS_BEST;
+  constexpr uint32_t SLOTS = PQT_RS_BEST + PQT_RS_PEND;
+  static_assert(BESTN + 64u * UREQ <= SLOTS, "a batch of appended keys must fit behind the best list");
+  const uint32_t kSel = MODE == 2 ? BESTN : k;
+  float qmax = 0.f;  // MODE 2: largest entry of the query's L1virt table
+  if constexpr (MODE == 2) {
+    for (uint32_t t = lane; t < LP * C1; t += 64) { const float v = sVirt[t]; qmax = v > qmax ? v : qmax; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(qmax, d, 64); qmax = o > qmax ? o : qmax; }
+  }
 
   auto flush = [&](const bool final) {
     // [best off0 (unsorted, after the first flush) | pending npend]: keep the k smallest.  More than 128 keys are cut
@@ -725,7 +751,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     // go through the (small) in-register sorting network.  The keys live in registers during the select, so its
     // counters reuse the pending area of sKeys (1056 bytes behind the best list).
     uint32_t have = off0 + npend;
-    if (have > PQT_RS_BEST) {
+    if (have > BESTN) {
       constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
       uint64_t key[RK];
 #pragma unroll
@@ -734,7 +760,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         key[r] = (e < have) ? sKeys[e] : ~0ull;
       }
       __builtin_amdgcn_wave_barrier();
-      tau = pqt_wave_kth_u64<RK>(key, k, reinterpret_cast<uint32_t*>(sKeys + PQT_RS_BEST));
+      tau = pqt_wave_kth_u64<RK>(key, kSel, reinterpret_cast<uint32_t*>(sKeys + BESTN));
       uint32_t cnt = 0;
 #pragma unroll
       for (int r = 0; r < RK; ++r) {
@@ -743,19 +769,20 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         if (key[r] <= tau) sKeys[cnt + rk] = key[r];
         cnt += tot;
       }
-      have = k;
+      have = kSel;
       __builtin_amdgcn_wave_barrier();
     }
     if (final) {
-      uint64_t key[2];
+      constexpr int FR = (int)(BESTN / 64);
+      uint64_t key[FR];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const uint32_t e = lane * 2 + r;
+      for (int r = 0; r < FR; ++r) {
+        const uint32_t e = lane * FR + r;
         key[r] = (e < have) ? sKeys[e] : ~0ull;
       }
-      if (!(dbg & 1)) pqt_wave_sort_u64<2>(key);
+      if (!(dbg & 1)) pqt_wave_sort_u64<FR>(key);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) sKeys[lane * 2 + r] = key[r];
+      for (int r = 0; r < FR; ++r) sKeys[lane * FR + r] = key[r];
       __builtin_amdgcn_wave_barrier();
     }
     npend = 0;
@@ -775,7 +802,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       uint4 rows[U][LPV];
       float rbias[U];
       (void)rbias;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -850,7 +877,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
             const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
             float sb, sa, sc;
-            if constexpr (MODE == 1) {
+            if constexpr (MODE != 0) {
               const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
               sb = sVirt[pv + A];
               sa = sVirt[pv + B];
@@ -872,7 +899,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             acc = acc + pqt_extract_distance(sa, sb, sc, lam);
           }
         }
-        if constexpr (MODE == 1) acc = acc + rbias[u];
+        if constexpr (MODE != 0) acc = acc + rbias[u];
         // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
         const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
         const bool pass = valid && key < tau;
@@ -887,7 +914,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     // single flush site: when the pending buffer could overflow on the next batch, and once at the end
     const bool last = base + 64 * U >= n;
     if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
-    if (last || off0 + npend + 64 * U > PQT_RS_BEST + PQT_RS_PEND) {
+    if (last || off0 + npend + 64 * U > SLOTS) {
       if (tstamp) ts0 = __builtin_readcyclecounter();
       flush(last);
       if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
@@ -897,6 +924,67 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   // results: first min(k, n) entries of the best list
   const uint32_t kk = n < k ? n : k;
   uint32_t ties = 0;
+  if constexpr (MODE == 2) {
+    // the list holds the off0 (<= 256) smallest MODE 1 keys in ascending order: re-evaluate the band [.., d1_(k) + 2 eps]
+    // with the reference association and order it by the exact key
+    if (kk) {
+      const float eps = A.epsKappa * (5.f * qmax + A.cmax20) * 1.001f;
+      const float dk = pqt_key2f((uint32_t)(sKeys[kk - 1] >> 32));
+      const float thr = dk + 2.f * eps + (dk < 0.f ? -dk : dk) * 1e-6f;
+      const uint32_t thrKey = pqt_f2key(thr);
+      uint32_t nT = 0;  // entries inside the band (a prefix of the sorted list)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t e = r * 64 + lane;
+        const bool in = e < off0 && (uint32_t)(sKeys[e] >> 32) <= thrKey;
+        nT += (uint32_t)__popcll(__ballot(in));
+      }
+      if (nT == BESTN && n > BESTN) {
+        // the band reaches the end of a full list: candidates outside the list may belong to it -> plain exact kernel
+        if (lane == 0) A.fbList[atomicAdd(A.fbCount, 1u)] = q;
+        __builtin_amdgcn_wave_barrier();
+        return;
+      }
+      uint64_t xk[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t e = r * 64 + lane;
+        xk[r] = ~0ull;
+        if (e < nT) {
+          const uint32_t j = (uint32_t)sKeys[e];
+          const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)cid[j] * LP);
+          float acc = 0.f;
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) {
+            const uint4 rv = row4[v];
+            const uint32_t w[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const uint32_t p = v * 4 + x;
+              const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+              const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);
+              const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+              const float sb = sVirt[pv + Aa], sa = sVirt[pv + Bb];
+              const float sc = A.coarse[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
+              acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+            }
+          }
+          xk[r] = ((uint64_t)pqt_f2key(acc) << 32) | j;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // blocked layout for the network: element e = lane*4 + r; go through LDS (pending area) to re-distribute
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sKeys[BESTN + r * 64 + lane] = xk[r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xk[r] = sKeys[BESTN + lane * 4 + r];
+      pqt_wave_sort_u64<4>(xk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sKeys[lane * 4 + r] = xk[r];
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   if (tstamp) ts0 = __builtin_readcyclecounter();
   for (uint32_t i = lane; i < k; i += 64) {
     const size_t o = (size_t)q * k + i;
@@ -1009,6 +1097,23 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
     pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE>(A, q, n, sKeys, sVirt, cz, qN, nN, slot);
     q = qN;
     n = nN;
+  }
+}
+
+// the queries MODE 2 handed back (fbList): plain exact rerank+select (MODE 0, coarse through L2), one wavefront per list entry
+template <int NW, int LPV, int UREQ, bool SHARDED, int C1M>
+__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select_list(const PqtRsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4;
+  const uint32_t C1 = C1M >= 2 ? (1u << C1M) : A.prm.C1;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint64_t* sKeys = (uint64_t*)smem_raw + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
+  float* sVirt = (float*)(smem_raw + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
+  const uint32_t cnt = *A.qcount;
+  for (uint32_t e = blockIdx.x * NW + wave; e < cnt; e += gridDim.x * NW) {
+    const uint32_t q = A.qlist[e];
+    uint32_t nN = 0;
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 0>(A, q, A.nLocal[q], sKeys, sVirt, A.coarse, 0xffffffffu, nN, 0u);
   }
 }
 

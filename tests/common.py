@@ -36,9 +36,9 @@ def quick_codebooks(train, P, C1, C2, seed, iters=4):
     cb2 = np.zeros((P, C1, C2, S), np.float32)
 
     def lloyd(x, k):
-        k_eff = min(k, max(1, x.shape[0]))
+        k_eff = min(k, x.shape[0])  # 0 for an empty cell: random fillers only
         cen = x[rng.choice(x.shape[0], k_eff, replace=False)].copy() if x.shape[0] else np.zeros((0, x.shape[1]), np.float32)
-        for _ in range(iters):
+        for _ in range(iters if x.shape[0] else 0):
             d = ((x[:, None, :] - cen[None]) ** 2).sum(-1)
             a = d.argmin(1)
             for c in range(k_eff):

@@ -672,3 +672,50 @@ def test_fused_big_k_select_shrinks_and_matches_oracle(k):
         assert np.array_equal(ids_s, ids) and np.array_equal(bits(dist_s), bits(dist)) and np.array_equal(cnt_s, cnt)
     finally:
         idx.close()
+
+
+def test_big_coarse_exact_filter_matches_workgroup_kernel_and_falls_back_on_tie_clusters():
+    """Shapes whose coarse table does not fit the LDS (BASELINE configs[2]/[3]) run the band-filtered exact rerank by default
+    (pqt_rs_query MODE 2): identical to the workgroup-per-query exact kernel.  A database of 600 copies of ONE vector per
+    bin puts hundreds of exactly tied candidates around the k-th distance, so the band overflows the wave's 256-entry list
+    and the query must take the fallback (plain exact kernel) -- still the oracle's result."""
+    from common import Fixture
+    for name in ("cfg3_small", "big_coarse"):
+        f = fixture(name)
+        bv, bb = BV_BB[name]
+        idx = f.hip_index()
+        try:
+            a = idx.query(f.queries, bv, bb, 100)
+            assert idx.stats()["filter_fallbacks"] == 0
+            idx.set_option("exact_filter", 0)
+            b = idx.query(f.queries, bv, bb, 100)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        finally:
+            idx.close()
+
+    def clustered(n, D, seed):
+        # 20 fixed prototypes; half of the vectors are exact copies of one (-> identical line codes, exactly tied
+        # distances, 300 per prototype in the database), the other half are noisy (so every tree cell can be trained)
+        protos = np.random.default_rng(777).integers(0, 256, (20, D)).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        x = protos[rng.integers(0, 20, n)]
+        noisy = rng.random(n) < 0.5
+        x[noisy] = np.clip(np.rint(x[noisy] + rng.normal(0, 25, (int(noisy.sum()), D))), 0, 255)
+        return x.astype(np.float32)
+
+    f = Fixture(D=64, P=2, C1=32, C2=4, W=2, LP=32, n_base=12000, n_query=8, seed=68, heur_rows=64, train=3000, data=clustered)
+    idx = f.hip_index()
+    try:
+        ids, dist, cnt = idx.query(f.queries, 10 ** 6, 64, 100)
+        st = idx.stats()
+        assert st["filter_fallbacks"] > 0, "fixture no longer overflows the band"
+        f.oracle.set_sort_mode(1)
+        for qi, q in enumerate(f.queries):
+            s_ids, s_d = f.oracle.query(q, 10 ** 6, 64)
+            kk = min(100, len(s_ids))
+            assert int(cnt[qi]) == len(s_ids)
+            assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), qi
+            assert np.array_equal(ids[qi, :kk], s_ids[:kk]), qi
+    finally:
+        f.oracle.set_sort_mode(0)
+        idx.close()
