@@ -296,6 +296,8 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-gt", action="store_true", help="skip the brute-force ground truth (recall fields become null): for rocprofv3 --pmc passes, "
+                    "where torch's reduce kernels crash the profiler on this image")
     ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k, "
                     "opt-in ADC modes); off by default so that a profile of the default command contains only the headline path's launches")
     ap.add_argument("--shard-db", action="store_true", help="(default for --gpus N > 1) range-shard the database")
@@ -365,7 +367,10 @@ def main():
         queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
     if mode == "shard_db":
         dist.broadcast(queries, 0)  # the SAME batch on every rank
-    if base is not None:
+    if args.no_gt:
+        gt = torch.full((qn,), -1, dtype=torch.int64, device=dev)
+        raw_u8 = None
+    elif base is not None:
         gt = brute_force_gt(base, queries, 1)[:, 0]
         raw_u8 = base.to(torch.uint8) if args.extras else None  # raw vectors for the optional exact re-rank (8f-4)
     else:
@@ -439,7 +444,7 @@ def main():
     elapsed = float(tmax.item())
 
     ids_t = out_idx.to(torch.int64) & 0xffffffff
-    r1, r10, r100 = recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100)
+    r1, r10, r100 = (None, None, None) if args.no_gt else (recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100))
     ncand_mean = float(out_cnt.to(torch.int64).float().mean())  # GLOBAL candidates per query (all shards)
     cq = torch.quantile(out_cnt.to(torch.float32), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
     log("[bench] candidates per query: median %.0f p90 %.0f p99 %.0f max %.0f" % tuple(cq))
@@ -463,7 +468,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     units = qn * (world if mode == "replica" else 1)  # queries answered by the whole job per step
     qps = units * args.steps / elapsed
-    if mode == "replica":  # job-wide recall / candidate statistics (outside the timed region)
+    if mode == "replica" and not args.no_gt:  # job-wide recall / candidate statistics (outside the timed region)
         agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
         dist.all_reduce(agg)
         r1, r10, r100, ncand_mean = (agg / world).tolist()
