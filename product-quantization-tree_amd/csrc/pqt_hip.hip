@@ -882,7 +882,14 @@ static int uploadHeuristic(pqt_index* idx) {
 int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows) {
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
   const uint64_t M = idx->maxMultiIndex;
-  if (M == 0) return fail(PQT_ERR_LIMIT, "(W*C2)^P wraps to 0 in uint32: the reference enumerates no bins for this configuration");
+  if (M == 0) {
+    // (W*C2)^P wraps to 0 in the reference's uint arithmetic (treequantizer.hpp:40-41, helper.hpp:19-22; BASELINE configs[4]:
+    // 64^8 = 2^48): its orderBins loop runs min(boundBins, 0) = 0 times, every query returns an empty candidate list.
+    // Same here: an empty heuristic, queries enumerate no rows.
+    idx->heurHost.clear();
+    idx->heurRows = 0;
+    return uploadHeuristic(idx);
+  }
   if (M > ((uint64_t)1 << 28)) return fail(PQT_ERR_LIMIT, "(W*C2)^P > 2^28 tuples: supply a prefix with pqt_index_set_heuristic");
   const uint32_t base = idx->dp.WC, P = idx->dp.P;
   std::vector<float> norm(M);

@@ -719,3 +719,40 @@ def test_big_coarse_exact_filter_matches_workgroup_kernel_and_falls_back_on_tie_
     finally:
         f.oracle.set_sort_mode(0)
         idx.close()
+
+
+def test_config5_shape_follows_the_reference_no_bins_enumerated():
+    """BASELINE configs[4] shape (d=256 p=8 c1=128 c2=64): (W*C2)^P = 64^8 wraps to 0 in the reference's uint arithmetic
+    (treequantizer.hpp:40-41), so its orderBins enumerates min(boundBins, 0) = 0 rows and every query returns an empty
+    list.  The engine does the same (no error, no invented semantics); the build side (insert) still works and matches."""
+    import torch
+    from oracle import Oracle
+    D, P, C1, C2, W, LP = 256, 8, 128, 64, 1, 32
+    rng = np.random.default_rng(5)
+    cb1 = rng.uniform(0, 255, (C1, D)).astype(np.float32)
+    cb2 = rng.uniform(0, 255, (P, C1, C2, D // P)).astype(np.float32)
+    base = rng.integers(0, 256, (300, D)).astype(np.float32)
+    o = Oracle(D, P, C1, C2, W, LP, heur_keep=16)
+    assert o.max_multi_index == 0
+    o.set_codebooks(cb1, cb2)
+    o.insert(base)
+    idx = pqt_pkg().PqtIndex(D, P, C1, C2, W, LP)
+    try:
+        idx.set_codebooks(cb1, cb2)
+        idx.build_heuristic(500)
+        ids_b, sizes_b, members = o.export_bins()
+        idx.set_bins(ids_b, sizes_b, members)
+        idx.set_lines(o.export_codes())
+        ids, dist, cnt = idx.query(base[:8], 20000, 500, 10)
+        assert np.all(cnt == 0) and np.all(ids == 0xffffffff) and np.all(np.isinf(dist))
+        for q in base[:8]:
+            assert len(o.query(q, 20000, 500)[0]) == 0
+        x = torch.from_numpy(base).cuda()
+        bins = torch.empty(300, dtype=torch.int32, device="cuda")
+        codes = torch.empty((300, LP), dtype=torch.int32, device="cuda")
+        idx.assign_encode_dev(x, bins, codes)
+        torch.cuda.synchronize()
+        assert np.array_equal(bins.cpu().numpy().view(np.uint32), np.array([o.bin_id(v) for v in base], np.uint32))
+        assert np.array_equal(codes.cpu().numpy().view(np.uint32), o.export_codes())
+    finally:
+        idx.close()
