@@ -728,6 +728,19 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   const uint32_t* cid = cand + (size_t)q * stride;
   const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
   if (tstamp) ts0 = __builtin_readcyclecounter();
+  // the store positions of a batch are requested one batch ahead (the first batch's here, under the L1virt copy): the
+  // id -> row chain of a batch is then ONE round trip on the critical path instead of two
+  uint32_t idNext[UREQ];
+#pragma unroll
+  for (int u = 0; u < UREQ; ++u) {
+    const uint32_t j = u * 64 + lane;
+    idNext[u] = n ? cid[j < n ? j : n - 1] : 0u;
+  }
+  if ((C1 & 3u) == 0) {  // LP*C1 floats as 16-byte pieces (both ends are 16-byte aligned)
+    const float4* src4 = reinterpret_cast<const float4*>(qL1virt + (size_t)q * LP * C1);
+    float4* dst4 = reinterpret_cast<float4*>(sVirt);
+    for (uint32_t t = lane; t < LP * C1 / 4; t += 64) dst4[t] = src4[t];
+  } else
   for (uint32_t t = lane; t < LP * C1; t += 64) sVirt[t] = qL1virt[(size_t)q * LP * C1 + t];
   __builtin_amdgcn_wave_barrier();
   uint64_t tau = ~0ull;
@@ -796,7 +809,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t j = base + u * 64 + lane;
-        id[u] = cid[j < n ? j : n - 1];  // position in the bin-ordered line store
+        id[u] = idNext[u];  // position in the bin-ordered line store (requested one batch ago)
         if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
       }
       uint4 rows[U][LPV];
@@ -855,6 +868,13 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 #pragma unroll
         for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
       }
+      }
+      if (base + 64 * U < n) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = base + 64 * U + u * 64 + lane;
+          idNext[u] = cid[j < n ? j : n - 1];
+        }
       }
       if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
 #pragma unroll
@@ -1206,14 +1226,15 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   PQT_TS(0);
   for (uint32_t i = lane; i < D; i += 64) sQ[i] = Q[(size_t)q * D + i];
   __builtin_amdgcn_wave_barrier();
-  // ---- a1 (4 accumulators per lane in flight: their cb1 reads overlap)
-  for (uint32_t t0 = lane; t0 < C1 * LP; t0 += 64 * 4) {
-    float acc[4];
-    uint32_t dst[4];
+  // ---- a1 (UA accumulators per lane in flight: their cb1 reads overlap; 8 sixteen-byte reads when the shape is known)
+  constexpr int UA = SHAPE == 2 ? 8 : 4;
+  for (uint32_t t0 = lane; t0 < C1 * LP; t0 += 64 * UA) {
+    float acc[UA];
+    uint32_t dst[UA];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UA; ++u) {
       const uint32_t t = t0 + 64 * u;
-      constexpr bool kFull = SHAPE != 0;  // compile-time shapes: C1*LP is a multiple of 256, every t is in range
+      constexpr bool kFull = SHAPE != 0;  // compile-time shapes: C1*LP is a multiple of 64*UA, every t is in range
       const uint32_t tt = (kFull || t < C1 * LP) ? t : t0;
       const uint32_t c = PQT_DIV(tt, LP, shLP), lp = PQT_MOD(tt, LP);
       const float* cen = cb1 + (size_t)PQT_MUL(c, D, shD) + PQT_MUL(lp, SS, shSS);
@@ -1240,10 +1261,47 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       dst[u] = (kFull || t < C1 * LP) ? PQT_MUL(lp, C1, shC1) + c : 0xffffffffu;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (dst[u] != 0xffffffffu) sVirt[dst[u]] = acc[u];
+    for (int u = 0; u < UA; ++u) if (dst[u] != 0xffffffffu) sVirt[dst[u]] = acc[u];
   }
   __builtin_amdgcn_wave_barrier();
   PQT_TS(1);
+  uint32_t ties = 0;
+  if constexpr (SHAPE != 0) {
+    // compile-time shapes: L1virt leaves in 16-byte pieces; the W nearest cells of a part come from W rounds of a
+    // wave-level arg-min over the part's C1 lanes (xor butterfly over (distance key << 32 | cell)) instead of counting
+    // every cell's rank against all others (C1 = 64: 1.3 k -> 0.12 k instructions per query).  Same result: keys are
+    // unique, the smallest key is the nearest cell, ties go to the lower index like the stable order.
+    {
+      const float4* src4 = reinterpret_cast<const float4*>(sVirt);
+      float4* dst4 = reinterpret_cast<float4*>(qL1virt + (size_t)q * LP * C1);
+      for (uint32_t t = lane; t < LP * C1 / 4; t += 64) dst4[t] = src4[t];
+    }
+    constexpr uint32_t kC1 = SH::C1, kW = SH::W, kR = SH::LP / SH::P;
+    static_assert(64 % kC1 == 0 && (SH::P * kC1) % 64 == 0, "a 64-lane chunk holds whole parts");
+#pragma unroll
+    for (uint32_t t0 = 0; t0 < SH::P * kC1; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const uint32_t p = t / kC1, c = t % kC1;
+      float d = 0.f;
+#pragma unroll
+      for (uint32_t pp = 0; pp < kR; ++pp) d = d + sVirt[(p * kR + pp) * kC1 + c];
+      sL1[t] = d;
+      uint64_t key = ((uint64_t)pqt_f2key(d) << 32) | c;
+#pragma unroll
+      for (uint32_t w = 0; w < kW; ++w) {
+        uint64_t m = key;
+        { const uint64_t o = pqt_lane_xor_u64<1>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<2>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<4>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<8>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<16>(m); m = o < m ? o : m; }
+        if constexpr (kC1 == 64) { const uint64_t o = pqt_lane_xor_u64<32>(m); m = o < m ? o : m; }
+        // exact ties that touch a selected cell (statistics; every tie that can influence the result is of this kind)
+        ties += (key != m && key != ~0ull && (uint32_t)(key >> 32) == (uint32_t)(m >> 32)) ? 1u : 0u;
+        if (key == m) { sOrd[p * kW + w] = c; key = ~0ull; }
+      }
+    }
+  } else {
   for (uint32_t t = lane; t < LP * C1; t += 64) qL1virt[(size_t)q * LP * C1 + t] = sVirt[t];
   for (uint32_t t = lane; t < P * C1; t += 64) {
     const uint32_t p = PQT_DIV(t, C1, shC1), c = PQT_MOD(t, C1);
@@ -1252,7 +1310,6 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     sL1[t] = d;
   }
   __builtin_amdgcn_wave_barrier();
-  uint32_t ties = 0;
   for (uint32_t t = lane; t < P * C1; t += 64) {
     const uint32_t p = PQT_DIV(t, C1, shC1), c = PQT_MOD(t, C1);
     const float my = sL1[t];
@@ -1277,6 +1334,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
     }
     if (rank < W) sOrd[p * W + rank] = c;
+  }
   }
   if (__any(ties != 0)) { if (ties) atomicAdd(&counters[0], (unsigned long long)ties); }
   __builtin_amdgcn_wave_barrier();
@@ -1375,8 +1433,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   // ---- a4 + a5: 8 rows per lane and block of 512 rows, row h = hb + lane + 64*r
   uint64_t key[8];
   uint32_t recG[8], recL[8];  // population of the row's bin (0: empty), start of its members (sharded: table slot)
-  auto rowKey = [&](const uint32_t h, uint32_t& globOut) -> uint64_t {
-    const uint4 hv = heur8[h];  // one 16-byte read: the row's P digits
+  auto rowKey = [&](const uint32_t h, const uint4 hv, uint32_t& globOut) -> uint64_t {
     const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
     float fine = 0.f;
     uint32_t g = 0;
@@ -1398,7 +1455,9 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       const uint32_t h = hb + lane + 64 * r;
       key[r] = ~0ull;
       glob[r] = 0;
-      if (h < He) key[r] = rowKey(h, glob[r]);
+      // (requesting the first block's rows at kernel start, before a1, was measured: 32 more live VGPRs spill at 5 waves
+      // per SIMD and a2 slows down by more than the round trip saved)
+      if (h < He) key[r] = rowKey(h, heur8[h] /* one 16-byte read: the row's P digits */, glob[r]);
     }
     // probes: first touch of all 8 slots is issued before any is consumed
     const uint4* table4 = reinterpret_cast<const uint4*>(table);  // {key, gcount, lstart, lcount}
@@ -1495,7 +1554,12 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
           for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)st, (int)b), l0 = (uint32_t)__builtin_amdgcn_readlane((int)ls, (int)b),
                            e0 = (uint32_t)__builtin_amdgcn_readlane((int)en, (int)b);
-            for (uint32_t j = s0 + lane; j < e0; j += 64) out[j] = l0 + (j - s0);
+            for (uint32_t j = s0 + lane; j < e0; j += 256) {  // 4 coalesced stores per trip
+              out[j] = l0 + (j - s0);
+              if (j + 64 < e0) out[j + 64] = l0 + (j + 64 - s0);
+              if (j + 128 < e0) out[j + 128] = l0 + (j + 128 - s0);
+              if (j + 192 < e0) out[j + 192] = l0 + (j + 192 - s0);
+            }
           }
         }
       } else
