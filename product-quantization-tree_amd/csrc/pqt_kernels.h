@@ -661,6 +661,12 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
                           // rows unchanged (12.6 k clocks) -- the wait is the id -> row dependent round trips, not the number of L1
                           // accesses per row -- so the variant stays off.
 #endif
+#ifndef PQT_RS_FINAL_SORT8
+#define PQT_RS_FINAL_SORT8 0  // 1: the last flush of a query sorts its <= 512 keys in one pass of the in-register network instead of
+                              // radix select + compaction + the 128-key network.  Measured r02 (SIFT1M shape): flush 16.5 k -> 17.0 k
+                              // clocks per query, rerank+select 0.155 -> 0.162 ms: the 1.5 k instructions of the big network cost
+                              // what the select's LDS round trips cost; off.
+#endif
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
 // arguments of the fused rerank + select (kernel-argument segment)
@@ -764,6 +770,28 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     // go through the (small) in-register sorting network.  The keys live in registers during the select, so its
     // counters reuse the pending area of sKeys (1056 bytes behind the best list).
     uint32_t have = off0 + npend;
+    if (PQT_RS_FINAL_SORT8 && final && have > BESTN) {
+      // last flush: at most 512 keys are held; one pass of the 512-key in-register network (no LDS atomics, no scans)
+      // replaces radix select + compaction + the small network
+      constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
+      uint64_t key[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        const uint32_t e = lane * RK + r;
+        key[r] = (e < have) ? sKeys[e] : ~0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (!(dbg & 1)) pqt_wave_sort_u64<RK>(key);
+      // the first BESTN sorted keys live in lanes 0 .. BESTN/RK - 1
+      if (lane < BESTN / RK) {
+#pragma unroll
+        for (int r = 0; r < RK; ++r) sKeys[lane * RK + r] = key[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      npend = 0;
+      off0 = have < kSel ? have : kSel;
+      return;
+    }
     if (have > BESTN) {
       constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
       uint64_t key[RK];
