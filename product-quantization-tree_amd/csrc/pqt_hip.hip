@@ -66,6 +66,7 @@ struct pqt_index {
   uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
   uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
   float* d_bias = nullptr; bool biasReady = false; bool adcBias = false; bool exactFilter = true; float coarseMax = 0.f;
+  unsigned long long* d_runs = nullptr; uint32_t* d_runGpos = nullptr; uint32_t* d_nRuns = nullptr; uint64_t runsCap = 0; bool useRuns = false; bool lastRuns = false;
   uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
    // opt-in adc_bias mode: per-row query-independent part of the ADC sum
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
@@ -74,6 +75,7 @@ struct pqt_index {
   uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
   hipEvent_t lev0 = nullptr, lev1 = nullptr;  // start/stop events attached to the next fused launch (lean timing), or null
+  bool curRuns = false;  // the current chunk hands bin runs (not a candidate list) from the traversal to the rerank
   bool curDynamic = false; unsigned long long* curZero8 = nullptr;  // rerank schedule and next statistics block of the current chunk
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
@@ -263,12 +265,14 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
   auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
   if constexpr (CL) { if (c1 == 32) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5>; }  // compile-time C1 only where the table is in LDS
+  if constexpr (CL && LPV == 4) { if (c1 == 32 && idx->curRuns) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5, 0, true>; }  // experimental bin-runs variant
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                         idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8,
-                        nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr};
+                        nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
+                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -350,7 +354,7 @@ PqtRsArgs rsArgsFilter(pqt_index* idx, const float* qL1virt, const uint32_t* nLo
   return PqtRsArgs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                    idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
                    (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
-                   idx->d_fbList, idx->d_fbCount};
+                   idx->d_fbList, idx->d_fbCount, nullptr, nullptr, nullptr};
 }
 template <int NW, int LPV, bool SH, int MODE>
 int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
@@ -531,6 +535,16 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   // a shape whose fused kernel does not fit the LDS (e.g. C1 = 256 with >= 16 line parts) runs the staged rerank/select,
   // which needs LP*C1*4 bytes only
   if (fused && !wgG && lFused > kMaxLds) fused = false;
+  // bin runs instead of a candidate list: fused traversal -> MODE 0 rerank with the LDS table (the SIFT1M shapes)
+  const size_t lRuns = ((lFused + 15) & ~(size_t)15) + (size_t)kFusedWaves * PQT_RUNCAP * 12;
+  const bool emitRuns = idx->useRuns && travFused && fused && coarseLds && !useBias && !wgG && lRuns <= kMaxLds && d.C1 == 32 && d.LP == 16;
+  if (emitRuns && (uint64_t)qChunk * PQT_RUNCAP > idx->runsCap) {
+    if ((rc = devAlloc(&idx->d_runs, (size_t)qChunk * PQT_RUNCAP))) return rc;
+    if ((rc = devAlloc(&idx->d_runGpos, (size_t)qChunk * PQT_RUNCAP))) return rc;
+    if ((rc = devAlloc(&idx->d_nRuns, (size_t)qChunk))) return rc;
+    idx->runsCap = (uint64_t)qChunk * PQT_RUNCAP;
+  }
+  idx->curRuns = emitRuns;
   // 128 < k <= 4096 (queryKNN(.., 4096) of the reference front-end): workgroup-per-query fused rerank+select, distances on chip
   const uint32_t kcap = std::max<uint32_t>(2 * kP2, 1024);
   const size_t lBigBase = (size_t)d.LP * d.C1 * 4 + (size_t)kcap * 8 + 256 * 4 + 4 * 8 + 16;
@@ -564,7 +578,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
                               idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
-                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits, (idx->dbg >> 5) & 1u};
+                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
+                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, (idx->dbg >> 5) & 1u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
@@ -653,7 +668,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       } else {
         idx->curZero8 = nextCtr;  // the kernel also zeroes the statistics block of the next call
         nextZeroed = true;
-        if ((rc = launchRerankSelect(idx, coarseLds, grid, lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
+        if ((rc = launchRerankSelect(idx, coarseLds, grid, emitRuns ? lRuns : lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                      stride, k, nq, oI, oD, oP))) return rc;
       }
       if (!leanEvents) PQT_REC(EV_RERANK);
@@ -711,6 +726,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->lastQn = qn; idx->lastHe = He;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
   idx->lastFilter = useFilter;
+  idx->lastRuns = emitRuns;
   idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
@@ -777,7 +793,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -802,6 +818,11 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
     idx->adcBias = (value != 0);
     return PQT_OK;
   }
+  // 1: the fused traversal hands the included bins to the MODE 0 rerank as (first position, first row) runs instead of
+  // materialising the candidate list.  Measured r02 (SIFT1M shape): traversal 0.066 -> 0.057 ms, but the rerank's expansion
+  // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
+  // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
+  if (strcmp(name, "bin_runs") == 0) { idx->useRuns = (value != 0); return PQT_OK; }
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
@@ -1170,6 +1191,8 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd
   if (idx->nChunks > 1 && (candIdx || candDist)) return fail(PQT_ERR_STATE, "last batch ran in several chunks; candidates of earlier chunks are gone");
   if ((segd || segbin) && !idx->lastSegKept)
     return fail(PQT_ERR_STATE, "the last call ran the fused traversal, which keeps seg_d2/seg_bin on chip: set_option(\"fused\", 0) first");
+  if (candIdx && idx->lastRuns)
+    return fail(PQT_ERR_STATE, "the last call handed bin runs from the traversal to the rerank, no candidate list was materialised: set_option(\"bin_runs\", 0) or use k > 128");
   if (candDist && !idx->lastDistKept)
     return fail(PQT_ERR_STATE, "the last call ran the fused rerank+select, which never writes cand_dist: use k > 128 or set_option(\"fused\", 0)");
   int rc = setDevice(idx);

@@ -667,6 +667,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
                               // clocks per query, rerank+select 0.155 -> 0.162 ms: the 1.5 k instructions of the big network cost
                               // what the select's LDS round trips cost; off.
 #endif
+#define PQT_RUNCAP 128   // bin runs per query handed from the traversal to the rerank (more: the plain candidate list is written)
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
 // arguments of the fused rerank + select (kernel-argument segment)
@@ -686,6 +687,10 @@ struct PqtRsArgs {
   float cmax20;     // 20 * max coarse entry
   uint32_t* fbList; uint32_t* fbCount;  // queries whose near-tie band did not fit the wave's list: redone by the plain exact kernel
   const uint32_t* qlist; const uint32_t* qcount;  // pqt_k_rerank_select_list: the queries to process
+  // bin runs instead of a candidate list (MODE 0 with the coarse table in LDS): runs[q][PQT_RUNCAP] = (first visiting
+  // position | first store position << 32) of the included bins in visiting order, nRuns[q] = their number or 0xffffffff
+  // when the traversal wrote the plain list after all; runGpos (sharded) = global visiting position of a run's first member
+  const unsigned long long* runs; const uint32_t* runGpos; const uint32_t* nRuns;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -708,9 +713,10 @@ struct PqtRsArgs {
 //   inside that band (coarse look-ups from L2, ~k + a few candidates per query instead of thousands), and sorts those by
 //   the exact key.  If the band reaches the end of a full list (a cluster of > 256 - k near-ties) the query is appended
 //   to fbList and redone by the plain exact kernel (pqt_k_rerank_select_list) -- never a wrong answer, rarely a slow one.
-template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0>
+template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
-                                             const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot) {
+                                             const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot,
+                                             unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t* __restrict__ codes = A.codes; const uint32_t* __restrict__ ids = A.ids; const float* __restrict__ qL1virt = A.qL1virt;
   const uint32_t* __restrict__ cand = A.cand; const uint32_t* __restrict__ candPos = A.candPos; const uint32_t* __restrict__ nLocal = A.nLocal;
@@ -734,13 +740,65 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   const uint32_t* cid = cand + (size_t)q * stride;
   const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
   if (tstamp) ts0 = __builtin_readcyclecounter();
+  // Bin runs (MODE 0 with the LDS table): the traversal hands over the included bins as (first visiting position, first
+  // store position) pairs instead of one store position per candidate; candidate j's row is found by a 7-step search
+  // over <= 128 LDS entries -- no candidate list in HBM, no id round trip in front of the row round trip.
+  constexpr bool kRuns = RUNS && MODE == 0 && COARSE_LDS;  // experimental, off by default (pqt_index_set_option "bin_runs")
+  uint32_t mRuns = 0xffffffffu;
+  // the run count and this lane's two run slots are requested together (one round trip; slots beyond the count hold
+  // stale words that are masked below)
+  unsigned long long rr0 = 0, rr1 = 0;
+  if constexpr (kRuns) {
+    if (sRuns && A.nRuns) {
+      mRuns = A.nRuns[q];
+      rr0 = A.runs[(size_t)q * PQT_RUNCAP + lane];
+      rr1 = A.runs[(size_t)q * PQT_RUNCAP + 64 + lane];
+    }
+  }
+  const bool useRuns = kRuns && mRuns != 0xffffffffu;
+  uint32_t* const sRunG = reinterpret_cast<uint32_t*>(sRuns + PQT_RUNCAP);
+  // runs `lane` and `64 + lane` also live in registers: a batch of 64 consecutive candidates spans a handful of runs, which
+  // are broadcast one after the other (v_readlane with a uniform index) -- no search, no LDS latency on the row path
+  uint32_t rs0 = 0xffffffffu, rl0 = 0, rs1 = 0xffffffffu, rl1 = 0;
+  if (useRuns) {
+    if (lane < mRuns) { sRuns[lane] = rr0; rs0 = (uint32_t)rr0; rl0 = (uint32_t)(rr0 >> 32); }
+    if (64 + lane < mRuns) { sRuns[64 + lane] = rr1; rs1 = (uint32_t)rr1; rl1 = (uint32_t)(rr1 >> 32); }
+    if (SHARDED) for (uint32_t i = lane; i < mRuns; i += 64) sRunG[i] = A.runGpos[(size_t)q * PQT_RUNCAP + i];
+  }
+  // store position of candidate jb + lane for the 64 consecutive candidates starting at jb (uniform)
+  auto expand64 = [&](const uint32_t jb) -> uint32_t {
+    const uint32_t jm = jb + lane;
+    uint32_t r = (uint32_t)__popcll(__ballot(rs0 <= jb)) + (uint32_t)__popcll(__ballot(rs1 <= jb));  // runs starting at or before jb
+    r = r ? r - 1 : 0;
+    uint32_t pos = 0;
+    for (;;) {
+      const uint32_t s0 = r < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)rs0, (int)r) : (uint32_t)__builtin_amdgcn_readlane((int)rs1, (int)(r - 64));
+      const uint32_t l0 = r < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)rl0, (int)r) : (uint32_t)__builtin_amdgcn_readlane((int)rl1, (int)(r - 64));
+      const uint32_t rn = r + 1;
+      const uint32_t e0 = rn < mRuns ? (rn < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)rs0, (int)rn) : (uint32_t)__builtin_amdgcn_readlane((int)rs1, (int)(rn - 64))) : 0xffffffffu;
+      if (jm >= s0 && jm < e0) pos = l0 + (jm - s0);
+      if (e0 >= jb + 64 || rn >= mRuns) break;
+      r = rn;
+    }
+    return pos;
+  };
+  // run index of candidate j: last run whose first visiting position is <= j (branch-free, 7 LDS reads)
+  auto runOf = [&](const uint32_t j) -> uint32_t {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t s2 = PQT_RUNCAP / 2; s2 >= 1; s2 >>= 1) {
+      const uint32_t mid = lo + s2;
+      if (mid < mRuns && (uint32_t)sRuns[mid] <= j) lo = mid;
+    }
+    return lo;
+  };
   // the store positions of a batch are requested one batch ahead (the first batch's here, under the L1virt copy): the
   // id -> row chain of a batch is then ONE round trip on the critical path instead of two
   uint32_t idNext[UREQ];
 #pragma unroll
   for (int u = 0; u < UREQ; ++u) {
     const uint32_t j = u * 64 + lane;
-    idNext[u] = n ? cid[j < n ? j : n - 1] : 0u;
+    idNext[u] = (n && !useRuns) ? cid[j < n ? j : n - 1] : 0u;
   }
   if ((C1 & 3u) == 0) {  // LP*C1 floats as 16-byte pieces (both ends are 16-byte aligned)
     const float4* src4 = reinterpret_cast<const float4*>(qL1virt + (size_t)q * LP * C1);
@@ -838,6 +896,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       for (int u = 0; u < U; ++u) {
         const uint32_t j = base + u * 64 + lane;
         id[u] = idNext[u];  // position in the bin-ordered line store (requested one batch ago)
+        if constexpr (kRuns) { if (useRuns) { const uint32_t p0 = expand64(base + u * 64); id[u] = j < n ? p0 : 0u; } }
         if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
       }
       uint4 rows[U][LPV];
@@ -897,7 +956,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
       }
       }
-      if (base + 64 * U < n) {
+      if (!useRuns && base + 64 * U < n) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + 64 * U + u * 64 + lane;
@@ -1039,9 +1098,16 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     if (i < kk) {
       const uint64_t key = sKeys[i];
       const uint32_t j = (uint32_t)key;
-      outIdx[o] = ids[cid[j]];
+      if (useRuns) {
+        const uint32_t ri = runOf(j);
+        const unsigned long long r = sRuns[ri];
+        outIdx[o] = ids[(uint32_t)(r >> 32) + (j - (uint32_t)r)];
+        if (SHARDED) outPos[o] = sRunG[ri] + (j - (uint32_t)r);
+      } else {
+        outIdx[o] = ids[cid[j]];
+        if (SHARDED) outPos[o] = cpos[j];
+      }
       outDist[o] = pqt_key2f((uint32_t)(key >> 32));
-      if (SHARDED) outPos[o] = cpos[j];
       if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
     } else {
       outIdx[o] = 0xffffffffu;
@@ -1059,7 +1125,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 }
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
-          int MODE = 0>
+          int MODE = 0, bool RUNS = false>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A) {
   const float* __restrict__ coarse = A.coarse; const uint32_t* __restrict__ nLocal = A.nLocal; const uint32_t qn = A.qn;
   const PqtDevParams& prm = A.prm; const uint32_t dbg = A.dbg; const uint32_t dynamic = A.dynamic; unsigned long long* __restrict__ zero8 = A.zero8;
@@ -1085,6 +1151,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   uint32_t* sList = sTicket + 4;             // PQT_RS_LIST: ordinal in the workgroup's list, longest first
   uint32_t* sListN = sList + PQT_RS_LIST;    // PQT_RS_LIST: its candidate count
   uint32_t* sTmpN = sListN + PQT_RS_LIST;    // PQT_RS_LIST: counts in list order (ranking input)
+  // per-wave bin-run area (MODE 0 with the LDS table only; the launcher sizes the LDS accordingly)
+  unsigned long long* sRuns = (RUNS && MODE == 0 && COARSE_LDS && A.runs)
+      ? reinterpret_cast<unsigned long long*>(smem_raw + ((ticketOff + 16 + 3 * PQT_RS_LIST * 4 + 15) & ~(size_t)15)) + (size_t)wave * (PQT_RUNCAP + PQT_RUNCAP / 2)
+      : nullptr;
   const uint32_t L = (dynamic && blockIdx.x < qn) ? (qn - blockIdx.x + G - 1) / G : 0u;
   const uint32_t Ls = L < PQT_RS_LIST ? L : PQT_RS_LIST;
   if (threadIdx.x == 0) *sTicket = 0;
@@ -1142,7 +1212,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
     // the next query is chosen now; a count that is not in the LDS list is fetched under the final select + sort below
     uint32_t nN = 0;
     const uint32_t qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE>(A, q, n, sKeys, sVirt, cz, qN, nN, slot);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, sRuns);
     q = qN;
     n = nN;
   }
@@ -1193,6 +1263,7 @@ struct PqtTravArgs {
   float* segDOut; uint32_t* segBOut;    // [q][P][WC]: sorted lists, written when He > 512 (overflow hand-over)
   uint32_t* ovList; uint32_t* ovCount;  // queries handed to pqt_k_bins (He > 512 and > 512 populated rows)
   const uint32_t* filter; uint32_t filterBits;  // presence bitmap over the bin keys, or null
+  unsigned long long* runs; uint32_t* runGpos; uint32_t* nRuns;  // bin runs for the rerank (see PqtRsArgs), or null
   uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
 };
 
@@ -1202,7 +1273,7 @@ struct PqtTravArgs {
 // unrolls the per-dimension loops and issues the centroid reads of a lane's accumulators together; with run-time SS it
 // emitted a remainder loop of one 4-byte load + s_waitcnt per dimension (cfg3 shape: 128 serialized round trips per
 // query in a1 alone, 56 k of the 228 k clocks of a traversal).
-template <int SHAPE> struct PqtShape { static constexpr uint32_t D = 0, P = 0, C1 = 0, C2 = 0, W = 0, LP = 0; };
+template <int SHAPE> struct PqtShape { static constexpr uint32_t D = 1, P = 1, C1 = 1, C2 = 1, W = 1, LP = 1; };  // run-time shape: unused
 template <> struct PqtShape<1> { static constexpr uint32_t D = 128, P = 4, C1 = 32, C2 = 32, W = 2, LP = 16; };
 template <> struct PqtShape<2> { static constexpr uint32_t D = 128, P = 4, C1 = 64, C2 = 64, W = 1, LP = 32; };
 __host__ __device__ inline int pqt_shape_of(const PqtDevParams& d) {
@@ -1568,6 +1639,15 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; }
       PQT_TS(7);
+      if (A.runs) {
+        // hand the compact list itself to the rerank when it fits: no candidate list is written
+        if (m <= PQT_RUNCAP) {
+          for (uint32_t i = lane; i < m; i += 64) A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i];
+          if (lane == 0) A.nRuns[q] = m;
+          return totNe;
+        }
+        if (lane == 0) A.nRuns[q] = 0xffffffffu;
+      }
       uint32_t* const out = cand + (size_t)q * stride;
       if (totCand >= 32u * m) {
         // long bins (BASELINE configs[2]/[3]: hundreds of members each): the wave walks the listed bins and writes each
@@ -1632,6 +1712,14 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; }
       PQT_TS(7);
+      if (A.runs) {
+        if (m <= PQT_RUNCAP) {
+          for (uint32_t i = lane; i < m; i += 64) { A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i]; A.runGpos[(size_t)q * PQT_RUNCAP + i] = sGpos[i]; }
+          if (lane == 0) A.nRuns[q] = m;
+          return totNe;
+        }
+        if (lane == 0) A.nRuns[q] = 0xffffffffu;
+      }
       uint32_t* const out = cand + (size_t)q * stride;
       uint32_t* const outP = candPos + (size_t)q * stride;
       if (totLocal >= 32u * m) {  // long bins: walk the listed bins, coalesced stores, no search (see the unsharded branch)
@@ -1692,7 +1780,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     }
     __builtin_amdgcn_wave_barrier();
     if (npop > 512) {
-      if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; }
+      if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
       return;
     }
     if (npop <= 128) {

@@ -212,17 +212,19 @@ def test_sharded_two_way_equals_unsharded(pair):
         Dd = torch.empty((2, qn, k), dtype=torch.float32, device="cuda")
         Pp = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
         Cc = torch.empty((2, qn), dtype=torch.int32, device="cuda")
-        for s, sh in enumerate(shards):
-            sh.query_shard_dev(q, Bv, Bb, k, I[s], Dd[s], Pp[s], Cc[s], sync=True)
-        oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
-        oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
-        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)  # [shard][QN][k] layout (shard_stride 0 = QN*k)
-        got_ids = oI.cpu().numpy().view(np.uint32)
-        got_d = oD.cpu().numpy()
-        assert np.array_equal(Cc[0].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
-        assert np.array_equal(Cc[1].cpu().numpy().view(np.uint32), ref_c)
-        assert np.array_equal(got_ids, ref_ids)
-        assert np.array_equal(bits(got_d), bits(ref_d))
+        for runs in (0, 1):  # 1: bin runs (with the global positions of their first members) instead of candidate lists
+            for s, sh in enumerate(shards):
+                sh.set_option("bin_runs", runs)
+                sh.query_shard_dev(q, Bv, Bb, k, I[s], Dd[s], Pp[s], Cc[s], sync=True)
+            oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+            oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+            shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)  # [shard][QN][k] layout (shard_stride 0 = QN*k)
+            got_ids = oI.cpu().numpy().view(np.uint32)
+            got_d = oD.cpu().numpy()
+            assert np.array_equal(Cc[0].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
+            assert np.array_equal(Cc[1].cpu().numpy().view(np.uint32), ref_c)
+            assert np.array_equal(got_ids, ref_ids)
+            assert np.array_equal(bits(got_d), bits(ref_d))
     finally:
         for sh in shards:
             sh.close()
@@ -424,14 +426,15 @@ def test_schedule_and_ordering_variants_change_nothing(name):
             assert np.array_equal(ref[2][r * n:(r + 1) * n], small[2])
         st_ref = idx.stats()
         # "static_shapes" 0: the run-time-shape traversal instead of the compile-time instantiation of the two BASELINE shapes
-        for opt in ("balance", "order_all_rows", "static_shapes"):
-            idx.set_option(opt, 1 if opt == "order_all_rows" else 0)
+        # "bin_runs" 1: the traversal hands bin runs to the rerank instead of materialising the candidate list
+        for opt in ("balance", "order_all_rows", "static_shapes", "bin_runs"):
+            idx.set_option(opt, 1 if opt in ("order_all_rows", "bin_runs") else 0)
             got = idx.query(big_q, bv, bb, 50)
             assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1])) and np.array_equal(got[2], ref[2])
             st = idx.stats()
             for key in ("candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_final"):
                 assert st[key] == st_ref[key], key
-            idx.set_option(opt, 0 if opt == "order_all_rows" else 1)
+            idx.set_option(opt, 0 if opt in ("order_all_rows", "bin_runs") else 1)
     finally:
         idx.close()
 
