@@ -112,6 +112,11 @@ int pqt_index_get_coarse(const pqt_index* idx, float* out_host);
  * set: takes a caller-supplied prefix tuples[rows][P] (e.g. dumped from a reference run). */
 int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows);
 int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples_host, uint64_t rows);
+/* Optional mode: the CUDA library's traversal heuristic, ProTree::prepareDistSequence(maxCluster, groupParts)
+ * (pqt/ProTree.cu:128-207; called with (C2*k1, p) by queryKNN, PerturbationProTree.cu:8191): digits in base
+ * min(16, max_cluster), tuples ordered by sum_p sqrt(digit) (f32, ties by tuple index), at most 65536 rows.  Changes the
+ * ORDER in which bins are enumerated, nothing else (bin ids, cut and rerank stay cpu_version). */
+int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_t rows);
 int pqt_index_get_heuristic(const pqt_index* idx, uint32_t* out_host, uint64_t rows);
 
 /* ---- bin store ----------------------------------------------------------------------------

@@ -43,7 +43,7 @@ class pqt_stats(C.Structure):
 EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
     "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather", "pqt_rerank_exact",
-    "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_set_heuristic",
+    "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_build_heuristic_cuda", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
@@ -79,6 +79,7 @@ def lib():
     L.pqt_index_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqt_index_get_coarse.argtypes = [C.c_void_p, f32p]
     L.pqt_index_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
+    L.pqt_index_build_heuristic_cuda.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     L.pqt_index_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_index_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_index_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p]
@@ -164,6 +165,10 @@ class PqtIndex:
 
     def build_heuristic(self, rows):
         _chk(self.L.pqt_index_build_heuristic(self.h, rows))
+
+    def build_heuristic_cuda(self, max_cluster, rows):
+        """The CUDA library's prepareDistSequence order (sum of sqrt(digit), digits < min(16, max_cluster)) as the table."""
+        _chk(self.L.pqt_index_build_heuristic_cuda(self.h, max_cluster, rows))
 
     def set_heuristic(self, tuples):
         t = _np(tuples, np.uint32).reshape(-1, self.P)

@@ -936,6 +936,36 @@ int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows) {
   return uploadHeuristic(idx);
 }
 
+// Optional mode ("next" row 8f-4 tail): the CUDA library's traversal heuristic, ProTree::prepareDistSequence
+// (pqt/ProTree.cu:128-207): digits in base b = min(16, max_cluster), all b^P tuples (digit p = i / b^p % b), key =
+// sum_p sqrt(digit) accumulated in f32 in part order, std::sort of (key, i) pairs (ties by tuple index: deterministic),
+// at most NUM_DISTSEQ = 65536 entries kept.  Only the ORDER of enumeration changes; bin ids, the cut and the rerank keep
+// cpu_version semantics, so results under this table are not the reference CPU path's (nor bit-comparable with the CUDA
+// path, whose bin-id digit order differs: SURVEY 8a "divergences").
+int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_t rows) {
+  if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  const uint32_t P = idx->dp.P;
+  uint32_t b = std::min<uint32_t>(std::min<uint32_t>(max_cluster, 16u), idx->dp.WC);
+  if (b == 0) return fail(PQT_ERR_INVALID, "max_cluster must be > 0");
+  uint64_t nVec = 1;
+  for (uint32_t p = 0; p < P; ++p) { nVec *= b; if (nVec > (1ull << 32)) return fail(PQT_ERR_LIMIT, "min(16, max_cluster)^P tuples exceed 2^32"); }
+  std::vector<std::pair<float, uint32_t> > dists((size_t)nVec);
+  std::vector<uint64_t> denom(P, 1);
+  for (uint32_t p = 1; p < P; ++p) denom[p] = denom[p - 1] * b;
+  for (uint64_t i = 0; i < nVec; ++i) {
+    float dist = 0.f;
+    for (uint32_t p = 0; p < P; ++p) dist += sqrtf((float)((i / denom[p]) % b));
+    dists[(size_t)i] = std::make_pair(dist, (uint32_t)i);
+  }
+  std::sort(dists.begin(), dists.end());
+  rows = std::min<uint64_t>(std::min<uint64_t>(rows, nVec), 65536);
+  idx->heurHost.assign(rows * P, 0);
+  for (uint64_t h = 0; h < rows; ++h)
+    for (uint32_t p = 0; p < P; ++p) idx->heurHost[h * P + p] = (uint32_t)((dists[(size_t)h].second / denom[p]) % b);
+  idx->heurRows = rows;
+  return uploadHeuristic(idx);
+}
+
 int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples, uint64_t rows) {
   if (!idx || (!tuples && rows)) return fail(PQT_ERR_INVALID, "null argument");
   idx->heurHost.assign(tuples, tuples + rows * idx->dp.P);

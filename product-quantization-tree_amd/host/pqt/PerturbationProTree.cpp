@@ -20,6 +20,11 @@ void ProTree::prepareDistSequence(uint _rows) {
   if (pqt_index_build_heuristic(handle(), _rows) != PQT_OK) throw std::runtime_error(pqt_last_error());
 }
 
+void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
+  if (_groupParts != (int)d_p) throw std::runtime_error("prepareDistSequence: groupParts must equal p");
+  if (pqt_index_build_heuristic_cuda(handle(), (uint32_t)_maxCluster, 65536) != PQT_OK) throw std::runtime_error(pqt_last_error());
+}
+
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
     : ProTree(_dim, _p, _p2), d_idx(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
       d_hashCounts(nullptr), d_hashSizeHeld(0), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),

@@ -56,6 +56,9 @@ class ProTree : public ProQuantization {
   /** traversal heuristic: the first _rows tuples of prepareHeuristic (treequantizer.hpp:75-127); the CUDA
    *  prepareDistSequence(int,int) (ProTree.hh:66) is its counterpart */
   void prepareDistSequence(uint _rows);
+  /** the CUDA library's own heuristic with its signature (ProTree.hh:66, ProTree.cu:128-207): sum-of-sqrt order over digits
+   *  < min(16, _maxCluster); _groupParts must be p.  Optional mode: changes the enumeration order only. */
+  void prepareDistSequence(int _maxCluster, int _groupParts);
 
  protected:
   virtual pqt_index* handle() = 0;

@@ -759,3 +759,39 @@ def test_config5_shape_follows_the_reference_no_bins_enumerated():
         assert np.array_equal(codes.cpu().numpy().view(np.uint32), o.export_codes())
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("name", ["tools_default", "cfg2_small"])
+def test_cuda_style_heuristic_mode(name):
+    """Optional mode (SURVEY 8f-4 tail): the CUDA library's prepareDistSequence order (pqt/ProTree.cu:128-207) as the
+    traversal heuristic.  The table equals a numpy restatement (f32 sum of sqrt(digit) in part order, ties by tuple index),
+    and queries under it equal the oracle's when the oracle is handed the same table (everything else is cpu_version)."""
+    f = fixture(name)
+    c = f.cfg
+    P, WC = c["P"], c["W"] * c["C2"]
+    b = min(16, WC)
+    n_vec = b ** P
+    i = np.arange(n_vec, dtype=np.int64)
+    digits = np.stack([(i // b ** p) % b for p in range(P)], 1)
+    key = np.zeros(n_vec, np.float32)
+    for p in range(P):
+        key = key + np.sqrt(digits[:, p].astype(np.float32))
+    order = np.lexsort((i, key))
+    rows = min(n_vec, 65536, 400)
+    want = digits[order[:rows]].astype(np.uint32)
+    idx = f.hip_index()
+    try:
+        idx.build_heuristic_cuda(WC, rows)
+        assert np.array_equal(idx.heuristic(rows), want)
+        ids, dist, cnt = idx.query(f.queries, 500, rows, 50)
+        f.oracle.set_heuristic(want)
+        f.oracle.set_sort_mode(1)
+        for qi, q in enumerate(f.queries):
+            s_ids, s_d = f.oracle.query(q, 500, rows)
+            kk = min(50, len(s_ids))
+            assert int(cnt[qi]) == len(s_ids)
+            assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])) and np.array_equal(ids[qi, :kk], s_ids[:kk])
+    finally:
+        f.oracle.set_heuristic(f.heur)
+        f.oracle.set_sort_mode(0)
+        idx.close()
