@@ -56,7 +56,7 @@ struct pqt_index {
   float* d_cb2T = nullptr;  // cb2 re-tiled per cell as [S/4][C2] 16-byte vectors (coalesced row walks), when S % 4 == 0
   bool haveTree = false;
   // heuristic prefix (a3)
-  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr;
+  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr; uint32_t* d_heur4 = nullptr;
   uint64_t maxMultiIndex = 0;
   // bin store (a5)
   PqtBinEntry* d_table = nullptr; uint32_t* d_lower = nullptr; uint32_t tableBits = 0;
@@ -574,7 +574,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
       const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
-      const PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, He, Bv,
+      const PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, (idx->dbg & 4096u) ? nullptr : idx->d_heur4, He, Bv,
                               idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
                               idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
@@ -791,7 +791,7 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
+  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -894,6 +894,14 @@ static int uploadHeuristic(pqt_index* idx) {
   for (uint64_t r = 0; r < idx->heurRows; ++r) for (uint32_t pp = 0; pp < P; ++pp) h8[r * 8 + pp] = h16[r * P + pp];
   if ((rc = devAlloc(&idx->d_heur8, h8.size()))) return rc;
   if (!h8.empty()) HIPCHK(hipMemcpy(idx->d_heur8, h8.data(), h8.size() * 2, hipMemcpyHostToDevice));
+  // packed rows (4 x u8 in one dword) for P <= 4 and digits < 256: the traversal requests them a block ahead
+  if (idx->d_heur4) { (void)hipFree(idx->d_heur4); idx->d_heur4 = nullptr; }
+  if (P <= 4 && idx->dp.WC <= 256) {
+    std::vector<uint32_t> h4(std::max<uint64_t>(idx->heurRows, 1), 0u);
+    for (uint64_t r = 0; r < idx->heurRows; ++r) for (uint32_t pp = 0; pp < P; ++pp) h4[r] |= (uint32_t)h16[r * P + pp] << (8 * pp);
+    if ((rc = devAlloc(&idx->d_heur4, h4.size()))) return rc;
+    HIPCHK(hipMemcpy(idx->d_heur4, h4.data(), h4.size() * 4, hipMemcpyHostToDevice));
+  }
   return PQT_OK;
 }
 

@@ -1254,6 +1254,7 @@ struct PqtTravArgs {
   const float4* cb2T;  // per (p,c1): [S/4][C2] 16-byte vectors, or null when S % 4 != 0
   PqtDevParams prm;
   const uint4* heur8;  // rows of 8 x u16
+  const uint32_t* heur4;  // rows of 4 x u8 (P <= 4 and W*C2 <= 256), or null: one dword per row, cheap to request ahead
   uint32_t He, Bv;
   const PqtBinEntry* table; const uint32_t* lower; uint32_t tableBits;
   const uint32_t* ids; uint32_t qn;
@@ -1323,6 +1324,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   uint32_t* sSegB = (uint32_t*)(sSegD + P * WC);    // P*WC sorted bin parts (pre-multiplied)
 
   PQT_TS(0);
+  const uint32_t* __restrict__ heur4 = A.heur4;
   for (uint32_t i = lane; i < D; i += 64) sQ[i] = Q[(size_t)q * D + i];
   __builtin_amdgcn_wave_barrier();
   // ---- a1 (UA accumulators per lane in flight: their cb1 reads overlap; 8 sixteen-byte reads when the shape is known)
@@ -1532,8 +1534,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   // ---- a4 + a5: 8 rows per lane and block of 512 rows, row h = hb + lane + 64*r
   uint64_t key[8];
   uint32_t recG[8], recL[8];  // population of the row's bin (0: empty), start of its members (sharded: table slot)
-  auto rowKey = [&](const uint32_t h, const uint4 hv, uint32_t& globOut) -> uint64_t {
-    const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
+  auto rowKey = [&](const uint32_t h, const uint32_t (&dg)[8], uint32_t& globOut) -> uint64_t {
     float fine = 0.f;
     uint32_t g = 0;
 #pragma unroll
@@ -1547,16 +1548,40 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     globOut = g;
     return ((uint64_t)pqt_f2key(fine) << 32) | h;
   };
+  uint32_t hw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto rowBlock = [&](const uint32_t hb) {
+    // packed table (one dword per row): the rows of the NEXT block of a wide enumeration are requested while this one is
+    // processed (8 VGPRs; wide traversal 0.272 -> 0.247 ms).  Requesting the first block at kernel start was measured as
+    // well: it costs the short enumeration 6 % (8 more registers live through a1/a2), so the first block is read here.
     uint32_t glob[8];
+    uint32_t cur[8];
+    if (heur4 && hb == 0) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const uint32_t h = lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cur[r] = hw[r];
+    if (heur4 && hb + 512 < He) {  // next block's rows, consumed one iteration later
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { const uint32_t h = hb + 512 + lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const uint32_t h = hb + lane + 64 * r;
       key[r] = ~0ull;
       glob[r] = 0;
-      // (requesting the first block's rows at kernel start, before a1, was measured: 32 more live VGPRs spill at 5 waves
-      // per SIMD and a2 slows down by more than the round trip saved)
-      if (h < He) key[r] = rowKey(h, heur8[h] /* one 16-byte read: the row's P digits */, glob[r]);
+      if (h < He) {
+        if (heur4) {
+          const uint32_t dg[8] = {cur[r] & 0xffu, (cur[r] >> 8) & 0xffu, (cur[r] >> 16) & 0xffu, cur[r] >> 24, 0u, 0u, 0u, 0u};
+          key[r] = rowKey(h, dg, glob[r]);
+        } else {
+          // (requesting the 16-byte rows ahead was measured: 32 more live VGPRs spill at 5 waves per SIMD and a2 slows
+          // down by more than the round trip saved)
+          const uint4 hv = heur8[h];  // one 16-byte read: the row's P digits
+          const uint32_t dg[8] = {hv.x & 0xffffu, hv.x >> 16, hv.y & 0xffffu, hv.y >> 16, hv.z & 0xffffu, hv.z >> 16, hv.w & 0xffffu, hv.w >> 16};
+          key[r] = rowKey(h, dg, glob[r]);
+        }
+      }
     }
     // probes: first touch of all 8 slots is issued before any is consumed
     const uint4* table4 = reinterpret_cast<const uint4*>(table);  // {key, gcount, lstart, lcount}
