@@ -8,6 +8,7 @@
 // reference whenever no two keys are exactly equal, and is the stable order otherwise.
 #pragma once
 #include "pqt_device.h"
+#include "pqt_wave.h"
 
 #define PQT_BLOCK 256
 
@@ -578,14 +579,20 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
   // line codes: for each line part, search all pairs A < B.  pair index e enumerates (A,B) in the
   // reference's scan order; reduce by (error key, e) so the first minimum wins like its strict '<'.
   const uint32_t npairs = C1 * (C1 - 1) / 2;
+  // a thread evaluates the same pairs e = tid + 256 i for every line part: decode them ONCE (the row-major walk costs up to
+  // C1 steps per pair and used to run LP times per pair -- two thirds of this kernel's instructions)
+  constexpr int kPairCache = 8;  // pairs per thread kept in registers: covers C1 <= 64
+  uint32_t pairAB[kPairCache];
+#pragma unroll
+  for (int i = 0; i < kPairCache; ++i) {
+    const uint32_t e = tid + PQT_BLOCK * i;
+    uint32_t A = 0, rem = e;
+    if (e < npairs) { while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; } }
+    pairAB[i] = A | ((A + 1 + rem) << 16);
+  }
   for (uint32_t lp = 0; lp < LP; ++lp) {
     uint64_t best = ~0ull;
-    for (uint32_t e = tid; e < npairs; e += PQT_BLOCK) {
-      // decode e -> (A,B), A<B, row-major over A
-      uint32_t A = 0, rem = e;
-      // rows have C1-1-A entries
-      while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; }
-      const uint32_t B = A + 1 + rem;
+    auto eval = [&](const uint32_t e, const uint32_t A, const uint32_t B) {
       const float sb = sVirt[lp * C1 + A], sa = sVirt[lp * C1 + B];
       const float sc = coarse[((size_t)lp * C1 + A) * C1 + B];
       const float lam = pqt_calc_ratio(sa, sb, sc);
@@ -595,15 +602,30 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
         const uint64_t key = ((uint64_t)pqt_f2key(err) << 32) | e;
         if (key < best) best = key;
       }
+    };
+#pragma unroll
+    for (int i = 0; i < kPairCache; ++i) {
+      const uint32_t e = tid + PQT_BLOCK * i;
+      if (e < npairs) eval(e, pairAB[i] & 0xffffu, pairAB[i] >> 16);
     }
-    sRed[tid] = best;
+    for (uint32_t e = tid + PQT_BLOCK * kPairCache; e < npairs; e += PQT_BLOCK) {
+      // e -> (A,B), A<B, row-major over A (rows have C1-1-A entries)
+      uint32_t A = 0, rem = e;
+      while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; }
+      eval(e, A, A + 1 + rem);
+    }
+    // minimum over the block: butterfly inside each wavefront, then the 4 wave minima through LDS
+    { uint64_t o = pqt_lane_xor_u64<1>(best); best = o < best ? o : best; }
+    { uint64_t o = pqt_lane_xor_u64<2>(best); best = o < best ? o : best; }
+    { uint64_t o = pqt_lane_xor_u64<4>(best); best = o < best ? o : best; }
+    { uint64_t o = pqt_lane_xor_u64<8>(best); best = o < best ? o : best; }
+    { uint64_t o = pqt_lane_xor_u64<16>(best); best = o < best ? o : best; }
+    { uint64_t o = pqt_lane_xor_u64<32>(best); best = o < best ? o : best; }
+    if ((tid & 63u) == 0) sRed[tid >> 6] = best;
     __syncthreads();
-    for (uint32_t s = PQT_BLOCK / 2; s > 0; s >>= 1) {
-      if (tid < s) { const uint64_t o = sRed[tid + s]; if (o < sRed[tid]) sRed[tid] = o; }
-      __syncthreads();
-    }
     if (tid == 0) {
-      const uint64_t w = sRed[0];
+      uint64_t w = sRed[0];
+      for (uint32_t wv = 1; wv < PQT_BLOCK / 64; ++wv) w = sRed[wv] < w ? sRed[wv] : w;
       uint32_t code;
       if (w == ~0ull) {
         code = pqt_lambda_encode(0.f) << 16;  // best_id_A = best_id_B = 0, best_lambda = 0 (initial values, :362-365)
@@ -649,7 +671,6 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 //     (pqt_wave_sort_u64<8>, 512 keys) and the first 128 become the new best.  Distances never touch HBM.
 // LDS: coarse (optional) + NW * (LP*C1*4 + 384*8) bytes.
 // ===================================================================================================
-#include "pqt_wave.h"
 
 #define PQT_RS_BEST 128
 #ifndef PQT_RS_PEND
