@@ -66,7 +66,7 @@ struct pqt_index {
   uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
   uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
   float* d_bias = nullptr; bool biasReady = false; bool adcBias = false; bool exactFilter = true; float coarseMax = 0.f;
-  unsigned long long* d_runs = nullptr; uint32_t* d_runGpos = nullptr; uint32_t* d_nRuns = nullptr; uint64_t runsCap = 0; bool useRuns = false; bool lastRuns = false;
+  unsigned long long* d_runs = nullptr; uint32_t* d_runGpos = nullptr; uint32_t* d_nRuns = nullptr; uint64_t runsCap = 0; int useRuns = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastRuns = false; uint32_t curRunCap = 0;
   uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
    // opt-in adc_bias mode: per-row query-independent part of the ADC sum
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
@@ -272,7 +272,7 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                         idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8,
                         nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
-                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns};
+                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -354,7 +354,7 @@ PqtRsArgs rsArgsFilter(pqt_index* idx, const float* qL1virt, const uint32_t* nLo
   return PqtRsArgs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                    idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
                    (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
-                   idx->d_fbList, idx->d_fbCount, nullptr, nullptr, nullptr};
+                   idx->d_fbList, idx->d_fbCount, idx->curRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap};
 }
 template <int NW, int LPV, bool SH, int MODE>
 int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
@@ -363,6 +363,8 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
   const uint32_t c1 = idx->dp.C1;
   auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, MODE>
                                                                                          : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, MODE>;
+  constexpr bool kRunsVariant = MODE == 2 && NW == 12 && LPV == 8;  // bin runs: BASELINE configs[2]/[3] shape only
+  if constexpr (kRunsVariant) { if (idx->curRuns) kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, 2, true>; }
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   const PqtRsArgs rargs = rsArgsFilter(idx, qL1virt, nLocal, stride, k, nq, oI, oD, oP);
@@ -372,7 +374,8 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
     // queries whose near-tie band overflowed the wave's list (normally none): plain exact kernel on that list
     constexpr int LNW = 4;
     auto lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1>;
-    const size_t llds = (size_t)LNW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
+    size_t llds = (size_t)LNW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
+    if constexpr (kRunsVariant) { if (idx->curRuns) { lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1, true>; llds = ((llds + 15) & ~(size_t)15) + (size_t)LNW * idx->curRunCap * 12; } }
     if ((rc = allowLds(lk, llds))) return rc;
     PqtRsArgs largs = rargs;
     largs.tstamp = nullptr; largs.dynamic = 0; largs.zero8 = nullptr;
@@ -536,8 +539,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   // which needs LP*C1*4 bytes only
   if (fused && !wgG && lFused > kMaxLds) fused = false;
   // bin runs instead of a candidate list: fused traversal -> MODE 0 rerank with the LDS table (the SIFT1M shapes)
+  // bin runs instead of a candidate list.  MODE 0 with the LDS table (SIFT1M shape): only on request (measured a net loss);
+  // MODE 2 at the configs[2]/[3] shape (long bins, few runs per query: 64 slots per wave): on unless switched off.
   const size_t lRuns = ((lFused + 15) & ~(size_t)15) + (size_t)kFusedWaves * PQT_RUNCAP * 12;
-  const bool emitRuns = idx->useRuns && travFused && fused && coarseLds && !useBias && !wgG && lRuns <= kMaxLds && d.C1 == 32 && d.LP == 16;
+  const size_t lRunsBig = ((lBias12 + 15) & ~(size_t)15) + (size_t)12 * 64 * 12;
+  const bool runsSmall = idx->useRuns == 1 && travFused && fused && coarseLds && !useBias && !wgG && lRuns <= kMaxLds && d.C1 == 32 && d.LP == 16;
+  const bool runsBig = idx->useRuns != 0 && travFused && useFilter && biasNW == 12 && d.C1 == 64 && d.LP == 32 && lRunsBig <= kMaxLds;
+  const bool emitRuns = runsSmall || runsBig;
+  idx->curRunCap = runsBig ? 64u : (uint32_t)PQT_RUNCAP;
   if (emitRuns && (uint64_t)qChunk * PQT_RUNCAP > idx->runsCap) {
     if ((rc = devAlloc(&idx->d_runs, (size_t)qChunk * PQT_RUNCAP))) return rc;
     if ((rc = devAlloc(&idx->d_runGpos, (size_t)qChunk * PQT_RUNCAP))) return rc;
@@ -579,7 +588,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
                               (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
-                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, (idx->dbg >> 5) & 1u};
+                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, (idx->dbg >> 5) & 1u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
@@ -652,8 +661,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         nextZeroed = true;
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         const uint32_t* nl = idx->d_nLocal + q0;
-#define PQT_LAUNCH_BIAS1(NWV, LPVV, MD) (idx->sharded ? launchRSBias<NWV, LPVV, true, MD>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
-                                                      : launchRSBias<NWV, LPVV, false, MD>(idx, grid, NWV == 12 ? lBias12 : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
+#define PQT_LAUNCH_BIAS1(NWV, LPVV, MD) (idx->sharded ? launchRSBias<NWV, LPVV, true, MD>(idx, grid, NWV == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
+                                                      : launchRSBias<NWV, LPVV, false, MD>(idx, grid, NWV == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
 #define PQT_LAUNCH_BIAS(NWV, LPVV) (useFilter ? PQT_LAUNCH_BIAS1(NWV, LPVV, 2) : PQT_LAUNCH_BIAS1(NWV, LPVV, 1))
         rc = d.LP == 16 ? (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 4) : PQT_LAUNCH_BIAS(6, 4)) : (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 8) : PQT_LAUNCH_BIAS(6, 8));
 #undef PQT_LAUNCH_BIAS1
@@ -822,7 +831,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // materialising the candidate list.  Measured r02 (SIFT1M shape): traversal 0.066 -> 0.057 ms, but the rerank's expansion
   // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
-  if (strcmp(name, "bin_runs") == 0) { idx->useRuns = (value != 0); return PQT_OK; }
+  if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }

@@ -712,6 +712,7 @@ struct PqtRsArgs {
   // position | first store position << 32) of the included bins in visiting order, nRuns[q] = their number or 0xffffffff
   // when the traversal wrote the plain list after all; runGpos (sharded) = global visiting position of a run's first member
   const unsigned long long* runs; const uint32_t* runGpos; const uint32_t* nRuns;
+  uint32_t runCap;  // run slots of a wavefront's LDS area (64 or PQT_RUNCAP); the traversal hands over at most this many
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -764,7 +765,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   // Bin runs (MODE 0 with the LDS table): the traversal hands over the included bins as (first visiting position, first
   // store position) pairs instead of one store position per candidate; candidate j's row is found by a 7-step search
   // over <= 128 LDS entries -- no candidate list in HBM, no id round trip in front of the row round trip.
-  constexpr bool kRuns = RUNS && MODE == 0 && COARSE_LDS;  // experimental, off by default (pqt_index_set_option "bin_runs")
+  constexpr bool kRuns = RUNS;  // compiled as separate variants (pqt_index_set_option "bin_runs")
   uint32_t mRuns = 0xffffffffu;
   // the run count and this lane's two run slots are requested together (one round trip; slots beyond the count hold
   // stale words that are masked below)
@@ -773,11 +774,11 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     if (sRuns && A.nRuns) {
       mRuns = A.nRuns[q];
       rr0 = A.runs[(size_t)q * PQT_RUNCAP + lane];
-      rr1 = A.runs[(size_t)q * PQT_RUNCAP + 64 + lane];
+      if (A.runCap > 64) rr1 = A.runs[(size_t)q * PQT_RUNCAP + 64 + lane];
     }
   }
   const bool useRuns = kRuns && mRuns != 0xffffffffu;
-  uint32_t* const sRunG = reinterpret_cast<uint32_t*>(sRuns + PQT_RUNCAP);
+  uint32_t* const sRunG = reinterpret_cast<uint32_t*>(sRuns + A.runCap);
   // runs `lane` and `64 + lane` also live in registers: a batch of 64 consecutive candidates spans a handful of runs, which
   // are broadcast one after the other (v_readlane with a uniform index) -- no search, no LDS latency on the row path
   uint32_t rs0 = 0xffffffffu, rl0 = 0, rs1 = 0xffffffffu, rl1 = 0;
@@ -1080,7 +1081,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         xk[r] = ~0ull;
         if (e < nT) {
           const uint32_t j = (uint32_t)sKeys[e];
-          const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)cid[j] * LP);
+          uint32_t posj;
+          if (useRuns) { const unsigned long long rr = sRuns[runOf(j)]; posj = (uint32_t)(rr >> 32) + (j - (uint32_t)rr); }
+          else posj = cid[j];
+          const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)posj * LP);
           float acc = 0.f;
 #pragma unroll
           for (int v = 0; v < LPV; ++v) {
@@ -1173,8 +1177,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   uint32_t* sListN = sList + PQT_RS_LIST;    // PQT_RS_LIST: its candidate count
   uint32_t* sTmpN = sListN + PQT_RS_LIST;    // PQT_RS_LIST: counts in list order (ranking input)
   // per-wave bin-run area (MODE 0 with the LDS table only; the launcher sizes the LDS accordingly)
-  unsigned long long* sRuns = (RUNS && MODE == 0 && COARSE_LDS && A.runs)
-      ? reinterpret_cast<unsigned long long*>(smem_raw + ((ticketOff + 16 + 3 * PQT_RS_LIST * 4 + 15) & ~(size_t)15)) + (size_t)wave * (PQT_RUNCAP + PQT_RUNCAP / 2)
+  unsigned long long* sRuns = (RUNS && A.runs)
+      ? reinterpret_cast<unsigned long long*>(smem_raw + ((ticketOff + 16 + 3 * PQT_RS_LIST * 4 + 15) & ~(size_t)15)) + (size_t)wave * (A.runCap + A.runCap / 2)
       : nullptr;
   const uint32_t L = (dynamic && blockIdx.x < qn) ? (qn - blockIdx.x + G - 1) / G : 0u;
   const uint32_t Ls = L < PQT_RS_LIST ? L : PQT_RS_LIST;
@@ -1240,7 +1244,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
 }
 
 // the queries MODE 2 handed back (fbList): plain exact rerank+select (MODE 0, coarse through L2), one wavefront per list entry
-template <int NW, int LPV, int UREQ, bool SHARDED, int C1M>
+template <int NW, int LPV, int UREQ, bool SHARDED, int C1M, bool RUNS = false>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select_list(const PqtRsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t LP = LPV * 4;
@@ -1252,7 +1256,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select_list(const PqtRsA
   for (uint32_t e = blockIdx.x * NW + wave; e < cnt; e += gridDim.x * NW) {
     const uint32_t q = A.qlist[e];
     uint32_t nN = 0;
-    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 0>(A, q, A.nLocal[q], sKeys, sVirt, A.coarse, 0xffffffffu, nN, 0u);
+    unsigned long long* sRuns = (RUNS && A.runs)
+        ? reinterpret_cast<unsigned long long*>(smem_raw + (((size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4) + 15) & ~(size_t)15)) + (size_t)wave * (A.runCap + A.runCap / 2)
+        : nullptr;
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 0, RUNS>(A, q, A.nLocal[q], sKeys, sVirt, A.coarse, 0xffffffffu, nN, 0u, sRuns);
   }
 }
 
@@ -1286,6 +1293,7 @@ struct PqtTravArgs {
   uint32_t* ovList; uint32_t* ovCount;  // queries handed to pqt_k_bins (He > 512 and > 512 populated rows)
   const uint32_t* filter; uint32_t filterBits;  // presence bitmap over the bin keys, or null
   unsigned long long* runs; uint32_t* runGpos; uint32_t* nRuns;  // bin runs for the rerank (see PqtRsArgs), or null
+  uint32_t runCap;  // at most this many runs are handed over (more: the plain candidate list is written)
   uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
 };
 
@@ -1687,7 +1695,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       PQT_TS(7);
       if (A.runs) {
         // hand the compact list itself to the rerank when it fits: no candidate list is written
-        if (m <= PQT_RUNCAP) {
+        if (m <= A.runCap) {
           for (uint32_t i = lane; i < m; i += 64) A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i];
           if (lane == 0) A.nRuns[q] = m;
           return totNe;
@@ -1759,7 +1767,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; }
       PQT_TS(7);
       if (A.runs) {
-        if (m <= PQT_RUNCAP) {
+        if (m <= A.runCap) {
           for (uint32_t i = lane; i < m; i += 64) { A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i]; A.runGpos[(size_t)q * PQT_RUNCAP + i] = sGpos[i]; }
           if (lane == 0) A.nRuns[q] = m;
           return totNe;

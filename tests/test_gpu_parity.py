@@ -693,6 +693,11 @@ def test_big_coarse_exact_filter_matches_workgroup_kernel_and_falls_back_on_tie_
             idx.set_option("exact_filter", 0)
             b = idx.query(f.queries, bv, bb, 100)
             assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+            # bin runs (default at the configs[2]/[3] shape) against the materialised candidate list
+            idx.set_option("exact_filter", 1)
+            idx.set_option("bin_runs", 0)
+            c = idx.query(f.queries, bv, bb, 100)
+            assert np.array_equal(a[0], c[0]) and np.array_equal(bits(a[1]), bits(c[1])) and np.array_equal(a[2], c[2])
         finally:
             idx.close()
 
@@ -706,22 +711,25 @@ def test_big_coarse_exact_filter_matches_workgroup_kernel_and_falls_back_on_tie_
         x[noisy] = np.clip(np.rint(x[noisy] + rng.normal(0, 25, (int(noisy.sum()), D))), 0, 255)
         return x.astype(np.float32)
 
-    f = Fixture(D=64, P=2, C1=32, C2=4, W=2, LP=32, n_base=12000, n_query=8, seed=68, heur_rows=64, train=3000, data=clustered)
-    idx = f.hip_index()
-    try:
-        ids, dist, cnt = idx.query(f.queries, 10 ** 6, 64, 100)
-        st = idx.stats()
-        assert st["filter_fallbacks"] > 0, "fixture no longer overflows the band"
-        f.oracle.set_sort_mode(1)
-        for qi, q in enumerate(f.queries):
-            s_ids, s_d = f.oracle.query(q, 10 ** 6, 64)
-            kk = min(100, len(s_ids))
-            assert int(cnt[qi]) == len(s_ids)
-            assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), qi
-            assert np.array_equal(ids[qi, :kk], s_ids[:kk]), qi
-    finally:
-        f.oracle.set_sort_mode(0)
-        idx.close()
+    # C1 = 32: candidate lists; C1 = 64 with 32 line parts: the variant that receives bin runs (the fallback kernel then
+    # expands the runs itself)
+    for C1 in (32, 64):
+        f = Fixture(D=64, P=2, C1=C1, C2=4, W=2, LP=32, n_base=12000, n_query=8, seed=68, heur_rows=64, train=3000, data=clustered)
+        idx = f.hip_index()
+        try:
+            ids, dist, cnt = idx.query(f.queries, 10 ** 6, 64, 100)
+            st = idx.stats()
+            assert st["filter_fallbacks"] > 0, "fixture no longer overflows the band"
+            f.oracle.set_sort_mode(1)
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, 10 ** 6, 64)
+                kk = min(100, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), (C1, qi)
+                assert np.array_equal(ids[qi, :kk], s_ids[:kk]), (C1, qi)
+        finally:
+            f.oracle.set_sort_mode(0)
+            idx.close()
 
 
 def test_config5_shape_follows_the_reference_no_bins_enumerated():
