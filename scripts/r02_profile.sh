@@ -15,7 +15,11 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$t
 cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/prof/ 2>/dev/null
 fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_${tag}_$c -o $tag -- python bench.py --no-cpu --no-gt --steps 5 --warmup 2 $args > /dev/null 2> gpurun_out/prof/${tag}_pmc_$c.log
+  # (rocprofv3 --pmc occasionally hangs at process start on this image: bounded, one retry)
+  for attempt in 1 2; do
+    rm -rf /tmp/prof_${tag}_$c
+    timeout ${PQT_PMC_TIMEOUT:-240} rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_${tag}_$c -o $tag -- python bench.py --no-cpu --no-gt --steps 5 --warmup 2 $args > /dev/null 2> gpurun_out/prof/${tag}_pmc_$c.log && break
+  done
   python - <<PY
 import csv, collections, glob
 fn = glob.glob('/tmp/prof_${tag}_$c/*counter_collection.csv')
