@@ -490,7 +490,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 
   // fused traversal (wave per query) when the bin list fits the in-register sorter
   const bool travFused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
-  const bool travWide = travFused && He > 512;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
+  const bool travWide = travFused && He > 512;
+  // the short fused traversal writes the caller's candidate counts itself (no device-to-device copy on the stream); the wide
+  // one can hand queries to pqt_k_bins, which fills them in later: copy at the end
+  const bool countDirect = outCount && travFused && !travWide;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
   const size_t travR0 = (std::max<size_t>(travWide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
   const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
   const size_t lTrav = (size_t)kTravWaves * travPerWave;
@@ -588,7 +591,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
                               (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
-                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, (idx->dbg >> 5) & 1u};
+                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
+                              countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
@@ -730,7 +734,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 #undef PQT_REC
   if (!nextZeroed) HIPCHK(hipMemsetAsync(nextCtr, 0, 8 * sizeof(unsigned long long), st));
   idx->ctrPos = (idx->ctrPos + 1) % kCtrRing;
-  if (outCount) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
+  if (outCount && !countDirect) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512

@@ -1294,6 +1294,7 @@ struct PqtTravArgs {
   const uint32_t* filter; uint32_t filterBits;  // presence bitmap over the bin keys, or null
   unsigned long long* runs; uint32_t* runGpos; uint32_t* nRuns;  // bin runs for the rerank (see PqtRsArgs), or null
   uint32_t runCap;  // at most this many runs are handed over (more: the plain candidate list is written)
+  uint32_t* outCount;  // the caller's per-query candidate count, written here directly (saves a copy on the stream), or null
   uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
 };
 
@@ -1691,7 +1692,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         if (g8[r]) { sBin[wpos] = (uint64_t)ex8[r] | ((uint64_t)ls8[r] << 32); ++wpos; }
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; }
+      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; if (A.outCount) A.outCount[q] = totCand; }
       PQT_TS(7);
       if (A.runs) {
         // hand the compact list itself to the rerank when it fits: no candidate list is written
@@ -1764,7 +1765,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         if (lc8[r]) { sBin[wpos] = (uint64_t)lrun | ((uint64_t)ls8[r] << 32); sGpos[wpos] = gp8[r]; ++wpos; lrun += lc8[r]; }
       }
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; }
+      if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; if (A.outCount) A.outCount[q] = totCand; }
       PQT_TS(7);
       if (A.runs) {
         if (m <= A.runCap) {
