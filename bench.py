@@ -13,7 +13,8 @@ Multi-GPU (--gpus N > 1), one process per GPU:
   * default = the north-star layout: the database is RANGE-SHARDED by vector id (every rank synthesises, assigns and
     line-encodes only its own id range, chunk by chunk; the per-bin global populations come from one all-gather at
     build time), every rank runs the traversal for the whole batch, reranks its own slice, and the per-shard top-k
-    lists are merged after ONE RCCL all-gather per batch => "scaling": "strong", value = QN*steps / time.
+    lists are exchanged over RCCL by query slice (all-to-all), merged, and the merged slices all-gathered
+    (--exchange allgather: one all-gather of the whole lists) => "scaling": "strong", value = QN*steps / time.
     Workload: BASELINE.json configs[2] shape, 100 M vectors (fits one GPU, so the same database is also timed on rank 0
     alone after the timed region: config.same_workload_1gpu, the denominator of the strong-scaling ratio); with
     --gpus 8 the default is configs[3]'s size, 1 B vectors (125 M per GPU).  --workload overrides either.
@@ -302,6 +303,8 @@ def main():
                     "opt-in ADC modes); off by default so that a profile of the default command contains only the headline path's launches")
     ap.add_argument("--shard-db", action="store_true", help="(default for --gpus N > 1) range-shard the database")
     ap.add_argument("--replicas", action="store_true", help="multi-GPU: replicate the index and shard the queries instead (weak scaling, no collective)")
+    ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"],
+                    help="range-sharded run: per-shard top-k exchanged by query slice (all-to-all, merged slices all-gathered) or by one all-gather of the whole lists")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
@@ -394,7 +397,7 @@ def main():
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
         else:
             # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
-            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf)
+            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf, exchange=args.exchange)
 
     def barrier():
         if world > 1:
@@ -517,8 +520,11 @@ def main():
                                (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
                    "workload_name": wl_name,
                    "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
-                                   "shard_db": "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), traversal replicated, "
-                                               "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge" % (world, n_local)}[mode],
+                                   "shard_db": "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), traversal replicated, %s"
+                                               % (world, n_local, "per-shard top-k exchanged by query slice (all-to-all of [3][QN/W][k] words per peer), exact (dist,pos) merge "
+                                                  "of the own slice, all-gather of the merged [2][QN/W][k] slices" if args.exchange == "alltoall" else
+                                                  "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge of all queries on every rank")}[mode],
+                   "exchange": args.exchange if mode == "shard_db" else None,
                    "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if world > 1 else None), "collective_world_size": world,
                    "options": args.option,
                    "global_batch": units,

@@ -363,8 +363,8 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
   const uint32_t c1 = idx->dp.C1;
   auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, MODE>
                                                                                          : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, MODE>;
-  constexpr bool kRunsVariant = MODE == 2 && NW == 12 && LPV == 8;  // bin runs: BASELINE configs[2]/[3] shape only
-  if constexpr (kRunsVariant) { if (idx->curRuns) kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, 2, true>; }
+  constexpr bool kRunsVariant = NW == 12 && LPV == 8;  // bin runs: BASELINE configs[2]/[3] shape only
+  if constexpr (kRunsVariant) { if (idx->curRuns) kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE, true>; }
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   const PqtRsArgs rargs = rsArgsFilter(idx, qL1virt, nLocal, stride, k, nq, oI, oD, oP);
@@ -547,7 +547,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t lRuns = ((lFused + 15) & ~(size_t)15) + (size_t)kFusedWaves * PQT_RUNCAP * 12;
   const size_t lRunsBig = ((lBias12 + 15) & ~(size_t)15) + (size_t)12 * 64 * 12;
   const bool runsSmall = idx->useRuns == 1 && travFused && fused && coarseLds && !useBias && !wgG && lRuns <= kMaxLds && d.C1 == 32 && d.LP == 16;
-  const bool runsBig = idx->useRuns != 0 && travFused && useFilter && biasNW == 12 && d.C1 == 64 && d.LP == 32 && lRunsBig <= kMaxLds;
+  const bool runsBig = idx->useRuns != 0 && travFused && useBias && biasNW == 12 && d.C1 == 64 && d.LP == 32 && lRunsBig <= kMaxLds;
   const bool emitRuns = runsSmall || runsBig;
   idx->curRunCap = runsBig ? 64u : (uint32_t)PQT_RUNCAP;
   if (emitRuns && (uint64_t)qChunk * PQT_RUNCAP > idx->runsCap) {

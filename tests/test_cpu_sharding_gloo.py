@@ -8,6 +8,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -54,7 +55,7 @@ class OracleShardEngine:
             out_dist[qi] = torch.from_numpy(d[order])
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="alltoall"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,10 +66,10 @@ def _worker(rank, world, port, q):
         n = fx.oracle.num_vectors
         lo, hi = sh.shard_range(rank, world, n)
         eng = OracleShardEngine(fx, lo, hi)
-        queries = torch.from_numpy(fx.queries[:6])
+        queries = torch.from_numpy(fx.queries[:7])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded
         k, bv, bb = 20, 300, 100
         buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu")
-        oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf)
+        oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange)
         ok = True
         fx.oracle.set_sort_mode(1)
         for qi in range(queries.shape[0]):
@@ -136,15 +137,18 @@ def test_shard_ranges_partition():
             assert max(hi - lo for lo, hi in r) - min(hi - lo for lo, hi in r) <= 1
 
 
-def test_two_rank_gloo_sharded_query_equals_unsharded():
+@pytest.mark.parametrize("world,exchange", [(2, "alltoall"), (3, "alltoall"), (2, "allgather")])
+def test_gloo_sharded_query_equals_unsharded(world, exchange):
+    """6 queries over 2 or 3 ranks (3: the query slices are padded, qn % world != 0 for the rows of the last slice): exchange
+    by query slice (all-to-all + all-gather of the merged slices) and the single all-gather give the unsharded result."""
     fixture("odd")  # build once before forking
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
