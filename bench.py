@@ -145,13 +145,13 @@ def chunk_ranges(w, lo, hi):
     return out
 
 
-def make_codebooks(w, dev, dist=None, world=1):
+def make_codebooks(w, dev, dist=None, world=1, force_collectives=False):
     """Tree of the benchmark index; rank 0's codebooks are broadcast (the k-means M step uses atomics: not bit-reproducible)."""
     D, P, C1, C2 = (w[k] for k in ("D", "P", "C1", "C2"))
     train = sift_like(w["n_train"], D, 0xC0DE01, dev)
     cb1, cb2 = train_codebooks(train, P, C1, C2, 0xC0DE04)
     del train
-    if world > 1:
+    if world > 1 or (force_collectives and dist is not None):
         t1, t2 = torch.from_numpy(cb1).to(dev), torch.from_numpy(cb2).to(dev)
         dist.broadcast(t1, 0)
         dist.broadcast(t2, 0)
@@ -159,7 +159,7 @@ def make_codebooks(w, dev, dist=None, world=1):
     return cb1, cb2
 
 
-def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codebooks=None):
+def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codebooks=None, force_collectives=False):
     """Synthesise the database chunk by chunk with the product's own build kernel (insert = id() + prepareReranking) and load
     it into a PqtIndex.  shard = (lo, hi): only that id range is generated, encoded and held (range shard built by the
     shard itself; the per-bin global counts come from ONE all-gather, sharding.global_bin_counts).
@@ -170,7 +170,7 @@ def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codeb
     n = w["n_base"]
     lo, hi = shard if shard is not None else (0, n)
     t0 = time.time()
-    cb1, cb2 = codebooks if codebooks is not None else make_codebooks(w, dev, dist, world)
+    cb1, cb2 = codebooks if codebooks is not None else make_codebooks(w, dev, dist, world, force_collectives)
     idx = pkg.PqtIndex(D, P, C1, C2, W, LP, device=dev_index)
     idx.set_codebooks(cb1, cb2)
     nl = hi - lo
@@ -202,7 +202,7 @@ def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codeb
         idx.set_lines_dev(codes, 0)
         meta.update(n_bins=int(bin_ids.shape[0]), max_bin=int(sizes.max()), bin_ids=bin_ids, sizes=sizes, members=mem)
     else:
-        uk, gs, low, ls = sharding.global_bin_counts(dist, world, rank, keys, counts)
+        uk, gs, low, ls = sharding.global_bin_counts(dist, world, rank, keys, counts, force_collectives)
         assert int(gs.max()) < 2 ** 32 and int(gs.sum()) == n, "global bin counts do not add up to the database size"
         idx.set_bins_local(uk.cpu().numpy(), gs.cpu().numpy(), low.cpu().numpy(), ls.cpu().numpy(), members.cpu().numpy(), n)
         idx.set_lines_dev(codes, lo)
@@ -226,7 +226,7 @@ def usable_cores(omp_max):
     return max(1, n)
 
 
-def brute_force_gt_chunked(w, queries, dev, lo=0, hi=None, dist=None, world=1):
+def brute_force_gt_chunked(w, queries, dev, lo=0, hi=None, dist=None, world=1, force_collectives=False):
     """Exact nearest neighbour over the chunk-generated database (chunks are regenerated from their seeds); with a range
     shard every rank scans its own ids and the per-query minimum is all-reduced (ties -> lowest id)."""
     hi = w["n_base"] if hi is None else hi
@@ -246,7 +246,7 @@ def brute_force_gt_chunked(w, queries, dev, lo=0, hi=None, dist=None, world=1):
             best_d[qa:qa + 2048] = torch.where(upd, v, best_d[qa:qa + 2048])
             best_i[qa:qa + 2048] = torch.where(upd, i + a, best_i[qa:qa + 2048])
         del x, bn
-    if world > 1:
+    if world > 1 or (force_collectives and dist is not None):
         gd = best_d.clone()
         dist.all_reduce(gd, op=dist.ReduceOp.MIN)
         best_i = torch.where(best_d == gd, best_i, torch.full_like(best_i, 2 ** 62))
@@ -321,8 +321,15 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     dist = None
     backend = None
-    if world > 1:
+    # PQT_BENCH_FORCE_SHARD=1: run the range-sharded layout with whatever world size there is -- with one rank this drives
+    # every collective of the path (broadcast, build-time all-gather, all-to-all / all-gather per batch, all-reduce) through
+    # RCCL on a 1-GPU box: an API/dtype check of the N > 1 code, not a measurement
+    force_shard = bool(os.environ.get("PQT_BENCH_FORCE_SHARD"))
+    if world > 1 or force_shard:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("PQT_BENCH_BACKEND", "nccl")  # "gloo" + PQT_BENCH_SAME_DEVICE=1: functional check on a 1-GPU box
         if os.environ.get("PQT_BENCH_SAME_DEVICE"):
@@ -342,14 +349,14 @@ def main():
     GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers, center_scale=args.center_scale)
     pkg = importlib.import_module("product-quantization-tree_amd")
     pkg.lib()  # fails loudly if the HIP library is missing
-    mode = "single" if world == 1 else ("replica" if args.replicas else "shard_db")
+    mode = "single" if (world == 1 and not force_shard) else ("replica" if args.replicas else "shard_db")
     wl_name = args.workload or ("sift1m" if mode != "shard_db" else ("synth1b" if world >= 8 else "synth100m"))
     w = WORKLOADS[wl_name]
     n = w["n_base"]
     sharding = importlib.import_module("product-quantization-tree_amd.sharding")
     shard = sharding.shard_range(rank, world, n) if mode == "shard_db" else None
     chunked = w.get("chunk", n) < n
-    idx, base, meta = build_index(pkg, w, local_rank, shard=shard, dist=dist, world=world if mode == "shard_db" else 1, rank=rank)
+    idx, base, meta = build_index(pkg, w, local_rank, shard=shard, dist=dist, world=world if mode == "shard_db" else 1, rank=rank, force_collectives=force_shard)
     for ov in args.option:
         name_, val_ = ov.split("=")
         idx.set_option(name_, int(val_))
@@ -378,7 +385,7 @@ def main():
         raw_u8 = base.to(torch.uint8) if args.extras else None  # raw vectors for the optional exact re-rank (8f-4)
     else:
         lo_, hi_ = shard if shard else (0, n)
-        gt = brute_force_gt_chunked(w, queries, dev, lo_, hi_, dist, world if mode == "shard_db" else 1)
+        gt = brute_force_gt_chunked(w, queries, dev, lo_, hi_, dist, world if mode == "shard_db" else 1, force_shard)
         raw_u8 = None
     del base
     torch.cuda.empty_cache()
@@ -397,10 +404,10 @@ def main():
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
         else:
             # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
-            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf, exchange=args.exchange)
+            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf, exchange=args.exchange, force_collectives=force_shard)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_shard:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -442,7 +449,7 @@ def main():
         step()
         barrier()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or force_shard:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -525,7 +532,7 @@ def main():
                                                   "of the own slice, all-gather of the merged [2][QN/W][k] slices" if args.exchange == "alltoall" else
                                                   "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge of all queries on every rank")}[mode],
                    "exchange": args.exchange if mode == "shard_db" else None,
-                   "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if world > 1 else None), "collective_world_size": world,
+                   "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if (world > 1 or force_shard) else None), "collective_world_size": world,
                    "options": args.option,
                    "global_batch": units,
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
@@ -731,7 +738,7 @@ def main():
         out["config"]["ranks_agree"] = bool(lo_c.item() == hi_c.item())
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_shard:
         dist.destroy_process_group()
 
 

@@ -46,14 +46,14 @@ def merge_bin_counts(all_keys, all_counts, rank):
     return uk, gsize, lower, lsize
 
 
-def global_bin_counts(dist, world, rank, keys, counts):
+def global_bin_counts(dist, world, rank, keys, counts, force_collectives=False):
     """Build-time exchange of a database built shard by shard (the CSR merge of test/test1B.cpp:783-871 reduced to the
     per-bin counts): every rank contributes (bin id, local population) of its non-empty bins through ONE padded
     all-gather and derives merge_bin_counts() of the gathered lists.
     keys/counts: int64 tensors (keys ascending, unique).  Returns (ukeys, gsize, lower, lsize) as int64 tensors."""
     dev = keys.device
     keys, counts = keys.to(torch.int64), counts.to(torch.int64)
-    if world == 1:
+    if world == 1 and not force_collectives:
         return keys, counts, torch.zeros_like(counts), counts
     n = torch.tensor([keys.numel()], dtype=torch.int64, device=dev)
     ns = torch.empty(world, dtype=torch.int64, device=dev)
@@ -98,7 +98,7 @@ class ShardBuffers:
         self.out_idx, self.out_dist = self.out_idx_pad[:qn], self.out_dist_pad[:qn]
 
 
-def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall"):
+def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False):
     """One step of the sharded hot path.  Returns (out_idx, out_dist, count) views into `buf`.
 
     exchange = "alltoall" (default): the per-shard top-k lists travel by query slice -- rank r gets from every shard only
@@ -111,7 +111,7 @@ def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall"):
     qn = q.shape[0]
     qs = buf.qs
     engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
-    if world == 1:
+    if world == 1 and not force_collectives:
         engine.merge_topk(1, qn, k, buf.pack[0], buf.pack[1].view(torch.float32), buf.pack[2], buf.out_idx, buf.out_dist, 3 * world * qs * k)
         return buf.out_idx, buf.out_dist, buf.count
     if exchange == "allgather":
