@@ -164,8 +164,15 @@ def build_index(pkg, w, dev_index, shard=None, dist=None, world=1, rank=0, codeb
     it into a PqtIndex.  shard = (lo, hi): only that id range is generated, encoded and held (range shard built by the
     shard itself; the per-bin global counts come from ONE all-gather, sharding.global_bin_counts).
     Returns (index, base vectors on the device if the database is a single unsharded chunk else None, meta)."""
-    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
     dev = torch.device("cuda", dev_index)
+    if torch.cuda.current_stream(dev).cuda_stream == 0:
+        # called on torch's legacy default stream (tests, scripts): its handle is NULL, which the C-ABI reads as "the handle's
+        # own non-blocking stream" -- not ordered with the data synthesis.  Build on an explicit stream instead.
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            out = build_index(pkg, w, dev_index, shard, dist, world, rank, codebooks, force_collectives)
+        torch.cuda.synchronize(dev)
+        return out
+    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
     D, P, C1, C2, W, LP = (w[k] for k in ("D", "P", "C1", "C2", "W", "LP"))
     n = w["n_base"]
     lo, hi = shard if shard is not None else (0, n)

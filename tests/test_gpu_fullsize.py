@@ -28,6 +28,8 @@ def big():
     idx, base, meta = bench.build_index(pkg, w, 0)
     idx.build_heuristic(500)
     queries = bench.sift_like(w["qn"], w["D"], 0xC0DE03, torch.device("cuda", 0))
+    torch.cuda.synchronize()  # the library enqueues on its own stream when handed torch's (NULL) default stream
+    assert meta["max_bin"] < 5000, "degenerate database (data synthesis and build kernel out of order?)"
     yield pkg, w, idx, base, meta, queries
     idx.close()
 
@@ -149,6 +151,8 @@ def big3():
     assert base is None  # chunk-built: the raw vectors are never resident as a whole
     idx.build_heuristic(4096)
     queries = bench.sift_like(512, w["D"], 0xC0DE03, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    assert meta["max_bin"] < 50000, "degenerate database (data synthesis and build kernel out of order?)"
     yield pkg, w, idx, meta, queries
     idx.close()
 
