@@ -40,6 +40,7 @@ def run(idx, q, bv, bb, k):
     oi = torch.empty((qn, k), dtype=torch.int32, device=q.device)
     od = torch.empty((qn, k), dtype=torch.float32, device=q.device)
     oc = torch.empty(qn, dtype=torch.int32, device=q.device)
+    torch.cuda.synchronize()  # q may be the product of a torch op still in flight on the default stream; the library uses its own
     idx.query_dev(q, bv, bb, k, oi, od, oc, sync=True)
     return oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy().view(np.uint32)
 
