@@ -969,7 +969,7 @@ int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_
   uint32_t b = std::min<uint32_t>(std::min<uint32_t>(max_cluster, 16u), idx->dp.WC);
   if (b == 0) return fail(PQT_ERR_INVALID, "max_cluster must be > 0");
   uint64_t nVec = 1;
-  for (uint32_t p = 0; p < P; ++p) { nVec *= b; if (nVec > (1ull << 32)) return fail(PQT_ERR_LIMIT, "min(16, max_cluster)^P tuples exceed 2^32"); }
+  for (uint32_t p = 0; p < P; ++p) { nVec *= b; if (nVec > (1ull << 26)) return fail(PQT_ERR_LIMIT, "min(16, max_cluster)^P tuples exceed 2^26 (the CUDA library builds them all, 16 bytes each, before keeping 65536)"); }
   std::vector<std::pair<float, uint32_t> > dists((size_t)nVec);
   std::vector<uint64_t> denom(P, 1);
   for (uint32_t p = 1; p < P; ++p) denom[p] = denom[p - 1] * b;
