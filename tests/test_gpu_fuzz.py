@@ -23,6 +23,8 @@ SHAPES = [
     (128, 4, 32, 16, 2, 32, 5000, 1000, 500,  100),   # 128-byte rows with coarse in LDS? (32*32*32*4 = 128 KB -> staged slices)
     (64,  2, 64, 4,  2, 32, 4000, 600,  64,   33),    # C1 = 64, LP = 32: workgroup-per-query rerank
     (24,  3, 5,  3,  2, 6,  1500, 100,  216,  10),    # everything odd
+    (64,  2, 128, 4, 2, 32, 6000, 600,  64,   33),    # C1 = 128, LP = 32 (configs[4]'s first level): 16 KB of L1virt per wave, 6-wave workgroups
+    (128, 4, 64, 64, 1, 32, 6000, 900,  300,  100),   # BASELINE configs[2]/[3] shape at a different seed
 ]
 
 
