@@ -1819,6 +1819,96 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     // 512-entry list (records + keys, 8 KB of LDS), which is then ordered and finished like the short list below.
     // A query with more than 512 populated rows is handed to pqt_k_bins (workgroup per query, He-sized arena).
     uint64_t* sKeyW = sBin + 512;
+    if (heur4 && filter && !prm.hashMod) {
+      // Two phases (packed table + presence bitmap).  Block by block the old loop chained three dependent round trips (rows ->
+      // bitmap -> table probes) eight times over.  Phase 1 only decides which rows MAY name an existing bin: bin id from the
+      // pre-multiplied part lists (4 LDS reads), one bitmap word -- with the next block's bin ids and bitmap reads issued
+      // before the current block's words are consumed -- and the few "maybe" rows (the populated ones plus ~1.6 % false
+      // positives) are appended to a work list (row | bin id << 32) in LDS.  Phase 2 probes the whole list at once (one round
+      // trip, 8 entries per lane), computes the distance key of the rows that exist and compacts them as before.
+      uint64_t* sWork = sKeyW;  // 512 entries; read back into registers before the final lists are written
+      uint32_t nwork = 0;
+      uint32_t gA[8], fA[8];
+      auto stageA = [&](const uint32_t hb, uint32_t (&g)[8], uint32_t (&f)[8]) {
+        if (hb == 0) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { const uint32_t h = lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+        }
+        uint32_t w[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = hw[r];
+        if (hb + 512 < He) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { const uint32_t h = hb + 512 + lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          uint32_t gg = 0;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) gg += sSegB[PQT_MUL((uint32_t)p, WC, shWC) + ((w[r] >> (8 * p)) & 0xffu)];
+          g[r] = gg;
+          f[r] = filter[pqt_hash_filter(gg, filterBits) >> 5];
+        }
+      };
+      stageA(0, gA, fA);
+      for (uint32_t hb = 0; hb < He; hb += 512) {
+        uint32_t gB[8], fB[8];
+        const bool more = hb + 512 < He;
+        if (more) stageA(hb + 512, gB, fB);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const uint32_t h = hb + lane + 64 * r;
+          const bool bit = h < He && ((fA[r] >> (pqt_hash_filter(gA[r], filterBits) & 31u)) & 1u);
+          uint32_t tot;
+          const uint32_t rk = pqt_ballot_rank(bit, &tot);
+          if (bit && nwork + rk < 512) sWork[nwork + rk] = (uint64_t)h | ((uint64_t)gA[r] << 32);
+          nwork += tot;
+        }
+        if (more) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) { gA[r] = gB[r]; fA[r] = fB[r]; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (nwork > 512) {  // more "maybe" rows than the list holds: workgroup-per-query kernel with the full-size arena
+        if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
+        return;
+      }
+      // phase 2: all probes in flight together
+      const uint4* table4 = reinterpret_cast<const uint4*>(table);
+      uint32_t hrow[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const uint32_t e = lane + 64 * r;
+        const uint64_t we = e < nwork ? sWork[e] : 0ull;
+        hrow[r] = (uint32_t)we;
+        uint32_t slot = 0;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        uint32_t wd = 0;
+        if (e < nwork) { x = pqt_table_lookup(table4, (uint32_t)(we >> 32), tableBits, prm.tableSeed, &slot); wd = heur4[hrow[r]]; }
+        recG[r] = x.y;
+        recL[r] = SHARDED ? slot : x.z;
+        key[r] = ~0ull;
+        if (x.y) {
+          float fine = 0.f;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) fine = fine + sSegD[PQT_MUL((uint32_t)p, WC, shWC) + ((wd >> (8 * p)) & 0xffu)];
+          key[r] = ((uint64_t)pqt_f2key(fine) << 32) | hrow[r];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the work list is in registers now: its LDS area becomes the key list
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(recG[r] != 0, &tot);
+        const uint32_t e = npop + rk;
+        if (recG[r]) {  // npop <= nwork <= 512
+          sBin[e] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
+          sKeyW[e] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | e;  // (distance, row, record)
+        }
+        npop += tot;
+      }
+    } else
     for (uint32_t hb = 0; hb < He; hb += 512) {
       rowBlock(hb);
 #pragma unroll
