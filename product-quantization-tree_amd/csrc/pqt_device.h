@@ -37,9 +37,9 @@ __host__ __device__ __forceinline__ uint32_t pqt_hash2(uint32_t key, uint32_t bi
 }
 // presence filter in front of the table (one bit per hashed key, 2^bits bits): a clear bit proves the bin empty
 __host__ __device__ __forceinline__ uint32_t pqt_hash_filter(uint32_t key, uint32_t bits) {
-  uint32_t x = key * 0x9E3779B1u;
-  x ^= x >> 16;
-  return (x * 0x7FEB352Du) >> (32u - bits);
+  // one multiply (the traversal evaluates it for every enumerated row and 32-bit multiplies are quarter rate): the top bits
+  // of the Fibonacci product depend on every key bit
+  return (key * 0x9E3779B1u) >> (32u - bits);
 }
 // returns {key, gcount, lstart, lcount}; gcount == 0 when the bin does not exist.  *slotOut = slot of the hit.
 __device__ __forceinline__ uint4 pqt_table_lookup(const uint4* __restrict__ table4, uint32_t key, uint32_t bits, uint32_t seed,

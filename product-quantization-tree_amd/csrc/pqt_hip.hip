@@ -598,7 +598,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                             targs, travPerWave)
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
                                 else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
-      const int shape = idx->noShape ? 0 : pqt_shape_of(d);  // the two BASELINE shapes run compile-time-shape instantiations
+      // the two BASELINE shapes run compile-time-shape instantiations (two-phase enumeration only: packed heuristic rows and
+      // the presence bitmap must be there, no modulo hashing, no order-all-rows debug switch)
+      const bool twoOk = targs.heur4 && targs.filter && !d.hashMod && !((idx->dbg >> 5) & 1u);
+      const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
       if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);
                         else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave); }
       else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);

@@ -1328,7 +1328,10 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   uint32_t* __restrict__ ovList = A.ovList; uint32_t* __restrict__ ovCount = A.ovCount;
   const uint32_t* __restrict__ filter = A.filter; const uint32_t filterBits = A.filterBits; const uint32_t tdbg = A.tdbg;
   (void)lower; (void)candPos;
-  const uint32_t forceFullOrder = tdbg & 1u;
+  // compile-time shapes: always the two-phase enumeration (the host selects them only with the packed heuristic rows, the
+  // presence bitmap, no modulo hashing and without the order-all-rows debug switch), so the single-pass code is not compiled in
+  constexpr bool TWO = SHAPE != 0;
+  const uint32_t forceFullOrder = TWO ? 0u : (tdbg & 1u);
 #define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
   using SH = PqtShape<SHAPE>;
   static_assert(SHAPE == 0 || (P2 && WCR == 1), "compile-time shapes are power-of-two shapes with W*C2 == 64");
@@ -1638,7 +1641,64 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       recL[r] = SHARDED ? slot : x.z;  // sharded: keep the slot, resolve the local fields after the cut
     }
   };
-  if (He <= 512) rowBlock(0);
+  // phase 2 of the two-phase enumeration: the work list (row | bin id << 32, nwork <= 512 entries, entry e = lane + 64 r) is
+  // probed in one round trip -- blocks of 64 entries beyond the list are skipped by a uniform branch -- and the rows whose
+  // bin exists get their distance key.  Leaves recG / recL / key in work-list arrangement; the list's LDS area is free after.
+  auto probeWork = [&](const uint64_t* sWork, const uint32_t nwork) {
+    const uint4* table4 = reinterpret_cast<const uint4*>(table);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      recG[r] = 0; recL[r] = 0; key[r] = ~0ull;
+      if (64u * r < nwork) {
+        const uint32_t e = lane + 64 * r;
+        const uint64_t we = e < nwork ? sWork[e] : 0ull;
+        const uint32_t hrow = (uint32_t)we;
+        uint32_t slot = 0;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        uint32_t wd = 0;
+        if (e < nwork) { x = pqt_table_lookup(table4, (uint32_t)(we >> 32), tableBits, prm.tableSeed, &slot); wd = heur4[hrow]; }
+        recG[r] = x.y;
+        recL[r] = SHARDED ? slot : x.z;
+        if (x.y) {
+          float fine = 0.f;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) fine = fine + sSegD[PQT_MUL((uint32_t)p, WC, shWC) + ((wd >> (8 * p)) & 0xffu)];
+          key[r] = ((uint64_t)pqt_f2key(fine) << 32) | hrow;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // the work list is in registers now: its LDS area can be overwritten
+  };
+  // Short enumeration (He <= 512) in the same two phases: every row's bin id + one bitmap word, the few "maybe" rows go to
+  // a work list that aliases sBin, one round of probes for the list.  (The single-pass rowBlock computed a distance key
+  // for every row and ran all eight predicated probe blocks; this kernel is issue-bound at 5 waves per SIMD.)
+  const bool twoShort = TWO && He <= 512;
+  if (twoShort) {
+    uint64_t* sWork = sBin;
+    uint32_t g[8], f[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const uint32_t h = lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t gg = 0;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) gg += sSegB[PQT_MUL((uint32_t)p, WC, shWC) + ((hw[r] >> (8 * p)) & 0xffu)];
+      g[r] = gg;
+      f[r] = filter[pqt_hash_filter(gg, filterBits) >> 5];
+    }
+    uint32_t nwork = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t h = lane + 64 * r;
+      const bool bit = h < He && ((f[r] >> (pqt_hash_filter(g[r], filterBits) & 31u)) & 1u);
+      uint32_t tot;
+      const uint32_t rk = pqt_ballot_rank(bit, &tot);
+      if (bit) sWork[nwork + rk] = (uint64_t)h | ((uint64_t)g[r] << 32);
+      nwork += tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    probeWork(sWork, nwork);
+  } else if (!TWO && He <= 512) rowBlock(0);
   PQT_TS(5);
 
   // ---- a6, shared by the two orderings below.  skey: the sorted keys, element i = lane*R + r, low word & 0xffff = index
@@ -1819,7 +1879,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     // 512-entry list (records + keys, 8 KB of LDS), which is then ordered and finished like the short list below.
     // A query with more than 512 populated rows is handed to pqt_k_bins (workgroup per query, He-sized arena).
     uint64_t* sKeyW = sBin + 512;
-    if (heur4 && filter && !prm.hashMod) {
+    if (TWO || (heur4 && filter && !prm.hashMod)) {
       // Two phases (packed table + presence bitmap).  Block by block the old loop chained three dependent round trips (rows ->
       // bitmap -> table probes) eight times over.  Phase 1 only decides which rows MAY name an existing bin: bin id from the
       // pre-multiplied part lists (4 LDS reads), one bitmap word -- with the next block's bin ids and bitmap reads issued
@@ -1874,29 +1934,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
         return;
       }
-      // phase 2: all probes in flight together
-      const uint4* table4 = reinterpret_cast<const uint4*>(table);
-      uint32_t hrow[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const uint32_t e = lane + 64 * r;
-        const uint64_t we = e < nwork ? sWork[e] : 0ull;
-        hrow[r] = (uint32_t)we;
-        uint32_t slot = 0;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        uint32_t wd = 0;
-        if (e < nwork) { x = pqt_table_lookup(table4, (uint32_t)(we >> 32), tableBits, prm.tableSeed, &slot); wd = heur4[hrow[r]]; }
-        recG[r] = x.y;
-        recL[r] = SHARDED ? slot : x.z;
-        key[r] = ~0ull;
-        if (x.y) {
-          float fine = 0.f;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) fine = fine + sSegD[PQT_MUL((uint32_t)p, WC, shWC) + ((wd >> (8 * p)) & 0xffu)];
-          key[r] = ((uint64_t)pqt_f2key(fine) << 32) | hrow[r];
-        }
-      }
-      __builtin_amdgcn_wave_barrier();  // the work list is in registers now: its LDS area becomes the key list
+      probeWork(sWork, nwork);
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         uint32_t tot;
@@ -1946,22 +1984,20 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     PQT_TS(8);
     return;
   }
-  uint32_t ent[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    uint32_t tot;
-    const uint32_t rk = pqt_ballot_rank(recG[r] != 0, &tot);
-    ent[r] = npop + rk;
-    npop += tot;
-  }
+  for (int r = 0; r < 8; ++r) npop += (uint32_t)__popcll(__ballot(recG[r] != 0));  // scalar; the ranks are taken where they are used
   if (npop <= 128 && !forceFullOrder) {
     uint64_t* sKeyC = sBin + 128;
+    uint32_t base = 0;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
+      uint32_t tot;
+      const uint32_t e = base + pqt_ballot_rank(recG[r] != 0, &tot);
       if (recG[r]) {
-        sBin[ent[r]] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
-        sKeyC[ent[r]] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | ent[r];  // (distance, row, record)
+        sBin[e] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
+        sKeyC[e] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | e;  // (distance, row, record)
       }
+      base += tot;
     }
     __builtin_amdgcn_wave_barrier();
     if (npop <= 64) {
@@ -1977,6 +2013,23 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       PQT_TS(6);
       totIncl = finish(k2, npop, totCand);
     }
+  } else if (twoShort) {
+    // more than 128 populated rows: records compacted like above, their keys (distance, row, record) stay in registers
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      uint32_t tot;
+      const uint32_t e = base + pqt_ballot_rank(recG[r] != 0, &tot);
+      if (recG[r]) {
+        sBin[e] = (uint64_t)recG[r] | ((uint64_t)recL[r] << 32);
+        key[r] = (key[r] & 0xffffffff00000000ull) | ((key[r] & 0xffffull) << 16) | e;
+      }
+      base += tot;
+    }
+    __builtin_amdgcn_wave_barrier();
+    pqt_wave_sort_u64<8>(key);
+    PQT_TS(6);
+    totIncl = finish(key, npop, totCand);
   } else {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
