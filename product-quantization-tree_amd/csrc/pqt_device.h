@@ -41,6 +41,15 @@ __host__ __device__ __forceinline__ uint32_t pqt_hash_filter(uint32_t key, uint3
   // of the Fibonacci product depend on every key bit
   return (key * 0x9E3779B1u) >> (32u - bits);
 }
+// size class of a query for the rerank schedule (quarter octaves of its local candidate count, 64 classes): queries are
+// drawn class by class, largest first -- a longest-first order to within 19 %
+#define PQT_SCHED_CLASSES 64
+__host__ __device__ __forceinline__ uint32_t pqt_sched_class(uint32_t n) {
+  if (n < 4u) return n;  // 0..3
+  const uint32_t e = 31u - (uint32_t)__builtin_clz(n);  // >= 2
+  const uint32_t c = 4u * (e - 1u) + ((n >> (e - 2u)) & 3u);
+  return c < PQT_SCHED_CLASSES - 1u ? c : PQT_SCHED_CLASSES - 1u;
+}
 // returns {key, gcount, lstart, lcount}; gcount == 0 when the bin does not exist.  *slotOut = slot of the hit.
 __device__ __forceinline__ uint4 pqt_table_lookup(const uint4* __restrict__ table4, uint32_t key, uint32_t bits, uint32_t seed,
                                                   uint32_t* slotOut) {

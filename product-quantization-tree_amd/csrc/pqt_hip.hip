@@ -39,6 +39,8 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 #endif
 constexpr int kFusedWaves = PQT_RS_NW;
 constexpr int kCtrRing = 4;
+constexpr int kPoolRing = 4;  // blocks of 16 draw counters + 8 x 64 registration counts behind the statistics ring (rerank schedule 2)
+constexpr size_t kPoolWords = 16 + 8 * PQT_SCHED_CLASSES;
 #ifndef PQT_TR_NW
 #define PQT_TR_NW 1
 #endif
@@ -76,7 +78,7 @@ struct pqt_index {
   uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
   hipEvent_t lev0 = nullptr, lev1 = nullptr;  // start/stop events attached to the next fused launch (lean timing), or null
   bool curRuns = false;  // the current chunk hands bin runs (not a candidate list) from the traversal to the rerank
-  bool curDynamic = false; unsigned long long* curZero8 = nullptr;  // rerank schedule and next statistics block of the current chunk
+  uint32_t curDynamic = 0; unsigned long long* curZero8 = nullptr; uint32_t* curPool = nullptr; uint32_t* curPoolNext = nullptr; uint32_t poolPos = 0; unsigned long long* d_schedList = nullptr; uint64_t schedCapQ = 0; uint32_t curSchedCap = 0;  // rerank schedule and next statistics block of the current chunk
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
@@ -93,7 +95,7 @@ struct pqt_index {
   size_t scratchBudget = (size_t)24 << 30;
   // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; bool noOrder = false; bool noShape = false; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = 2; bool noShape = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -253,6 +255,9 @@ int allowLds(K kernel, size_t bytes) {
 #ifndef PQT_RS_U16
 #define PQT_RS_U16 4   // candidates per lane in flight when LP = 16 (scaled so that U * LP/4 stays 16 code vectors)
 #endif
+static uint32_t* poolBlock(pqt_index* idx, uint32_t pos) {
+  return reinterpret_cast<uint32_t*>(idx->d_counters + 8 * (kCtrRing + 1)) + (size_t)(pos % kPoolRing) * kPoolWords;
+}
 template <int LPV, bool CL, bool SH>
 int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
              uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
@@ -270,9 +275,9 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
   const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic ? 1u : 0u, idx->curZero8,
+                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic, idx->curZero8,
                         nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
-                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap};
+                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
@@ -352,9 +357,9 @@ PqtRsArgs rsArgsFilter(pqt_index* idx, const float* qL1virt, const uint32_t* nLo
   const double lp = idx->dp.LP;
   const float kappa = (float)(2.02 * (lp * lp + 8.0 * lp + 2.0) / 16777216.0);
   return PqtRsArgs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                   idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic ? 1u : 0u, idx->curZero8,
+                   idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic, idx->curZero8,
                    (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
-                   idx->d_fbList, idx->d_fbCount, idx->curRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap};
+                   idx->d_fbList, idx->d_fbCount, idx->curRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
 }
 template <int NW, int LPV, bool SH, int MODE>
 int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
@@ -378,7 +383,7 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
     if constexpr (kRunsVariant) { if (idx->curRuns) { lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1, true>; llds = ((llds + 15) & ~(size_t)15) + (size_t)LNW * idx->curRunCap * 12; } }
     if ((rc = allowLds(lk, llds))) return rc;
     PqtRsArgs largs = rargs;
-    largs.tstamp = nullptr; largs.dynamic = 0; largs.zero8 = nullptr;
+    largs.tstamp = nullptr; largs.dynamic = 0; largs.zero8 = nullptr; largs.pool = nullptr; largs.poolNext = nullptr; largs.schedCnt = nullptr;
     hipLaunchKernelGGL(lk, dim3(std::min<uint32_t>((nq + LNW - 1) / LNW, (uint32_t)idx->numCUs * 2)), dim3(LNW * 64), llds, st, largs);
   }
   return PQT_OK;
@@ -582,6 +587,16 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       idx->evMask[idx->ringPos][c] |= (1u << EV_BEGIN) | (1u << EV_BINS);
     } else PQT_REC(EV_BEGIN);
     unsigned long long* const tstamp = (nq <= (1u << 16)) ? idx->d_tstamp : nullptr;  // debug buffer holds 65536 query records
+    // rerank schedule of this chunk (decided here: schedule 2 needs the short fused traversal to register the queries)
+    const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
+    const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
+    const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
+    const bool useSched = severalPerWave && idx->balance == 2 && travFused && !travWide;
+    idx->curSchedCap = (nq + 7) / 8;
+    if (useSched && (uint64_t)idx->curSchedCap > idx->schedCapQ) {
+      if ((rc = devAlloc(&idx->d_schedList, (size_t)8 * PQT_SCHED_CLASSES * idx->curSchedCap))) return rc;
+      idx->schedCapQ = idx->curSchedCap;
+    }
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
@@ -592,7 +607,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
                               (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                               emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
-                              countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u};
+                              countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u,
+                              useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
@@ -649,10 +665,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     }
     // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query
-    const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
-    const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
-    idx->curDynamic = fused && !idx->noOrder && nq > rsGrid * rsNW;
+    idx->curDynamic = (severalPerWave && idx->balance) ? (useSched ? 2u : 1u) : 0u;
     idx->curZero8 = nullptr;
+    // draw counters of this launch (zeroed by the previous one) and the block the launch zeroes for the next
+    idx->curPool = poolBlock(idx, idx->poolPos); idx->curPoolNext = poolBlock(idx, idx->poolPos + 1);
+    if (fused && !wgG) idx->poolPos++;
     idx->lev0 = idx->lev1 = nullptr;
     if (leanEvents) {
       idx->lev0 = idx->evRing[idx->ringPos][c][EV_ORDER]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_RERANK];
@@ -787,16 +804,16 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
   for (uint32_t i = 0; i < PQT_MAXP; ++i) d.powers[i] = i < p.p ? upow(p.c1 * p.c2, i) : 0;  // treequantizer.hpp:45-49
   idx->maxMultiIndex = upow(d.WC, p.p);  // treequantizer.hpp:40-41 (wraps in uint32 like the reference)
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&idx->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void**)&idx->d_counters, 8 * (kCtrRing + 1) * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void**)&idx->d_counters, (8 * (kCtrRing + 1) * sizeof(unsigned long long) + kPoolRing * kPoolWords * sizeof(uint32_t))) != hipSuccess) {
     delete idx;
     return fail(PQT_ERR_DEVICE, "stream/counter allocation failed");
   }
-  (void)hipMemset(idx->d_counters, 0, 8 * (kCtrRing + 1) * sizeof(unsigned long long));
+  (void)hipMemset(idx->d_counters, 0, (8 * (kCtrRing + 1) * sizeof(unsigned long long) + kPoolRing * kPoolWords * sizeof(uint32_t)));
   size_t freeB = 0, totalB = 0;
   idx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
   if (getenv("PQT_DBG")) idx->dbg = (uint32_t)atoi(getenv("PQT_DBG"));
-  if (getenv("PQT_BALANCE")) idx->noOrder = atoi(getenv("PQT_BALANCE")) == 0;
+  if (getenv("PQT_BALANCE")) idx->balance = std::max(0, std::min(2, atoi(getenv("PQT_BALANCE"))));
   if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * 16 * 8) != hipSuccess) idx->d_tstamp = nullptr; }
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
   *out = idx;
@@ -809,7 +826,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -841,7 +858,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
-  if (strcmp(name, "balance") == 0) { idx->noOrder = (value == 0); return PQT_OK; }
+  if (strcmp(name, "balance") == 0) { idx->balance = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return PQT_OK; }  // rerank schedule: 0 static, 1 workgroup-local, 2 global pools
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }

@@ -689,6 +689,9 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
                               // what the select's LDS round trips cost; off.
 #endif
 #define PQT_RUNCAP 128   // bin runs per query handed from the traversal to the rerank (more: the plain candidate list is written)
+#ifndef PQT_RS_STATIC_PCT
+#define PQT_RS_STATIC_PCT 45  // rerank schedule 2: share of an XCD pool (its longest queries) handed out without atomics
+#endif
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
 // arguments of the fused rerank + select (kernel-argument segment)
@@ -698,7 +701,8 @@ struct PqtRsArgs {
   const uint32_t* nLocal; uint64_t stride; uint32_t k, qn; PqtDevParams prm;
   uint32_t* outIdx; float* outDist; uint32_t* outPos;
   unsigned long long* counters; uint32_t dbg; unsigned long long* tstamp;
-  uint32_t dynamic;          // 1: workgroup-local dynamic schedule (several queries per wavefront), 0: static round-robin
+  uint32_t dynamic;          // 0: static round-robin; 1: workgroup-local dynamic schedule over a fixed share of the queries,
+                             // longest first; 2: chunks drawn from global per-XCD pools, other pools' leftovers when the own is empty
   unsigned long long* zero8; // statistics block of the next call, zeroed here (saves a memset launch)
   // opt-in "adc_bias" mode (MODE 1 of pqt_rs_query): group-major copy of the line store [LP/4][nIds] 16-byte pieces, rows in
   // it, and the per-row query-independent part of the ADC sum
@@ -713,6 +717,11 @@ struct PqtRsArgs {
   // when the traversal wrote the plain list after all; runGpos (sharded) = global visiting position of a run's first member
   const unsigned long long* runs; const uint32_t* runGpos; const uint32_t* nRuns;
   uint32_t runCap;  // run slots of a wavefront's LDS area (64 or PQT_RUNCAP); the traversal hands over at most this many
+  // dynamic == 2: eight global draw counters (pool x = the queries q with q % 8 == x, in index order) of this launch, and the
+  // block of the next launch, zeroed here
+  uint32_t* pool; uint32_t* poolNext;
+  // ... the traversal's registration lists (see PqtTravArgs): pool x is drawn class by class, largest first
+  const uint32_t* schedCnt; const unsigned long long* schedList; uint32_t schedCap;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -758,7 +767,9 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   (void)c1sh; (void)vOff;
   // debug timestamps (slots 9..13 of the per-query record): start, cycles waiting for rows, ADC + filter, flushes, end
   unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
-  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = __builtin_readcyclecounter();
+  unsigned long long tsStart = 0, wallStart = 0;
+  if (tstamp) { tsStart = __builtin_readcyclecounter(); wallStart = wall_clock64(); }
+  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = tsStart;
   const uint32_t* cid = cand + (size_t)q * stride;
   const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
   if (tstamp) ts0 = __builtin_readcyclecounter();
@@ -1144,8 +1155,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   __builtin_amdgcn_wave_barrier();
   if (tstamp && lane == 0) {
     tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
-    tstamp[(size_t)q * 16 + 13] = __builtin_readcyclecounter();
-    tstamp[(size_t)q * 16 + 14] = slot;
+    // [13] = shader clocks of this query | start on the 100 MHz wall clock << 32; [14] = wave slot | XCC id << 16 | end on the
+    // wall clock << 32 (the cycle counters of different XCDs have different origins, the wall clock is global)
+    tstamp[(size_t)q * 16 + 13] = ((__builtin_readcyclecounter() - tsStart) & 0xffffffffull) | (wallStart << 32);
+    tstamp[(size_t)q * 16 + 14] = (unsigned long long)slot | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 16) | (wall_clock64() << 32);
   }
 }
 
@@ -1180,11 +1193,92 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   unsigned long long* sRuns = (RUNS && A.runs)
       ? reinterpret_cast<unsigned long long*>(smem_raw + ((ticketOff + 16 + 3 * PQT_RS_LIST * 4 + 15) & ~(size_t)15)) + (size_t)wave * (A.runCap + A.runCap / 2)
       : nullptr;
-  const uint32_t L = (dynamic && blockIdx.x < qn) ? (qn - blockIdx.x + G - 1) / G : 0u;
+  const uint32_t L = (dynamic == 1 && blockIdx.x < qn) ? (qn - blockIdx.x + G - 1) / G : 0u;
   const uint32_t Ls = L < PQT_RS_LIST ? L : PQT_RS_LIST;
-  if (threadIdx.x == 0) *sTicket = 0;
+  if (threadIdx.x < 4) sTicket[threadIdx.x] = 0;  // head, tail, done, lock
   if (blockIdx.x == 0 && threadIdx.x < 8 && zero8) zero8[threadIdx.x] = 0;
-  if (dynamic && wave == 0) {
+  if (blockIdx.x == 0 && A.poolNext) for (uint32_t t = threadIdx.x; t < 16u + 8u * PQT_SCHED_CLASSES; t += NW * 64) A.poolNext[t] = 0;  // draw counters + registration counts
+  // ---- dynamic == 2: per-XCD pools in longest-first order, a static share and a dynamic remainder.
+  // The per-query time differs several-fold, workgroups with a fixed share finish up to 25 % apart, and four of the eight
+  // XCDs see ~25 % slower memory (scripts/micro/xcd_latency.hip, profiles/r02_xcd_latency.txt): with a fixed partition the
+  // launch lasts as long as the slowest workgroup of the slow XCDs.  Pool x = the queries q with q % 8 == x (their
+  // traversal ran on XCD x: candidate list and L1virt are in that L2), ordered by the traversal's registration lists --
+  // size class by size class, largest first.  Entry i of the pool's first 70 % belongs to workgroup i % nW of the pool (an
+  // interleaved longest-first share, taken without any atomic); the rest -- the short queries -- is drawn in chunks of 2..6
+  // with ONE device-scope atomic per chunk, by whichever wavefront finds at most 6 undrawn entries in the workgroup's LDS
+  // ring (a lock word keeps it to one at a time; the others keep taking tickets), first from the own pool, then from
+  // whichever pool has most left.
+  uint32_t* sPoolCur = sTmpN;      // [0] pool drawn from, [1] next chunk size, [2] low-water mark
+  uint32_t* sIncl = sTmpN + 4;     // 64: inclusive class counts of the pool being read
+  constexpr uint32_t kLow = 6;     // request the next chunk when at most this many undrawn entries are left in the ring
+  auto poolCount = [&](const uint32_t x) -> uint32_t { return x < qn ? (qn - x + 7u) / 8u : 0u; };
+  auto poolWgs = [&](const uint32_t x) -> uint32_t { return x < G ? (G - x + 7u) / 8u : 0u; };
+  // entries of the static share per workgroup of pool x (the ring holds 256)
+  auto poolStatic = [&](const uint32_t x) -> uint32_t { const uint32_t w = poolWgs(x); uint32_t j = w ? (poolCount(x) * PQT_RS_STATIC_PCT / 100u) / w : 0u; return j > 192u ? 192u : j; };
+  // chunk size and low-water mark shrink with what the pool has left: at the end nothing sits reserved in a ring while
+  // other workgroups run dry (a query is a third of a wavefront's share of the launch: reservations are expensive there)
+  auto chunkOf = [&](const uint32_t rem) -> uint32_t { const uint32_t c = rem / 128u; return c < 1u ? 1u : (c > 6u ? 6u : c); };
+  auto lowOf = [&](const uint32_t rem) -> uint32_t { const uint32_t c = rem / 64u; return c > kLow ? kLow : c; };
+  // lanes < cnt: ring[tail + lane] = entry idx (per lane) of pool x; then publishes tail + cnt
+  auto fetchEntries = [&](const uint32_t x, const uint32_t idx, const uint32_t cnt, const uint32_t tail) {
+    const uint32_t cl = PQT_SCHED_CLASSES - 1u - lane;  // classes in descending order: lane l looks at class 63 - l
+    const uint32_t cn = A.schedCnt[x * PQT_SCHED_CLASSES + cl];
+    const uint32_t incl = pqt_wave_incl_scan(cn);
+    *(volatile uint32_t*)&sIncl[lane] = incl;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      uint32_t lo = 0;  // first lane whose inclusive count exceeds idx (6-step search)
+#pragma unroll
+      for (uint32_t st = 32; st >= 1; st >>= 1) { if (lo + st <= 63u && *(volatile uint32_t*)&sIncl[lo + st - 1] <= idx) lo += st; }
+      const uint32_t ex = lo ? *(volatile uint32_t*)&sIncl[lo - 1] : 0u;
+      const unsigned long long ev = A.schedList[(size_t)(x * PQT_SCHED_CLASSES + (PQT_SCHED_CLASSES - 1u - lo)) * A.schedCap + (idx - ex)];
+      sList[(tail + lane) & (PQT_RS_LIST - 1)] = (uint32_t)ev;
+      sListN[(tail + lane) & (PQT_RS_LIST - 1)] = (uint32_t)(ev >> 32);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&sTicket[1], tail + cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // appends one chunk of the dynamic remainder to the ring (caller holds the lock); sets done when every pool is exhausted
+  auto refill = [&]() {
+    uint32_t x = *(volatile uint32_t*)&sPoolCur[0], ch = *(volatile uint32_t*)&sPoolCur[1];
+    uint32_t got = 0, first = 0;
+    bool exhausted = false;
+    for (int attempt = 0; attempt < 4; ++attempt) {  // (a draw that loses the race for a pool's last entries is retried by the caller)
+      const uint32_t dyn0 = poolWgs(x) * poolStatic(x);
+      const uint32_t cx = poolCount(x) - dyn0;  // entries of the pool's dynamic remainder
+      uint32_t c = cx;
+      if (cx) { if (lane == 0) c = __hip_atomic_fetch_add(&A.pool[x], ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c); }
+      if (c < cx) {
+        got = cx - c < ch ? cx - c : ch; first = dyn0 + c;
+        if (lane == 0) { *(volatile uint32_t*)&sPoolCur[0] = x; *(volatile uint32_t*)&sPoolCur[1] = chunkOf(cx - c - got); *(volatile uint32_t*)&sPoolCur[2] = lowOf(cx - c - got); }
+        break;
+      }
+      // this pool is empty: the one with most left (one round trip for all eight counters)
+      uint32_t rem = 0;
+      if (lane < 8) {
+        const uint32_t ci = poolCount(lane) - poolWgs(lane) * poolStatic(lane);
+        const uint32_t di = __hip_atomic_load(&A.pool[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rem = di < ci ? ci - di : 0u;
+      }
+      uint32_t best = (rem << 3) | (7u - lane);
+#pragma unroll
+      for (int d = 4; d > 0; d >>= 1) { const uint32_t o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+      best = (uint32_t)__builtin_amdgcn_readfirstlane((int)best);
+      if ((best >> 3) == 0) { exhausted = true; break; }  // nothing left anywhere
+      x = 7u - (best & 7u);
+      ch = chunkOf(best >> 3);
+    }
+    if (got) fetchEntries(x, first + lane, got, __hip_atomic_load(&sTicket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    else if (exhausted && lane == 0) __hip_atomic_store(&sTicket[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  if (dynamic == 2 && wave == 0) {
+    const uint32_t x = blockIdx.x & 7u, w = poolWgs(x), J = poolStatic(x), i = blockIdx.x >> 3;
+    if (lane == 0) { *(volatile uint32_t*)&sPoolCur[0] = x; *(volatile uint32_t*)&sPoolCur[1] = chunkOf(poolCount(x) - w * J); *(volatile uint32_t*)&sPoolCur[2] = lowOf(poolCount(x) - w * J); }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j0 = 0; j0 < J; j0 += 64) fetchEntries(x, i + w * (j0 + lane), J - j0 < 64u ? J - j0 : 64u, j0);
+  }
+  if (dynamic == 1 && wave == 0) {
     uint32_t ne[PQT_RS_LIST / 64];
 #pragma unroll
     for (int j = 0; j < PQT_RS_LIST / 64; ++j) {
@@ -1215,6 +1309,39 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   // next query of this wavefront and its candidate count (0xffffffff: count still to be fetched from global memory)
   uint32_t round = 0;
   auto nextQuery = [&](uint32_t& cnt) -> uint32_t {
+    if (dynamic == 2) {
+      uint32_t t = 0;
+      if (lane == 0) t = atomicAdd(sTicket, 1u);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      cnt = 0xffffffffu;
+      for (;;) {
+        uint32_t done = 0, tail = 0;
+        if (lane == 0) { done = __hip_atomic_load(&sTicket[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); tail = __hip_atomic_load(&sTicket[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done); tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail);
+        const uint32_t lw = *(volatile uint32_t*)&sPoolCur[2];
+        if (!done && tail <= t + lw) {  // low water: request the next chunk unless somebody already does
+          uint32_t won = 0;
+          if (lane == 0) won = atomicCAS(&sTicket[3], 0u, 1u) == 0u ? 1u : 0u;
+          won = (uint32_t)__builtin_amdgcn_readfirstlane((int)won);
+          if (won) {
+            uint32_t d2 = 0, t2 = 0;
+            if (lane == 0) { d2 = __hip_atomic_load(&sTicket[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); t2 = __hip_atomic_load(&sTicket[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            d2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d2); t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t2);
+            if (!d2 && t2 <= t + lw) refill();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_store(&sTicket[3], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
+          }
+        }
+        if (t < tail) break;
+        if (done) return 0xffffffffu;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      uint32_t qv = 0, nv = 0;
+      if (lane == 0) { qv = sList[t & (PQT_RS_LIST - 1)]; nv = sListN[t & (PQT_RS_LIST - 1)]; }
+      cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nv);
+      return (uint32_t)__builtin_amdgcn_readfirstlane((int)qv);
+    }
     if (dynamic) {
       uint32_t t = 0;
       if (lane == 0) t = atomicAdd(sTicket, 1u);
@@ -1230,14 +1357,18 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
     cnt = 0xffffffffu;
     return nx < qn ? (uint32_t)nx : 0xffffffffu;
   };
+  // schedule 2 draws the next query when the current one is done (its count comes with the ring entry): nothing is reserved
+  // ahead by a wavefront, which matters at the end of the launch; the other schedules choose it now and fetch a count that
+  // is not in the LDS list under the final select + sort
   uint32_t n = 0;
   uint32_t q = nextQuery(n);
-  if (q != 0xffffffffu && n == 0xffffffffu) n = (dbg & 2) ? 0u : nLocal[q];
+  if (q != 0xffffffffu && n == 0xffffffffu) n = nLocal[q];
+  if (dbg & 2) n = 0;
   while (q != 0xffffffffu) {
-    // the next query is chosen now; a count that is not in the LDS list is fetched under the final select + sort below
-    uint32_t nN = 0;
-    const uint32_t qN = nextQuery(nN);
+    uint32_t nN = 0, qN = 0xffffffffu;
+    if (dynamic != 2) qN = nextQuery(nN);
     pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, sRuns);
+    if (dynamic == 2) { qN = nextQuery(nN); if (dbg & 2) nN = 0; }
     q = qN;
     n = nN;
   }
@@ -1296,6 +1427,9 @@ struct PqtTravArgs {
   uint32_t runCap;  // at most this many runs are handed over (more: the plain candidate list is written)
   uint32_t* outCount;  // the caller's per-query candidate count, written here directly (saves a copy on the stream), or null
   uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
+  // rerank schedule 2: the query registers itself in the list of (XCD pool q % 8, size class of its local candidate count):
+  // schedCnt[pool * 64 + class] entries so far, schedList[(pool * 64 + class) * schedCap + i] = i-th query; or null
+  uint32_t* schedCnt; unsigned long long* schedList /* query | local candidates << 32 */; uint32_t schedCap;
 };
 
 // the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
@@ -1705,6 +1839,19 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   // of the bin's record in sBin; cnt elements.  Scans the populations in visiting order, applies the cut, writes the
   // compact list of the included populated bins to LDS and gathers the candidates by binary search over it.
   // Returns the number of included populated bins and (by reference) the candidate total.
+  // rerank schedule 2: position in the (pool, size class) list -- the atomic is issued as soon as the count is known and its
+  // result is used after the candidate list is written (the round trip hides under the expansion)
+  uint32_t schedSlot = 0, schedPos = 0, schedN = 0;
+  auto schedDraw = [&](const uint32_t nloc) {
+    schedN = nloc;
+    if (A.schedCnt && lane == 0) {
+      schedSlot = (q & 7u) * PQT_SCHED_CLASSES + pqt_sched_class(nloc);
+      schedPos = __hip_atomic_fetch_add(&A.schedCnt[schedSlot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto schedCommit = [&]() {
+    if (A.schedCnt && lane == 0) A.schedList[(size_t)schedSlot * A.schedCap + schedPos] = (unsigned long long)q | ((unsigned long long)schedN << 32);
+  };
   auto finish = [&](auto& skey, const uint32_t cnt, uint32_t& totCandOut) -> uint32_t {
     constexpr int R = (int)(sizeof(skey) / sizeof(skey[0]));
     uint32_t g8[R], ls8[R];
@@ -1753,12 +1900,14 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totCand; if (A.outCount) A.outCount[q] = totCand; }
+      schedDraw(totCand);
       PQT_TS(7);
       if (A.runs) {
         // hand the compact list itself to the rerank when it fits: no candidate list is written
         if (m <= A.runCap) {
           for (uint32_t i = lane; i < m; i += 64) A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i];
           if (lane == 0) A.nRuns[q] = m;
+          schedCommit();
           return totNe;
         }
         if (lane == 0) A.nRuns[q] = 0xffffffffu;
@@ -1826,11 +1975,13 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) { nCand[q] = totCand; nLocal[q] = totLocal; if (A.outCount) A.outCount[q] = totCand; }
+      schedDraw(totLocal);
       PQT_TS(7);
       if (A.runs) {
         if (m <= A.runCap) {
           for (uint32_t i = lane; i < m; i += 64) { A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i]; A.runGpos[(size_t)q * PQT_RUNCAP + i] = sGpos[i]; }
           if (lane == 0) A.nRuns[q] = m;
+          schedCommit();
           return totNe;
         }
         if (lane == 0) A.nRuns[q] = 0xffffffffu;
@@ -1863,6 +2014,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         outP[j] = sGpos[lo] + off;
       }
     }
+    schedCommit();
     return totNe;
   };
 

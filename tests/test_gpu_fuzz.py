@@ -76,7 +76,7 @@ def _random_case(seed):
     bb = int(rng.integers(1, min(4096, (W * C2) ** P) + 1))
     k = int(rng.choice([1, 17, 100, 128, 129, 700, 4096]))
     opts = {"bin_runs": int(rng.choice([-1, 0, 1])), "exact_filter": int(rng.integers(0, 2)), "static_shapes": int(rng.integers(0, 2)),
-            "order_all_rows": int(rng.integers(0, 2)), "balance": int(rng.integers(0, 2)), "wg_rerank": int(rng.integers(0, 2))}
+            "order_all_rows": int(rng.integers(0, 2)), "balance": int(rng.integers(0, 3)), "wg_rerank": int(rng.integers(0, 2))}
     return (D, P, C1, C2, W, LP, n, bv, bb, k), opts
 
 
