@@ -587,11 +587,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       idx->evMask[idx->ringPos][c] |= (1u << EV_BEGIN) | (1u << EV_BINS);
     } else PQT_REC(EV_BEGIN);
     unsigned long long* const tstamp = (nq <= (1u << 16)) ? idx->d_tstamp : nullptr;  // debug buffer holds 65536 query records
-    // rerank schedule of this chunk (decided here: schedule 2 needs the short fused traversal to register the queries)
+    // rerank schedule of this chunk (decided here: for schedule 2 the traversal kernels register the queries by size class)
     const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
     const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
     const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
-    const bool useSched = severalPerWave && idx->balance == 2 && travFused && !travWide;
+    const bool useSched = severalPerWave && idx->balance == 2;
+    uint32_t* const schedCntArg = useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr;
     idx->curSchedCap = (nq + 7) / 8;
     if (useSched && (uint64_t)idx->curSchedCap > idx->schedCapQ) {
       if ((rc = devAlloc(&idx->d_schedList, (size_t)8 * PQT_SCHED_CLASSES * idx->curSchedCap))) return rc;
@@ -608,7 +609,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                               (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                               emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
                               countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u,
-                              useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
+                              schedCntArg, idx->d_schedList, idx->curSchedCap};
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
       hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
                             targs, travPerWave)
@@ -632,12 +633,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
           hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                              idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                              idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
         else
           hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                              idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                              idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
       }
     } else {
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
@@ -656,12 +657,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                            idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
       else
         hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                            idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
     }
     }
     // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query

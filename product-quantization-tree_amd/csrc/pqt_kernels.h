@@ -142,7 +142,8 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     const uint32_t* __restrict__ lower, uint32_t tableBits, uint32_t* __restrict__ cand, uint32_t* __restrict__ candPos,
     uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
     const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qcount, uint32_t* __restrict__ ovList,
-    uint32_t* __restrict__ ovCount, unsigned long long* __restrict__ counters) {
+    uint32_t* __restrict__ ovCount, unsigned long long* __restrict__ counters,
+    uint32_t* __restrict__ schedCnt, unsigned long long* __restrict__ schedList, uint32_t schedCap /* rerank schedule 2: see PqtTravArgs */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (qlist && blockIdx.x >= *qcount) return;
   const uint32_t q = qlist ? qlist[blockIdx.x] : blockIdx.x;
@@ -262,6 +263,11 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     nCand[q] = nGlobal;
     nLocal[q] = nLoc;
     nIncl[q] = nb;
+    if (schedCnt) {  // registration for the rerank schedule (the fused traversal does the same in its finish step)
+      const uint32_t slot = (q & 7u) * PQT_SCHED_CLASSES + pqt_sched_class(nLoc);
+      const uint32_t pos = __hip_atomic_fetch_add(&schedCnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      schedList[(size_t)slot * schedCap + pos] = (unsigned long long)q | ((unsigned long long)nLoc << 32);
+    }
   }
   // a6 gather: candidate j lives in the last included bin whose list start is <= j
   for (uint32_t j = tid; j < nLoc; j += PQT_BLOCK) {
