@@ -86,8 +86,10 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
- * "balance" = 0 disables the dynamic schedule of the wave-per-query rerank (a workgroup's wavefronts draw its queries
- * longest-first through an LDS ticket) in favour of a static round-robin; it only changes the schedule, never a result.
+ * "balance" = schedule of the wave-per-query rerank: 2 (default) = per-XCD query pools in longest-first order (the traversal
+ * registers every query under its size class), a share dealt out statically and the rest drawn in shrinking chunks, other
+ * pools' leftovers when the own is empty; 1 = a fixed share per workgroup whose wavefronts draw it longest-first through an
+ * LDS ticket; 0 = static round-robin.  It only changes the schedule, never a result.
  * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
  * "debug_bits" = ablation switches of the fused kernels (measurement only: results are WRONG for non-zero values;

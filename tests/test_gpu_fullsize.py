@@ -83,6 +83,21 @@ def test_fullsize_properties(big):
     finally:
         idx.set_option("fused", 1)
     assert np.array_equal(ids_s, ids) and np.array_equal(dist_s.view(np.uint32), dist.view(np.uint32)) and np.array_equal(cnt_s, cnt)
+    # schedule independence: static round-robin, workgroup-local lists, global pools (the default) -- also behind the wide traversal
+    for knobs in ((bv, bb), (4096, 4096)):
+        idx.build_heuristic(max(knobs[1], 500))
+        ref = None
+        for bal in (2, 1, 0):
+            idx.set_option("balance", bal)
+            try:
+                got = run(idx, queries, knobs[0], knobs[1], 100)
+            finally:
+                idx.set_option("balance", 2)
+            if ref is None:
+                ref = got
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), (knobs, bal)
+        if knobs == (bv, bb):
+            assert np.array_equal(ref[0], ids) and np.array_equal(ref[2], cnt)
     # a tighter vector bound really cuts, and the cut list is a prefix-in-visiting-order subset of the uncut one
     ids_c, dist_c, cnt_c = run(idx, queries[:256], 50, bb, 100)
     assert np.all(cnt_c <= cnt[:256]) and np.any(cnt_c < cnt[:256])
