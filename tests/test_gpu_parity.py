@@ -803,3 +803,65 @@ def test_cuda_style_heuristic_mode(name):
         f.oracle.set_heuristic(f.heur)
         f.oracle.set_sort_mode(0)
         idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,knobs,opts", [
+    ("cfg2_small", (800, 500, 100), {}),                     # LDS coarse table (MODE 0), short fused traversal
+    ("cfg2_small", (800, 500, 100), {"bin_runs": 1}),        # ... with bin runs instead of candidate lists
+    ("cfg2_small", (300, 1500, 17), {}),                     # wide traversal (1500 rows)
+    ("cfg3_small", (2000, 400, 100), {}),                    # MODE 2 filter + bin runs (6/12-wave workgroups)
+    ("cfg3_small", (2000, 400, 100), {"exact_filter": 0}),   # workgroup-per-query kernel (no wave schedule at all)
+    ("wrap", (500, 300, 64), {}),                            # LP = 8
+    ("big_coarse", (400, 64, 33), {}),                       # coarse table through L2
+])
+def test_rerank_schedules_agree_on_large_batches(name, knobs, opts):
+    """More queries than wavefront slots (> 256 CUs x 12): the three rerank schedules (static round-robin, workgroup-local lists,
+    global pools fed by the traversal's registration lists) must give identical results; a sample is checked against the oracle,
+    and the same through two range shards merged."""
+    import torch
+    f = fixture(name)
+    rng = np.random.default_rng(4242)
+    qn = 3300
+    pick = rng.integers(0, f.base.shape[0], qn)
+    queries = np.clip(np.rint(f.base[pick] + rng.normal(0, 6, (qn, f.base.shape[1]))), 0, 255).astype(np.float32)
+    bv, bb, k = knobs
+    bb = min(bb, f.heur.shape[0])
+    idx = f.hip_index()
+    n = f.base.shape[0]
+    shards = [f.hip_index(shard=(0, n // 3)), f.hip_index(shard=(n // 3, n))]
+    try:
+        for h in [idx] + shards:
+            for o, v in opts.items():
+                h.set_option(o, v)
+        ref = None
+        for bal in (2, 1, 0):
+            idx.set_option("balance", bal)
+            got = idx.query(queries, bv, bb, k)
+            if ref is None:
+                ref = got
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), bal
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi in range(0, qn, 97):
+                s_ids, s_d = f.oracle.query(queries[qi], bv, bb)
+                kk = min(k, len(s_ids))
+                assert int(ref[2][qi]) == len(s_ids)
+                assert np.array_equal(ref[0][qi, :kk], s_ids[:kk]) and np.array_equal(ref[1][qi, :kk].view(np.uint32), s_d[:kk].view(np.uint32))
+        finally:
+            f.oracle.set_sort_mode(0)
+        # two range shards, schedule 2 on each, merged
+        q = torch.from_numpy(queries).cuda()
+        torch.cuda.synchronize()
+        pack = torch.empty((2, 3, qn, k), dtype=torch.int32, device="cuda")
+        cnt = torch.empty((2, qn), dtype=torch.int32, device="cuda")
+        for s, sh in enumerate(shards):
+            sh.query_shard_dev(q, bv, bb, k, pack[s, 0], pack[s, 1].view(torch.float32), pack[s, 2], cnt[s], sync=True)
+        oi = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        od = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_dev(2, qn, k, pack[0, 0], pack[0, 1].view(torch.float32), pack[0, 2], oi, od, sync=True, shard_stride=3 * qn * k)
+        assert np.array_equal(oi.cpu().numpy().view(np.uint32), ref[0])
+        assert np.array_equal(od.cpu().numpy().view(np.uint32), ref[1].view(np.uint32))
+    finally:
+        for h in [idx] + shards:
+            h.close()
