@@ -593,7 +593,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
     const bool useSched = severalPerWave && idx->balance == 2;
     uint32_t* const schedCntArg = useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr;
-    idx->curSchedCap = (nq + 7) / 8;
+    idx->curSchedCap = (nq + 7) / 8;  // entries a (pool, class) list can be asked to hold: a pool's queries
     if (useSched && (uint64_t)idx->curSchedCap > idx->schedCapQ) {
       if ((rc = devAlloc(&idx->d_schedList, (size_t)8 * PQT_SCHED_CLASSES * idx->curSchedCap))) return rc;
       idx->schedCapQ = idx->curSchedCap;

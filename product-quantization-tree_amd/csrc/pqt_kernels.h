@@ -1217,7 +1217,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   uint32_t* sPoolCur = sTmpN;      // [0] pool drawn from, [1] next chunk size, [2] low-water mark
   uint32_t* sIncl = sTmpN + 4;     // 64: inclusive class counts of the pool being read
   constexpr uint32_t kLow = 6;     // request the next chunk when at most this many undrawn entries are left in the ring
-  auto poolCount = [&](const uint32_t x) -> uint32_t { return x < qn ? (qn - x + 7u) / 8u : 0u; };
+  uint32_t* sPoolTot = sTmpN + 72;  // 8: queries registered in each pool (from the traversal's counts)
+  auto poolCount = [&](const uint32_t x) -> uint32_t { return *(volatile uint32_t*)&sPoolTot[x & 7u]; };
   auto poolWgs = [&](const uint32_t x) -> uint32_t { return x < G ? (G - x + 7u) / 8u : 0u; };
   // entries of the static share per workgroup of pool x (the ring holds 256)
   auto poolStatic = [&](const uint32_t x) -> uint32_t { const uint32_t w = poolWgs(x); uint32_t j = w ? (poolCount(x) * PQT_RS_STATIC_PCT / 100u) / w : 0u; return j > 192u ? 192u : j; };
@@ -1279,6 +1280,13 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
     else if (exhausted && lane == 0) __hip_atomic_store(&sTicket[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   if (dynamic == 2 && wave == 0) {
+    for (uint32_t xx = 0; xx < 8; ++xx) {
+      uint32_t c = A.schedCnt[xx * PQT_SCHED_CLASSES + lane];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+      if (lane == 0) *(volatile uint32_t*)&sPoolTot[xx] = c;
+    }
+    __builtin_amdgcn_wave_barrier();
     const uint32_t x = blockIdx.x & 7u, w = poolWgs(x), J = poolStatic(x), i = blockIdx.x >> 3;
     if (lane == 0) { *(volatile uint32_t*)&sPoolCur[0] = x; *(volatile uint32_t*)&sPoolCur[1] = chunkOf(poolCount(x) - w * J); *(volatile uint32_t*)&sPoolCur[2] = lowOf(poolCount(x) - w * J); }
     __builtin_amdgcn_wave_barrier();
