@@ -314,6 +314,9 @@ def main():
                     help="range-sharded run: per-shard top-k exchanged by query slice (all-to-all, merged slices all-gathered) or by one all-gather of the whole lists")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")
+    ap.add_argument("--timing-period", type=int, default=4,
+                    help="every N-th call of the timed region carries the per-kernel start/stop HIP events the roofline figures come from "
+                         "(1 = every call: the events cost ~10 us per call, see DESIGN.md section 6)")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
     ap.add_argument("--centers", type=int, default=GEN["n_centers"])
@@ -418,14 +421,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # per-kernel HIP events on every P-th call (the first call after the option is set is a timed one): the timed region holds
+    # the calls warmup .. warmup + steps - 1
+    period = max(1, args.timing_period)
+    timed_in_region = [i for i in range(args.steps) if (args.warmup + i) % period == 0]
+    if not timed_in_region:
+        period, timed_in_region = 1, list(range(args.steps))
+    idx.set_option("stage_timing", period)
     elapsed = time_steps(step, barrier, args.warmup, args.steps)
+    idx.set_option("stage_timing", 1)  # the side legs below time every call
     if mode == "shard_db":
         out_idx.copy_(sbuf.out_idx)
         out_dist.copy_(sbuf.out_dist)
         out_cnt.copy_(sbuf.count)
     # per-stage device times of the timed steps themselves: the library records HIP events around every kernel on the
     # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
-    hist = idx.stage_ms_history(min(args.steps, 32))
+    hist = idx.stage_ms_history(min(len(timed_in_region), 32))
     st = idx.stats()
     stage = dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), hist.mean(0).tolist()))
     if os.environ.get("PQT_TSTAMP"):
@@ -541,6 +552,8 @@ def main():
                    "exchange": args.exchange if mode == "shard_db" else None,
                    "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if (world > 1 or force_shard) else None), "collective_world_size": world,
                    "options": args.option,
+                   "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call; the events cost ~10 us per call)"
+                                    % (len(timed_in_region), args.steps, {1: "", 2: "2nd"}.get(period, "%dth" % period)),
                    "global_batch": units,
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
                    "mean_candidates_this_rank": ncand_rank,
@@ -558,8 +571,8 @@ def main():
                      "intermediate_bytes": rr_inter,
                      "accounting": "SURVEY 8(d) terms only -- rerank+select: 4*nCand + 4*LP*nCand + 8k per query; traversal: 4*D + 8*Bb per query; "
                                    "intermediate_bytes (L1virt and candidate-list round trips between the two launches) are listed, not priced",
-                     "timing": "mean over the timed steps of the kernel's own duration: start/stop HIP events attached to the dispatch "
-                               "(hipExtLaunchKernel) on the launch stream, read after the closing barrier",
+                     "timing": "mean of the kernel's own duration over the %d of the %d timed steps that carry events: start/stop HIP events attached to "
+                               "the dispatch (hipExtLaunchKernel) on the launch stream, read after the closing barrier" % (len(timed_in_region), args.steps),
                      "other_kernels": {kname[n_]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kb[n_][0], "intermediate_bytes": kb[n_][1],
                                                    "GBps": kb[n_][0] / max(stage[n_], 1e-9) / 1e6, "frac": kb[n_][0] / max(stage[n_], 1e-9) / 1e6 / HBM_PEAK_GBS}
                                        for n_ in kname if n_ != dominant}},

@@ -90,6 +90,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * registers every query under its size class), a share dealt out statically and the rest drawn in shrinking chunks, other
  * pools' leftovers when the own is empty; 1 = a fixed share per workgroup whose wavefronts draw it longest-first through an
  * LDS ticket; 0 = static round-robin.  It only changes the schedule, never a result.
+ * "stage_timing" = N: the per-kernel start/stop events behind pqt_get_stage_ms_history / pqt_get_stats ride on every N-th
+ * call (1 = every call, the default; 0 = never); they cost about 5 us per kernel launch.
  * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
  * "debug_bits" = ablation switches of the fused kernels (measurement only: results are WRONG for non-zero values;

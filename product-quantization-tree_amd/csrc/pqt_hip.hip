@@ -95,7 +95,7 @@ struct pqt_index {
   size_t scratchBudget = (size_t)24 << 30;
   // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = 2; bool noShape = false; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = 2; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -572,16 +572,17 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
+  idx->timedCall = idx->stageTiming > 0 && (idx->timingPhase++ % (unsigned long long)idx->stageTiming) == 0;  // the first call after the option is set is a timed one
   idx->calls++;
   // the two fused launches are bracketed by three events; the staged path keeps one event per stage
   const bool leanEvents = travFused && (fused || bigK);
-#define PQT_REC(e) do { HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][e], st)); idx->evMask[idx->ringPos][c] |= 1u << (e); } while (0)
+#define PQT_REC(e) do { if (idx->timedCall) { HIPCHK(hipEventRecord(idx->evRing[idx->ringPos][c][e], st)); idx->evMask[idx->ringPos][c] |= 1u << (e); } } while (0)
   for (int c = 0; c < nChunks; ++c) {
     const uint32_t q0 = (uint32_t)c * qChunk;
     const uint32_t nq = std::min<uint32_t>(qChunk, qn - q0);
     idx->evMask[idx->ringPos][c] = 0;
     idx->lev0 = idx->lev1 = nullptr;
-    if (leanEvents) {
+    if (leanEvents && idx->timedCall) {
       // lean timing: start/stop timestamps ride on the two fused dispatches (no event packets between the kernels)
       idx->lev0 = idx->evRing[idx->ringPos][c][EV_BEGIN]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_BINS];
       idx->evMask[idx->ringPos][c] |= (1u << EV_BEGIN) | (1u << EV_BINS);
@@ -672,7 +673,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     idx->curPool = poolBlock(idx, idx->poolPos); idx->curPoolNext = poolBlock(idx, idx->poolPos + 1);
     if (fused && !wgG) idx->poolPos++;
     idx->lev0 = idx->lev1 = nullptr;
-    if (leanEvents) {
+    if (leanEvents && idx->timedCall) {
       idx->lev0 = idx->evRing[idx->ringPos][c][EV_ORDER]; idx->lev1 = idx->evRing[idx->ringPos][c][EV_RERANK];
       idx->evMask[idx->ringPos][c] |= (1u << EV_ORDER) | (1u << EV_RERANK);
     } else PQT_REC(EV_BINS);
@@ -859,6 +860,9 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
+  // per-kernel start/stop events (they cost ~5 us per kernel launch): 1 = every call (default), N = every N-th call, 0 = never;
+  // pqt_get_stage_ms_history reports the timed calls only
+  if (strcmp(name, "stage_timing") == 0) { idx->stageTiming = value < 0 ? 0 : (int)std::min<int64_t>(value, 1 << 20); idx->timingPhase = 0; return PQT_OK; }
   if (strcmp(name, "balance") == 0) { idx->balance = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return PQT_OK; }  // rerank schedule: 0 static, 1 workgroup-local, 2 global pools
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
@@ -1369,10 +1373,14 @@ int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
   if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
   if (hipSetDevice(idx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(PQT_ERR_DEVICE, "sync failed");
   const int have = (int)std::min<unsigned long long>(idx->calls, (unsigned long long)kRing);
-  const int n = std::min(have, cap);
+  // the most recent TIMED calls of the ring (option "stage_timing": not every call carries events), oldest first
+  int slots[kRing], n = 0;
+  for (int b = 1; b <= have && n < cap; ++b) {
+    const int slot = (int)((idx->calls - b) % kRing);
+    if (idx->ringChunks[slot] > 0 && (idx->evMask[slot][0] & 1u)) slots[n++] = slot;
+  }
   for (int i = 0; i < n; ++i) {
-    // oldest of the n most recent calls first
-    const int slot = (int)((idx->calls - n + i) % kRing);
+    const int slot = slots[n - 1 - i];
     float st[5] = {0, 0, 0, 0, 0};
     for (int ch = 0; ch < idx->ringChunks[slot]; ++ch) (void)stageMs(idx, slot, ch, st);
     for (int e = 0; e < 5; ++e) out[i * 5 + e] = st[e];
