@@ -86,7 +86,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
- * "balance" = schedule of the wave-per-query rerank: 2 (default) = per-XCD query pools in longest-first order (the traversal
+ * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache, 1
+ * otherwise; 2 = per-XCD query pools in longest-first order (the traversal
  * registers every query under its size class), a share dealt out statically and the rest drawn in shrinking chunks, other
  * pools' leftovers when the own is empty; 1 = a fixed share per workgroup whose wavefronts draw it longest-first through an
  * LDS ticket; 0 = static round-robin.  It only changes the schedule, never a result.

@@ -95,7 +95,7 @@ struct pqt_index {
   size_t scratchBudget = (size_t)24 << 30;
   // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = 2; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
+  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = -1 /* auto */; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
 };
 
 namespace {
@@ -592,7 +592,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
     const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
     const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
-    const bool useSched = severalPerWave && idx->balance == 2;
+    // automatic choice: the global pools pay for their registration atomics and chunk draws when a query brings thousands of
+    // candidates from an HBM-resident store (configs[2]/[3]: -8..-10 % on the rerank launch); with a cache-resident store and
+    // a few hundred candidates per query the fixed share per workgroup is 1-2 % ahead (SIFT1M shape)
+    const int balance = idx->balance >= 0 ? idx->balance : ((size_t)idx->nIds * d.LP * 4 > ((size_t)256 << 20) ? 2 : 1);
+    const bool useSched = severalPerWave && balance == 2;
     uint32_t* const schedCntArg = useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr;
     idx->curSchedCap = (nq + 7) / 8;  // entries a (pool, class) list can be asked to hold: a pool's queries
     if (useSched && (uint64_t)idx->curSchedCap > idx->schedCapQ) {
@@ -667,7 +671,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     }
     // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query
-    idx->curDynamic = (severalPerWave && idx->balance) ? (useSched ? 2u : 1u) : 0u;
+    idx->curDynamic = (severalPerWave && balance) ? (useSched ? 2u : 1u) : 0u;
     idx->curZero8 = nullptr;
     // draw counters of this launch (zeroed by the previous one) and the block the launch zeroes for the next
     idx->curPool = poolBlock(idx, idx->poolPos); idx->curPoolNext = poolBlock(idx, idx->poolPos + 1);
@@ -815,7 +819,7 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
   idx->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
   if (getenv("PQT_DBG")) idx->dbg = (uint32_t)atoi(getenv("PQT_DBG"));
-  if (getenv("PQT_BALANCE")) idx->balance = std::max(0, std::min(2, atoi(getenv("PQT_BALANCE"))));
+  if (getenv("PQT_BALANCE")) idx->balance = std::max(-1, std::min(2, atoi(getenv("PQT_BALANCE"))));
   if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * 16 * 8) != hipSuccess) idx->d_tstamp = nullptr; }
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
   *out = idx;
@@ -863,7 +867,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // per-kernel start/stop events (they cost ~5 us per kernel launch): 1 = every call (default), N = every N-th call, 0 = never;
   // pqt_get_stage_ms_history reports the timed calls only
   if (strcmp(name, "stage_timing") == 0) { idx->stageTiming = value < 0 ? 0 : (int)std::min<int64_t>(value, 1 << 20); idx->timingPhase = 0; return PQT_OK; }
-  if (strcmp(name, "balance") == 0) { idx->balance = value <= 0 ? 0 : (value >= 2 ? 2 : 1); return PQT_OK; }  // rerank schedule: 0 static, 1 workgroup-local, 2 global pools
+  if (strcmp(name, "balance") == 0) { idx->balance = value < 0 ? -1 : (value >= 2 ? 2 : (int)value); return PQT_OK; }  // rerank schedule: -1 automatic, 0 static, 1 workgroup-local, 2 global pools
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }

@@ -92,7 +92,7 @@ def test_fullsize_properties(big):
             try:
                 got = run(idx, queries, knobs[0], knobs[1], 100)
             finally:
-                idx.set_option("balance", 2)
+                idx.set_option("balance", -1)
             if ref is None:
                 ref = got
             assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(got[2], ref[2]), (knobs, bal)
