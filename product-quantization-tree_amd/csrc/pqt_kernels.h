@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     if (schedCnt) {  // registration for the rerank schedule (the fused traversal does the same in its finish step)
       const uint32_t slot = (q & 7u) * PQT_SCHED_CLASSES + pqt_sched_class(nLoc);
       const uint32_t pos = __hip_atomic_fetch_add(&schedCnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      schedList[(size_t)slot * schedCap + pos] = (unsigned long long)q | ((unsigned long long)nLoc << 32);
+      if (pos < schedCap) schedList[(size_t)slot * schedCap + pos] = (unsigned long long)q | ((unsigned long long)nLoc << 32);
     }
   }
   // a6 gather: candidate j lives in the last included bin whose list start is <= j
@@ -1238,9 +1238,11 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
 #pragma unroll
       for (uint32_t st = 32; st >= 1; st >>= 1) { if (lo + st <= 63u && *(volatile uint32_t*)&sIncl[lo + st - 1] <= idx) lo += st; }
       const uint32_t ex = lo ? *(volatile uint32_t*)&sIncl[lo - 1] : 0u;
-      const unsigned long long ev = A.schedList[(size_t)(x * PQT_SCHED_CLASSES + (PQT_SCHED_CLASSES - 1u - lo)) * A.schedCap + (idx - ex)];
-      sList[(tail + lane) & (PQT_RS_LIST - 1)] = (uint32_t)ev;
-      sListN[(tail + lane) & (PQT_RS_LIST - 1)] = (uint32_t)(ev >> 32);
+      const uint32_t within = idx - ex < A.schedCap ? idx - ex : A.schedCap - 1u;
+      const unsigned long long ev = A.schedList[(size_t)(x * PQT_SCHED_CLASSES + (PQT_SCHED_CLASSES - 1u - lo)) * A.schedCap + within];
+      const uint32_t qe = (uint32_t)ev;  // (clamped: a registration block left dirty by a failed call must not send a wave out of bounds)
+      sList[(tail + lane) & (PQT_RS_LIST - 1)] = qe < qn ? qe : qn - 1u;
+      sListN[(tail + lane) & (PQT_RS_LIST - 1)] = qe < qn ? (uint32_t)(ev >> 32) : 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(&sTicket[1], tail + cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1864,7 +1866,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     }
   };
   auto schedCommit = [&]() {
-    if (A.schedCnt && lane == 0) A.schedList[(size_t)schedSlot * A.schedCap + schedPos] = (unsigned long long)q | ((unsigned long long)schedN << 32);
+    if (A.schedCnt && lane == 0 && schedPos < A.schedCap) A.schedList[(size_t)schedSlot * A.schedCap + schedPos] = (unsigned long long)q | ((unsigned long long)schedN << 32);
   };
   auto finish = [&](auto& skey, const uint32_t cnt, uint32_t& totCandOut) -> uint32_t {
     constexpr int R = (int)(sizeof(skey) / sizeof(skey[0]));
