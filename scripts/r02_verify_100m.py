@@ -2,7 +2,7 @@
 test-suite (the index build alone is ~20 s, the oracle needs the 12.8 GB line store on the host), run by hand on the GPU box:
     python scripts/r02_verify_100m.py > gpurun_out/r02_verify_100m.json
 Checks: 64 queries of the bench batch against the oracle loaded with the same index (ids and distance bits, both knob sets);
-2000 queries: band-filtered exact rerank (MODE 2, bin runs) == workgroup-per-query exact kernel == candidate-list variant."""
+4000 queries: the three rerank schedules agree; band-filtered exact rerank (MODE 2, bin runs) == workgroup-per-query exact kernel == candidate-list variant."""
 import importlib, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 t0 = time.time()
 idx, base, meta = bench.build_index(pkg, w, 0)
 idx.build_heuristic(4096)
-queries = bench.sift_like(2000, w["D"], 0xC0DE03, dev)
+queries = bench.sift_like(4000, w["D"], 0xC0DE03, dev)  # more than 256 CUs x 12 wavefronts: the dynamic rerank schedules are in play
 res = {"workload": "N=%d d=128 p=4 c1=64 c2=64 w=1 lineparts=32" % w["n_base"], "build_s": round(time.time() - t0, 1), "n_bins": meta["n_bins"], "max_bin": meta["max_bin"]}
 
 
@@ -31,7 +31,7 @@ for bv, bb in ((20000, 500), (4096, 4096)):
     a = run(queries, bv, bb)
     fb = idx.stats()["filter_fallbacks"]
     same = {}
-    for opt, val, back in (("exact_filter", 0, 1), ("bin_runs", 0, -1)):
+    for opt, val, back in (("exact_filter", 0, 1), ("bin_runs", 0, -1), ("balance", 0, -1), ("balance", 1, -1), ("balance", 2, -1)):
         idx.set_option(opt, val)
         b = run(queries, bv, bb)
         idx.set_option(opt, back)
