@@ -1209,14 +1209,14 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   // XCDs see ~25 % slower memory (scripts/micro/xcd_latency.hip, profiles/r02_xcd_latency.txt): with a fixed partition the
   // launch lasts as long as the slowest workgroup of the slow XCDs.  Pool x = the queries q with q % 8 == x (their
   // traversal ran on XCD x: candidate list and L1virt are in that L2), ordered by the traversal's registration lists --
-  // size class by size class, largest first.  Entry i of the pool's first 70 % belongs to workgroup i % nW of the pool (an
-  // interleaved longest-first share, taken without any atomic); the rest -- the short queries -- is drawn in chunks of 2..6
-  // with ONE device-scope atomic per chunk, by whichever wavefront finds at most 6 undrawn entries in the workgroup's LDS
-  // ring (a lock word keeps it to one at a time; the others keep taking tickets), first from the own pool, then from
-  // whichever pool has most left.
+  // size class by size class, largest first.  Entry i of the pool's first PQT_RS_STATIC_PCT % belongs to workgroup i % nW of
+  // the pool (an interleaved longest-first share, taken without any atomic); the rest -- the short queries -- is drawn in
+  // chunks of 6 .. 1 (shrinking with what the pool has left, like the ring's low-water mark) with ONE device-scope atomic per
+  // chunk, by whichever wavefront finds the workgroup's LDS ring low (a lock word keeps it to one at a time; the others keep
+  // taking tickets), first from the own pool, then from whichever pool has most left.
   uint32_t* sPoolCur = sTmpN;      // [0] pool drawn from, [1] next chunk size, [2] low-water mark
   uint32_t* sIncl = sTmpN + 4;     // 64: inclusive class counts of the pool being read
-  constexpr uint32_t kLow = 6;     // request the next chunk when at most this many undrawn entries are left in the ring
+  constexpr uint32_t kLow = 6;     // request the next chunk when at most this many undrawn entries are left in the ring (fewer near a pool's end)
   uint32_t* sPoolTot = sTmpN + 72;  // 8: queries registered in each pool (from the traversal's counts)
   auto poolCount = [&](const uint32_t x) -> uint32_t { return *(volatile uint32_t*)&sPoolTot[x & 7u]; };
   auto poolWgs = [&](const uint32_t x) -> uint32_t { return x < G ? (G - x + 7u) / 8u : 0u; };
