@@ -696,7 +696,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
 #endif
 #define PQT_RUNCAP 128   // bin runs per query handed from the traversal to the rerank (more: the plain candidate list is written)
 #ifndef PQT_RS_STATIC_PCT
-#define PQT_RS_STATIC_PCT 45  // rerank schedule 2: share of an XCD pool (its longest queries) handed out without atomics
+#define PQT_RS_STATIC_PCT 65  // rerank schedule 2: share of an XCD pool (its longest queries) handed out without atomics
 #endif
 #define PQT_RS_LIST 256   // queries of a workgroup's list that are ranked by candidate count (the rest follow in index order)
 
