@@ -5,22 +5,28 @@ CPU baseline beside it.
 One "step" = one pass of the whole hot path (distance tables -> traversal -> bin enumeration -> ADC line
 rerank -> top-k) over one batch of QN synthetic SIFT-shaped queries, inputs and outputs resident in HBM.
 
-    python bench.py                       # N=1, BASELINE.json configs[1] (SIFT1M shape, batch 10k)
+    python bench.py                       # N=1: BASELINE.json configs[1] (SIFT1M shape, batch 10k) is `value`; the same line
+                                          #      carries config.hbm_roofline_leg = configs[2] (100 M vectors) at both knob sets
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU (--gpus N > 1), one process per GPU:
-  * default = the north-star layout: the database is RANGE-SHARDED by vector id (every rank synthesises, assigns and
-    line-encodes only its own id range, chunk by chunk; the per-bin global populations come from one all-gather at
-    build time), every rank runs the traversal for the whole batch, reranks its own slice, and the per-shard top-k
-    lists are exchanged over RCCL by query slice (all-to-all), merged, and the merged slices all-gathered
-    (--exchange allgather: one all-gather of the whole lists) => "scaling": "strong", value = QN*steps / time.
-    Workload: BASELINE.json configs[2] shape, 100 M vectors (fits one GPU, so the same database is also timed on rank 0
-    alone after the timed region: config.same_workload_1gpu, the denominator of the strong-scaling ratio); with
-    --gpus 8 the default is configs[3]'s size, 1 B vectors (125 M per GPU).  --workload overrides either.
+Multi-GPU (--gpus N > 1), one process per GPU.  ONE workload for the whole scaling sweep: for every N >= 2 the
+database of BASELINE.json configs[2] (100 M vectors) is RANGE-SHARDED by vector id (every rank synthesises, assigns and
+line-encodes only its own id range; the per-bin global populations come from one all-gather at build time); per batch the
+traversal is sharded by QUERIES (rank r traverses QN/N of them, one all-gather of the per-query bin lists), every rank reranks
+its own slice of the database, and the per-shard top-k lists are exchanged over RCCL by query slice (all-to-all), merged, and
+the merged slices all-gathered => "scaling": "strong", value = QN*steps / time.  Because 100 M vectors also fit one GPU,
+rank 0 afterwards builds the database whole and times the single-GPU path on the same queries: config.same_workload_1gpu is
+the denominator and the top-level `scaling_vs_1gpu` the ratio of the run's own strong scaling.
+With --gpus 8 `value` is BASELINE configs[3]'s size (1 B vectors, 125 M per GPU: the metric names SIFT1B on 8 GPUs) and the
+100 M strong-scaling leg of the sweep rides beside it (config.strong_scaling_leg, `scaling_vs_1gpu`).  --workload overrides.
+  * --traversal replicated: every rank traverses the whole batch (no second exchange; the protocol of rounds 1-2).
   * --replicas: queries are the units instead -- every rank holds the whole SIFT1M-shape index and answers its own
     batch, no data-path collective => "scaling": "weak", value = N*QN*steps / time (never the default: it does not
     exercise the exchange step).
+--dataset-dir DIR: real data (sift_base/sift_learn/sift_query .fvecs|.bvecs + sift_groundtruth.ivecs as fetched by the
+reference's scripts/prepare_data.sh): tree and database are built by the product's own front-end (tool_createdb: createTree +
+buildKBestDB), recall@1/@10/@100 of the engine is reported beside the checker's on the same index.
 """
 import argparse
 import importlib
@@ -292,13 +298,353 @@ def time_steps(step, barrier, warmup, steps):
     return time.perf_counter() - t0
 
 
+STAGES = ("tables", "traverse", "gap", "rerank_select", "select")
+
+
+class Ctx:
+    """Process-wide state of one bench run: rank layout, device, the one stream everything is enqueued on."""
+    pass
+
+
+def init_ctx(args):
+    c = Ctx()
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != c.world and c.world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    c.dist = None
+    c.backend = None
+    # PQT_BENCH_FORCE_SHARD=1: run the range-sharded layout with whatever world size there is -- with one rank this drives
+    # every collective of the path (broadcast, build-time all-gather, all-to-all / all-gather per batch, all-reduce) through
+    # RCCL on a 1-GPU box: an API/dtype check of the N > 1 code, not a measurement
+    c.force_shard = bool(os.environ.get("PQT_BENCH_FORCE_SHARD"))
+    if c.world > 1 or c.force_shard:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        c.backend = os.environ.get("PQT_BENCH_BACKEND", "nccl")  # "gloo" + PQT_BENCH_SAME_DEVICE=1: functional check on a 1-GPU box
+        if os.environ.get("PQT_BENCH_SAME_DEVICE"):
+            c.local_rank = 0
+        torch.cuda.set_device(c.local_rank)
+        if c.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", c.local_rank))
+        else:
+            dist.init_process_group(c.backend)
+        c.dist = dist
+    c.dev = torch.device("cuda", c.local_rank)
+    torch.cuda.set_device(c.dev)
+    # everything (data synthesis and the library's kernels) is enqueued on ONE explicit stream: the C-ABI treats a NULL
+    # stream as "the handle's own non-blocking stream", which is not ordered with torch's legacy default stream
+    c.work_stream = torch.cuda.Stream(c.dev)
+    torch.cuda.set_stream(c.work_stream)
+    c.stream = torch.cuda.current_stream(c.dev).cuda_stream
+    c.pkg = importlib.import_module("product-quantization-tree_amd")
+    c.pkg.lib()  # fails loudly if the HIP library is missing
+    c.sharding = importlib.import_module("product-quantization-tree_amd.sharding")
+    c.collectives = c.world > 1 or c.force_shard
+    return c
+
+
+def barrier(ctx):
+    if ctx.collectives:
+        ctx.dist.barrier()
+    torch.cuda.synchronize(ctx.dev)
+
+
+def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
+    """Index + query batch (+ exact ground truth) of one workload.  mode: single | replica | shard_db."""
+    w = WORKLOADS[wl_name]
+    n = w["n_base"]
+    shard = ctx.sharding.shard_range(ctx.rank, ctx.world, n) if mode == "shard_db" else None
+    idx, base, meta = build_index(ctx.pkg, w, ctx.local_rank, shard=shard, dist=ctx.dist, world=ctx.world if mode == "shard_db" else 1, rank=ctx.rank,
+                                  codebooks=codebooks, force_collectives=ctx.force_shard)
+    for ov in args.option:
+        name_, val_ = ov.split("=")
+        idx.set_option(name_, int(val_))
+    t0 = time.time()
+    idx.build_heuristic(max(args.bb, 1))
+    log("[bench] %s index: N=%d%s bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
+        (wl_name, n, (" (this rank: ids [%d, %d))" % shard) if shard else "", meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"],
+         meta["t_csr"], time.time() - t0))
+    # queries: fresh draws from the same mixture (like SIFT's separate query set), ground truth by exact brute force
+    dev = ctx.dev
+    g = torch.Generator(device=dev)
+    g.manual_seed(0xC0DE03)
+    qn = w["qn"]
+    if args.query_mode == "perturbed" and base is not None:
+        pick = torch.randint(0, n, (qn,), generator=g, device=dev)
+        queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
+    else:
+        queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * ctx.rank if mode == "replica" else 0), dev)
+    if mode == "shard_db":
+        ctx.dist.broadcast(queries, 0)  # the SAME batch on every rank
+    raw_u8 = None
+    if args.no_gt or not want_gt:
+        gt = torch.full((qn,), -1, dtype=torch.int64, device=dev)
+    elif base is not None:
+        gt = brute_force_gt(base, queries, 1)[:, 0]
+        raw_u8 = base.to(torch.uint8) if args.extras else None  # raw vectors for the optional exact re-rank (8f-4)
+    else:
+        lo_, hi_ = shard if shard else (0, n)
+        gt = brute_force_gt_chunked(w, queries, dev, lo_, hi_, ctx.dist, ctx.world if mode == "shard_db" else 1, ctx.force_shard)
+    del base
+    torch.cuda.empty_cache()
+    return dict(name=wl_name, w=w, n=n, shard=shard, idx=idx, meta=meta, queries=queries, gt=gt, have_gt=not (args.no_gt or not want_gt), raw_u8=raw_u8,
+                chunked=w.get("chunk", n) < n, mode=mode, qn=qn)
+
+
+def time_path(ctx, args, W, bv, bb, k, steps, warmup, period):
+    """W warm-up steps, then exactly `steps` timed steps of the hot path between barriers (+ device synchronisation); the
+    per-kernel HIP events ride on every period-th call.  Returns the timing, the stage means and the outputs."""
+    idx, queries, qn, dev, mode = W["idx"], W["queries"], W["qn"], ctx.dev, W["mode"]
+    out_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
+    out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
+    out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
+    sbuf = engine = None
+    if mode == "shard_db":
+        sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev)
+        engine = ctx.sharding.PqtShardEngine(idx)
+
+    def step():
+        if mode != "shard_db":
+            idx.query_dev(queries, bv, bb, k, out_idx, out_dist, out_cnt, stream=ctx.stream)
+        else:
+            ctx.sharding.sharded_query(engine, ctx.dist, ctx.world, queries, bv, bb, k, sbuf, exchange=args.exchange, force_collectives=ctx.force_shard,
+                                       traversal=args.traversal)
+
+    # per-kernel HIP events on every P-th call (the first call after the option is set is a timed one): the timed region holds
+    # the calls warmup .. warmup + steps - 1
+    period = max(1, period)
+    timed_in_region = [i for i in range(steps) if (warmup + i) % period == 0]
+    if not timed_in_region:
+        period, timed_in_region = 1, list(range(steps))
+    idx.set_option("stage_timing", period)
+    elapsed = time_steps(step, lambda: barrier(ctx), warmup, steps)
+    idx.set_option("stage_timing", 1)  # later legs time every call
+    if mode == "shard_db":
+        out_idx.copy_(sbuf.out_idx)
+        out_dist.copy_(sbuf.out_dist)
+        out_cnt.copy_(sbuf.count)
+    # per-stage device times of the timed steps themselves: the library records HIP events around every kernel on the
+    # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
+    hist = idx.stage_ms_history(min(len(timed_in_region), 32))
+    st = idx.stats()
+    stage = dict(zip(STAGES, hist.mean(0).tolist())) if hist.shape[0] else dict.fromkeys(STAGES, 0.0)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if ctx.collectives:
+        ctx.dist.all_reduce(tmax, op=ctx.dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    units = qn * (ctx.world if mode == "replica" else 1)  # queries answered by the whole job per step
+    return dict(elapsed=elapsed, steps=steps, warmup=warmup, qps=units * steps / elapsed, ms_per_step=elapsed / steps * 1e3, units=units, stage=stage, st=st,
+                out_idx=out_idx, out_dist=out_dist, out_cnt=out_cnt, sbuf=sbuf, step=step, period=period, n_timed=len(timed_in_region), bv=bv, bb=bb, k=k,
+                path=idx.last_path())
+
+
+def roofline_block(ctx, args, W, R):
+    """`roofline` object of the dominant kernel (largest mean launch duration over the timed steps) + the whole-path figures."""
+    w, qn, k, st, stage = W["w"], W["qn"], R["k"], R["st"], R["stage"]
+    LP, C1 = w["LP"], w["C1"]
+    cand_local = st["candidates"]  # local candidates reranked on this rank in the last step
+    He = st["bins_visited"] / max(1, st["queries"])  # heuristic rows enumerated per query
+    fused_rs = k <= 128
+    kb = kernel_bytes(w, qn, k, He, cand_local, fused_rs)
+    # big coarse tables: band-filtered exact rerank (pqt_k_rerank_select, MODE 2) unless --option exact_filter=0 (workgroup kernel)
+    rs_name = ("pqt_k_rerank_select_wg" if (4 * LP * C1 * C1 > 65536 and "exact_filter=0" in args.option) else "pqt_k_rerank_select") if fused_rs else \
+              ("pqt_k_rerank_select_big" if k <= 4096 else "pqt_k_rerank")
+    kname = {"traverse": "pqt_k_traverse", "rerank_select": rs_name}
+    dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
+    rr_name = kname[dominant]
+    rr_bytes, rr_inter = kb[dominant]
+    rr_ms = float(stage[dominant])
+    rr_gbs = rr_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
+    # whole-path algorithmic bytes per query (SURVEY 8d): 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k (this rank's candidates)
+    ncand_rank = cand_local / max(1, qn)
+    path_bytes_q = 4 * w["D"] + 8 * He + 4 * ncand_rank + 4 * LP * ncand_rank + 8 * k
+    shard = W["shard"]
+    n_local = (shard[1] - shard[0]) if shard else W["n"]
+    store_bytes = n_local * LP * 4
+    resident = "infinity_cache" if store_bytes < (256 << 20) else "hbm"
+    # HBM traffic of the dominant kernel: NOT measured in this run -- replayed from the committed PMC profile of this very command
+    # (profiles/pmc_latest.json, produced by scripts/r03_profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE
+    # factor from the calibration in profiles/r01_pmc_calibration.json: 1.0 for 64-B code rows, 2.0 for 128-B rows)
+    traffic = None
+    traffic_source = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        pms = next((r_ for r_ in pm.get("runs", []) if r_.get("workload") == W["name"] and r_.get("bv") == R["bv"] and r_.get("bb") == R["bb"] and r_.get("k") == k), {})
+        if pms and ctx.world == 1 and not args.option:
+            ent = pms["kernels"].get(rr_name)
+            if ent:
+                traffic = (ent["FETCH_SIZE_KiB"] * pms["fetch_factor"] + ent["WRITE_SIZE_KiB"]) * 1024.0
+                traffic_source = "committed profile (profiles/pmc_latest.json: %s); not collected in this run" % pms.get("source", "rocprofv3 --pmc passes")
+    except Exception:
+        traffic = None
+    roof = {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_ratio": (traffic / rr_bytes) if (traffic and rr_bytes) else None,
+            "resident": resident, "line_store_bytes": store_bytes,
+            "avg_launch_ms": rr_ms,
+            "algorithmic_bytes_per_launch": rr_bytes,
+            "intermediate_bytes": rr_inter,
+            "accounting": "SURVEY 8(d) terms only -- rerank+select: 4*nCand + 4*LP*nCand + 8k per query; traversal: 4*D + 8*Bb per query; "
+                          "intermediate_bytes (L1virt and candidate-list round trips between the two launches) are listed, not priced",
+            "timing": "mean of the kernel's own duration over the %d of the %d timed steps that carry events: start/stop HIP events attached to "
+                      "the dispatch (hipExtLaunchKernel) on the launch stream, read after the closing barrier" % (R["n_timed"], R["steps"]),
+            "other_kernels": {kname[n_]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kb[n_][0], "intermediate_bytes": kb[n_][1],
+                                          "GBps": kb[n_][0] / max(stage[n_], 1e-9) / 1e6, "frac": kb[n_][0] / max(stage[n_], 1e-9) / 1e6 / HBM_PEAK_GBS}
+                              for n_ in kname if n_ != dominant}}
+    if resident == "infinity_cache":
+        roof["note"] = ("the %d MB line store of this workload stays in the 256 MiB Infinity Cache across batches: `frac` is priced against the HBM "
+                        "peak but is not an HBM-bound result; the HBM-roofline configuration (BASELINE configs[2], 100 M vectors) is config.hbm_roofline_leg" % (store_bytes >> 20))
+    extra = dict(He=He, cand_local=cand_local, ncand_rank=ncand_rank, path_bytes_q=path_bytes_q, n_local=n_local, dominant=rr_name)
+    return roof, extra
+
+
+def recalls(W, out_idx):
+    if not W["have_gt"]:
+        return None, None, None
+    ids_t = out_idx.to(torch.int64) & 0xffffffff
+    return recall_at(ids_t, W["gt"], 1), recall_at(ids_t, W["gt"], 10), recall_at(ids_t, W["gt"], 100)
+
+
+def make_line(ctx, args, W, R):
+    """The JSON line of one timed workload."""
+    w, qn, n, mode, k = W["w"], W["qn"], W["n"], W["mode"], R["k"]
+    world, dev, dist = ctx.world, ctx.dev, ctx.dist
+    r1, r10, r100 = recalls(W, R["out_idx"])
+    out_cnt = R["out_cnt"]
+    ncand_mean = float(out_cnt.to(torch.int64).float().mean())  # GLOBAL candidates per query (all shards)
+    cq = torch.quantile(out_cnt.to(torch.float32), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
+    log("[bench] %s candidates per query: median %.0f p90 %.0f p99 %.0f max %.0f   path: %s" % ((W["name"],) + tuple(cq) + (R["path"],)))
+    if mode == "replica" and W["have_gt"]:  # job-wide recall / candidate statistics (outside the timed region)
+        agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg)
+        r1, r10, r100, ncand_mean = (agg / world).tolist()
+    roof, ex = roofline_block(ctx, args, W, R)
+    meta, st, stage = W["meta"], R["st"], R["stage"]
+    shard_par = "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), %s, %s" % (
+        world, ex["n_local"],
+        "traversal sharded by queries (QN/W per rank; one all-gather of the per-query bin lists, <= %d x 8 B per query)" % ctx.sharding.BIN_CAP
+        if args.traversal == "sharded" else "traversal replicated",
+        "per-shard top-k exchanged by query slice (all-to-all of [3][QN/W][k] words per peer), exact (dist,pos) merge of the own slice, all-gather of the merged "
+        "[2][QN/W][k] slices" if args.exchange == "alltoall" else "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge of all queries on every rank")
+    out = {
+        "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
+        "value": R["qps"], "unit": "queries/sec", "n_gpus": world, "steps": R["steps"], "warmup": R["warmup"],
+        "ms_per_step": R["ms_per_step"], "higher_is_better": True,
+        # the sweep the driver runs (N = 1, 2, 4, 8) is a STRONG-scaling design: for N >= 2 the total work (one database, one batch)
+        # is fixed; --replicas is the weak-scaling variant
+        "scaling": "weak" if mode == "replica" else "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("SIFT1M-shape synthetic" if W["name"] in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
+                               "query(boundVectors=%d, boundBins=%d), k=%d" %
+                               (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, R["bv"], R["bb"], k),
+                   "workload_name": W["name"],
+                   "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
+                                   "shard_db": shard_par}[mode],
+                   "exchange": args.exchange if mode == "shard_db" else None,
+                   "traversal": args.traversal if mode == "shard_db" else None,
+                   "collective_backend": ({"nccl": "rccl"}.get(ctx.backend, ctx.backend) if ctx.collectives else None), "collective_world_size": world,
+                   "options": args.option,
+                   "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call; the events cost ~10 us per call)"
+                                    % (R["n_timed"], R["steps"], {1: "", 2: "2nd"}.get(R["period"], "%dth" % R["period"])),
+                   "kernel_path": R["path"],
+                   "global_batch": R["units"],
+                   "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
+                   "mean_candidates_this_rank": ex["ncand_rank"],
+                   "mean_bins_visited": ex["He"], "n_bins": meta["n_bins"], "max_bin": meta["max_bin"], "filter_fallbacks": st.get("filter_fallbacks"),
+                   "algorithmic_bytes_per_query": ex["path_bytes_q"],
+                   "path_GBps": ex["path_bytes_q"] * qn * R["steps"] / R["elapsed"] / 1e9,
+                   "path_frac_of_hbm_peak": ex["path_bytes_q"] * qn * R["steps"] / R["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                   "stage_ms": stage, "dominant_kernel_by_time": ex["dominant"], "build_s": {k_: meta[k_] for k_ in ("t_data", "t_encode", "t_csr")}},
+        "roofline": roof,
+    }
+    return out
+
+
+def same_workload_1gpu(ctx, args, W, R):
+    """Range-sharded run: the SAME database on ONE GPU (rank 0 builds it whole and times the single-GPU path while the others
+    wait), so the line carries the denominator of its own strong-scaling ratio."""
+    w, n, qn, k, dev = W["w"], W["n"], W["qn"], R["k"], ctx.dev
+    ref1 = None
+    try:
+        if not args.no_ref1 and n <= 200_000_000:
+            if ctx.rank == 0:
+                ridx, _, rmeta = build_index(ctx.pkg, w, ctx.local_rank, codebooks=(W["meta"]["cb1"], W["meta"]["cb2"]))
+                ridx.build_heuristic(max(R["bb"], 1))
+                for ov in args.option:
+                    ridx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
+                ro = (torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty((qn, k), dtype=torch.float32, device=dev), torch.empty(qn, dtype=torch.int32, device=dev))
+                nst = max(3, min(R["steps"], 10))
+                t1g = time_steps(lambda: ridx.query_dev(W["queries"], R["bv"], R["bb"], k, ro[0], ro[1], ro[2], stream=ctx.stream),
+                                 lambda: torch.cuda.synchronize(dev), 2, nst)
+                same = bool(torch.equal(ro[0], R["out_idx"]) and torch.equal(ro[1], R["out_dist"]) and torch.equal(ro[2], R["out_cnt"]))
+                h1 = ridx.stage_ms_history(nst).mean(0).tolist()
+                ref1 = {"queries_per_sec": qn * nst / t1g, "ms_per_step": t1g / nst * 1e3, "results_identical_to_sharded": same,
+                        "stage_ms": dict(zip(STAGES, h1)), "kernel_path": ridx.last_path(),
+                        "speedup_of_this_run": R["qps"] / (qn * nst / t1g)}
+                ridx.close()
+                del ridx, ro
+                torch.cuda.empty_cache()
+            ctx.dist.barrier()
+    except Exception as e:
+        ref1 = {"error": repr(e)[:300]}
+    return ref1
+
+
+def ranks_agree(ctx, R):
+    chk = (R["sbuf"].out_idx.to(torch.int64) & 0xffffffff).sum().reshape(1)
+    lo_c, hi_c = chk.clone(), chk.clone()
+    ctx.dist.all_reduce(lo_c, op=ctx.dist.ReduceOp.MIN)
+    ctx.dist.all_reduce(hi_c, op=ctx.dist.ReduceOp.MAX)
+    return bool(lo_c.item() == hi_c.item())
+
+
+def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
+    """One knob set on an index that is already built: q/s, stage ms, roofline of its dominant kernel."""
+    W["idx"].build_heuristic(max(bb, 1))
+    R = time_path(ctx, args, W, bv, bb, k, steps, warmup, period=2)
+    roof, ex = roofline_block(ctx, args, W, R)
+    r1, r10, r100 = recalls(W, R["out_idx"])
+    leg = {"query": "query(boundVectors=%d, boundBins=%d), k=%d" % (bv, bb, k), "queries_per_sec": R["qps"], "ms_per_step": R["ms_per_step"], "steps": steps, "warmup": warmup,
+           "stage_ms": R["stage"], "kernel_path": R["path"], "mean_candidates": float(R["out_cnt"].to(torch.int64).float().mean()),
+           "mean_bins_visited": ex["He"], "filter_fallbacks": R["st"].get("filter_fallbacks"),
+           "recall@1": r1, "recall@100": r100,
+           "algorithmic_bytes_per_query": ex["path_bytes_q"], "path_frac_of_hbm_peak": ex["path_bytes_q"] * W["qn"] * steps / R["elapsed"] / 1e9 / HBM_PEAK_GBS,
+           "roofline": {k_: roof[k_] for k_ in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_source",
+                                                 "traffic_ratio", "resident", "line_store_bytes", "other_kernels")}}
+    return leg, R
+
+
+def hbm_roofline_leg(ctx, args):
+    """BASELINE configs[2] inside the default N = 1 command: 100 M vectors (12.8 GB of line codes: HBM resident), 10 k queries, the
+    reference-default knobs and the CUDA library's (4096, 4096).  `value` stays the SIFT1M-shape number."""
+    t0 = time.time()
+    W = build_workload(ctx, args, args.hbm_workload, "single", want_gt=not args.no_gt)
+    leg = {"workload": "BASELINE configs[2]: synthetic SIFT-shaped (chunk-built) N=%d d=128 p=4 c1=64 c2=64 w=1 lineparts=32, batch=%d queries, 1 GPU" % (W["n"], W["qn"]),
+           "workload_name": W["name"], "n_bins": W["meta"]["n_bins"], "max_bin": W["meta"]["max_bin"],
+           "build_s": {k_: W["meta"][k_] for k_ in ("t_data", "t_encode", "t_csr")}}
+    steps = max(4, min(args.steps, 10))
+    for bv, bb in ((20000, 500), (4096, 4096)):
+        leg["knobs_%d_%d" % (bv, bb)], _ = knob_leg(ctx, args, W, bv, bb, args.k, steps, 2)
+    W["idx"].close()
+    del W
+    torch.cuda.empty_cache()
+    leg["leg_seconds"] = time.time() - t0
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
-                    help="default: sift1m on 1 GPU (BASELINE configs[1]); synth100m range-sharded on 2..7 GPUs, synth1b on 8 (configs[2]/[3])")
+                    help="default: sift1m on 1 GPU (BASELINE configs[1]); synth100m range-sharded on every N >= 2 (configs[2], the scaling sweep's one workload), "
+                         "with synth1b (configs[3]) as the headline beside it on 8")
     ap.add_argument("--bv", type=int, default=20000, help="boundVectors (reference default: query(20000, 500, ...))")
     ap.add_argument("--bb", type=int, default=500, help="boundBins")
     ap.add_argument("--k", type=int, default=100)
@@ -308,141 +654,50 @@ def main():
                     "where torch's reduce kernels crash the profiler on this image")
     ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k, "
                     "opt-in ADC modes); off by default so that a profile of the default command contains only the headline path's launches")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="N = 1: skip config.hbm_roofline_leg (the 100 M-vector configuration beside the headline)")
+    ap.add_argument("--hbm-workload", default="synth100m", choices=list(WORKLOADS), help="workload of the hbm_roofline_leg (tests use a small one)")
     ap.add_argument("--shard-db", action="store_true", help="(default for --gpus N > 1) range-shard the database")
     ap.add_argument("--replicas", action="store_true", help="multi-GPU: replicate the index and shard the queries instead (weak scaling, no collective)")
     ap.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"],
                     help="range-sharded run: per-shard top-k exchanged by query slice (all-to-all, merged slices all-gathered) or by one all-gather of the whole lists")
+    ap.add_argument("--traversal", default=None, choices=["sharded", "replicated"],
+                    help="range-sharded run: traversal sharded by queries with one all-gather of the per-query bin lists (default) or replicated on every rank")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
+    ap.add_argument("--no-scaling-leg", action="store_true", help="--gpus 8 default (synth1b): skip the synth100m strong-scaling leg of the sweep")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")
     ap.add_argument("--timing-period", type=int, default=4,
                     help="every N-th call of the timed region carries the per-kernel start/stop HIP events the roofline figures come from "
                          "(1 = every call: the events cost ~10 us per call, see DESIGN.md section 6)")
+    ap.add_argument("--dataset-dir", default=None, help="real data: directory with sift_base / sift_learn / sift_query (.fvecs or .bvecs) and sift_groundtruth.ivecs")
+    ap.add_argument("--dataset-train", type=int, default=20000, help="--dataset-dir: vectors of the learn set used by createTree (the reference trains on 20000)")
     ap.add_argument("--iso-noise", type=float, default=GEN["iso_noise"])
     ap.add_argument("--lat-noise", type=float, default=GEN["lat_noise"])
     ap.add_argument("--centers", type=int, default=GEN["n_centers"])
     ap.add_argument("--center-scale", type=float, default=GEN["center_scale"])
     ap.add_argument("--query-mode", default="fresh", choices=["fresh", "perturbed"])
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    dist = None
-    backend = None
-    # PQT_BENCH_FORCE_SHARD=1: run the range-sharded layout with whatever world size there is -- with one rank this drives
-    # every collective of the path (broadcast, build-time all-gather, all-to-all / all-gather per batch, all-reduce) through
-    # RCCL on a 1-GPU box: an API/dtype check of the N > 1 code, not a measurement
-    force_shard = bool(os.environ.get("PQT_BENCH_FORCE_SHARD"))
-    if world > 1 or force_shard:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_PORT", "29655")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PQT_BENCH_BACKEND", "nccl")  # "gloo" + PQT_BENCH_SAME_DEVICE=1: functional check on a 1-GPU box
-        if os.environ.get("PQT_BENCH_SAME_DEVICE"):
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    # everything (data synthesis and the library's kernels) is enqueued on ONE explicit stream: the C-ABI treats a NULL
-    # stream as "the handle's own non-blocking stream", which is not ordered with torch's legacy default stream
-    work_stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(work_stream)
-
+    ctx = init_ctx(args)
+    world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
+    if args.traversal is None:
+        args.traversal = os.environ.get("PQT_BENCH_TRAVERSAL", "replicated")  # TODO(phase 2): sharded
     GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers, center_scale=args.center_scale)
-    pkg = importlib.import_module("product-quantization-tree_amd")
-    pkg.lib()  # fails loudly if the HIP library is missing
-    mode = "single" if (world == 1 and not force_shard) else ("replica" if args.replicas else "shard_db")
-    wl_name = args.workload or ("sift1m" if mode != "shard_db" else ("synth1b" if world >= 8 else "synth100m"))
-    w = WORKLOADS[wl_name]
-    n = w["n_base"]
-    sharding = importlib.import_module("product-quantization-tree_amd.sharding")
-    shard = sharding.shard_range(rank, world, n) if mode == "shard_db" else None
-    chunked = w.get("chunk", n) < n
-    idx, base, meta = build_index(pkg, w, local_rank, shard=shard, dist=dist, world=world if mode == "shard_db" else 1, rank=rank, force_collectives=force_shard)
-    for ov in args.option:
-        name_, val_ = ov.split("=")
-        idx.set_option(name_, int(val_))
-    t0 = time.time()
-    idx.build_heuristic(max(args.bb, 1))
-    log("[bench] %s index: N=%d%s bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
-        (wl_name, n, (" (this rank: ids [%d, %d))" % shard) if shard else "", meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"],
-         meta["t_csr"], time.time() - t0))
-
-    # queries: fresh draws from the same mixture (like SIFT's separate query set), ground truth by exact brute force
-    g = torch.Generator(device=dev)
-    g.manual_seed(0xC0DE03)
-    qn = w["qn"]
-    if args.query_mode == "perturbed" and base is not None:
-        pick = torch.randint(0, n, (qn,), generator=g, device=dev)
-        queries = (base[pick] + torch.randn(qn, w["D"], generator=g, device=dev) * 8.0).round().clamp_(0, 255).contiguous()
-    else:
-        queries = sift_like(qn, w["D"], 0xC0DE03 + (1000 * rank if mode == "replica" else 0), dev)
-    if mode == "shard_db":
-        dist.broadcast(queries, 0)  # the SAME batch on every rank
-    if args.no_gt:
-        gt = torch.full((qn,), -1, dtype=torch.int64, device=dev)
-        raw_u8 = None
-    elif base is not None:
-        gt = brute_force_gt(base, queries, 1)[:, 0]
-        raw_u8 = base.to(torch.uint8) if args.extras else None  # raw vectors for the optional exact re-rank (8f-4)
-    else:
-        lo_, hi_ = shard if shard else (0, n)
-        gt = brute_force_gt_chunked(w, queries, dev, lo_, hi_, dist, world if mode == "shard_db" else 1, force_shard)
-        raw_u8 = None
-    del base
-    torch.cuda.empty_cache()
-
-    k = args.k
-    out_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
-    out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
-    out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    if mode == "shard_db":
-        sbuf = sharding.ShardBuffers(world, qn, k, dev)
-        engine = sharding.PqtShardEngine(idx)
-
-    def step():
-        if mode != "shard_db":
-            idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
-        else:
-            # traversal for the whole batch + rerank of the local slice, ONE RCCL all-gather, exact merge
-            sharding.sharded_query(engine, dist, world, queries, args.bv, args.bb, k, sbuf, exchange=args.exchange, force_collectives=force_shard)
-
-    def barrier():
-        if world > 1 or force_shard:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    # per-kernel HIP events on every P-th call (the first call after the option is set is a timed one): the timed region holds
-    # the calls warmup .. warmup + steps - 1
-    period = max(1, args.timing_period)
-    timed_in_region = [i for i in range(args.steps) if (args.warmup + i) % period == 0]
-    if not timed_in_region:
-        period, timed_in_region = 1, list(range(args.steps))
-    idx.set_option("stage_timing", period)
-    elapsed = time_steps(step, barrier, args.warmup, args.steps)
-    idx.set_option("stage_timing", 1)  # the side legs below time every call
-    if mode == "shard_db":
-        out_idx.copy_(sbuf.out_idx)
-        out_dist.copy_(sbuf.out_dist)
-        out_cnt.copy_(sbuf.count)
-    # per-stage device times of the timed steps themselves: the library records HIP events around every kernel on the
-    # stream it launches on (ring of the last 32 calls); they are read only now, after the closing barrier.
-    hist = idx.stage_ms_history(min(len(timed_in_region), 32))
-    st = idx.stats()
-    stage = dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), hist.mean(0).tolist()))
+    if args.dataset_dir:
+        out = run_dataset_dir(ctx, args)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+    mode = "single" if (world == 1 and not ctx.force_shard) else ("replica" if args.replicas else "shard_db")
+    SWEEP_WL = "synth100m"  # the one workload of the strong-scaling sweep
+    wl_name = args.workload or ("sift1m" if mode != "shard_db" else ("synth1b" if world >= 8 else SWEEP_WL))
+    W = build_workload(ctx, args, wl_name, mode)
+    w, n, qn, idx, meta, queries, k = W["w"], W["n"], W["qn"], W["idx"], W["meta"], W["queries"], args.k
+    R = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period)
+    out_idx, out_dist, out_cnt, gt, stream = R["out_idx"], R["out_dist"], R["out_cnt"], W["gt"], ctx.stream
+    st = R["st"]
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
         ts = np.zeros((qn, 16), np.uint64)
-        L = pkg.lib()
+        L = ctx.pkg.lib()
         L.pqt_debug_tstamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         if L.pqt_debug_tstamps(idx.h, ts.ctypes.data, qn) == 0:
             d = np.diff(ts[:, :9].astype(np.int64), axis=1)
@@ -459,28 +714,19 @@ def main():
         for v in os.environ["PQT_DBG_SWEEP"].split(","):
             idx.set_option("debug_bits", int(v))
             for _ in range(6):
-                step()
-            barrier()
+                R["step"]()
+            barrier(ctx)
             h_ = idx.stage_ms_history(5).mean(0).tolist()
             log("[dbg-sweep] bits %s: traverse %.4f  rerank_select %.4f ms" % (v, h_[1], h_[3]))
         idx.set_option("debug_bits", 0)
-        step()
-        barrier()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1 or force_shard:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        R["step"]()
+        barrier(ctx)
 
-    ids_t = out_idx.to(torch.int64) & 0xffffffff
-    r1, r10, r100 = (None, None, None) if args.no_gt else (recall_at(ids_t, gt, 1), recall_at(ids_t, gt, 10), recall_at(ids_t, gt, 100))
-    ncand_mean = float(out_cnt.to(torch.int64).float().mean())  # GLOBAL candidates per query (all shards)
-    cq = torch.quantile(out_cnt.to(torch.float32), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
-    log("[bench] candidates per query: median %.0f p90 %.0f p99 %.0f max %.0f" % tuple(cq))
-    cand_local = st["candidates"]  # local candidates reranked on this rank in the last step
-    He = st["bins_visited"] / max(1, st["queries"])  # heuristic rows enumerated per query
+    out = make_line(ctx, args, W, R)
 
     # optional "next" row 8f-4 (not part of the timed path): exact re-rank of the k results against the raw uint8 vectors
     exact = None
+    raw_u8 = W["raw_u8"]
     if args.extras and raw_u8 is not None and k <= 512 and mode != "shard_db":
         ri = torch.empty_like(out_idx)
         rd = torch.empty_like(out_dist)
@@ -493,114 +739,16 @@ def main():
         te = (time.perf_counter() - te) / 5 * 1e3
         rt = ri.to(torch.int64) & 0xffffffff
         exact = {"recall@1": recall_at(rt, gt, 1), "recall@10": recall_at(rt, gt, 10), "ms_per_batch": te}
-    ms_per_step = elapsed / args.steps * 1e3
-    units = qn * (world if mode == "replica" else 1)  # queries answered by the whole job per step
-    qps = units * args.steps / elapsed
-    if mode == "replica" and not args.no_gt:  # job-wide recall / candidate statistics (outside the timed region)
-        agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
-        dist.all_reduce(agg)
-        r1, r10, r100, ncand_mean = (agg / world).tolist()
+    out["config"]["exact_rerank_of_topk"] = exact
 
-    # ---- roofline of the dominant kernel (largest mean launch duration over the timed steps) ---------------------
-    LP, C1 = w["LP"], w["C1"]
-    fused_rs = args.k <= 128
-    kb = kernel_bytes(w, qn, k, He, cand_local, fused_rs)
-    # big coarse tables: band-filtered exact rerank (pqt_k_rerank_select, MODE 2) unless --option exact_filter=0 (workgroup kernel)
-    rs_name = ("pqt_k_rerank_select_wg" if (4 * LP * C1 * C1 > 65536 and "exact_filter=0" in args.option) else "pqt_k_rerank_select") if fused_rs else \
-              ("pqt_k_rerank_select_big" if k <= 4096 else "pqt_k_rerank")
-    kname = {"traverse": "pqt_k_traverse", "rerank_select": rs_name}
-    dominant = max(("traverse", "rerank_select"), key=lambda n_: stage[n_])
-    rr_name = kname[dominant]
-    rr_bytes, rr_inter = kb[dominant]
-    rr_ms = float(stage[dominant])
-    rr_gbs = rr_bytes / (rr_ms * 1e-3) / 1e9 if rr_ms > 0 else 0.0
-    # whole-path algorithmic bytes per query: 4D + 8*Bb_visited + 4*nCand + 4*LP*nCand + 8k (this rank's candidates)
-    ncand_rank = cand_local / max(1, qn)
-    path_bytes_q = 4 * w["D"] + 8 * He + 4 * ncand_rank + 4 * LP * ncand_rank + 8 * k
-    n_local = (shard[1] - shard[0]) if shard else n
-    store_bytes = n_local * LP * 4
-    resident = "infinity_cache" if store_bytes < (256 << 20) else "hbm"
-
-    # HBM traffic of the dominant kernel from the committed PMC profile of this very command (profiles/pmc_latest.json,
-    # produced by scripts/profile.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE factor from the
-    # calibration in profiles/r01_pmc_calibration.json: 1.0 for 64-B code rows, 2.0 for 128-B rows)
-    traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        pms = pm if "runs" not in pm else next((r_ for r_ in pm["runs"] if r_.get("workload") == wl_name and r_.get("bv") == args.bv and r_.get("bb") == args.bb and r_.get("k") == args.k), {})
-        if pms.get("workload") == wl_name and pms.get("bv") == args.bv and pms.get("bb") == args.bb and pms.get("k") == args.k and world == 1 and not args.option:
-            ent = pms["kernels"].get(rr_name)
-            if ent:
-                traffic = (ent["FETCH_SIZE_KiB"] * pms["fetch_factor"] + ent["WRITE_SIZE_KiB"]) * 1024.0
-    except Exception:
-        traffic = None
-
-    out = {
-        "metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)",
-        "value": qps, "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if mode == "shard_db" else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("SIFT1M-shape synthetic" if wl_name in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
-                               "query(boundVectors=%d, boundBins=%d), k=%d" %
-                               (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, args.bv, args.bb, k),
-                   "workload_name": wl_name,
-                   "parallelism": {"single": "1 GPU", "replica": "%d GPUs: index replicated, queries sharded (%d per rank per step), no data-path collective" % (world, qn),
-                                   "shard_db": "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), traversal replicated, %s"
-                                               % (world, n_local, "per-shard top-k exchanged by query slice (all-to-all of [3][QN/W][k] words per peer), exact (dist,pos) merge "
-                                                  "of the own slice, all-gather of the merged [2][QN/W][k] slices" if args.exchange == "alltoall" else
-                                                  "ONE all-gather of per-shard top-k [3][QN][k] words per batch + exact (dist,pos) merge of all queries on every rank")}[mode],
-                   "exchange": args.exchange if mode == "shard_db" else None,
-                   "collective_backend": ({"nccl": "rccl"}.get(backend, backend) if (world > 1 or force_shard) else None), "collective_world_size": world,
-                   "options": args.option,
-                   "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call; the events cost ~10 us per call)"
-                                    % (len(timed_in_region), args.steps, {1: "", 2: "2nd"}.get(period, "%dth" % period)),
-                   "global_batch": units,
-                   "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
-                   "mean_candidates_this_rank": ncand_rank,
-                   "mean_bins_visited": He, "n_bins": meta["n_bins"], "max_bin": meta["max_bin"], "filter_fallbacks": st.get("filter_fallbacks"),
-                   "exact_rerank_of_topk": exact,
-                   "algorithmic_bytes_per_query": path_bytes_q,
-                   "path_GBps": path_bytes_q * qn * args.steps / elapsed / 1e9, "path_frac_of_hbm_peak": path_bytes_q * qn * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
-                   "stage_ms": stage, "dominant_kernel_by_time": rr_name, "build_s": {k_: meta[k_] for k_ in ("t_data", "t_encode", "t_csr")}},
-        "roofline": {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_ratio": (traffic / rr_bytes) if traffic else None,
-                     "resident": resident, "line_store_bytes": store_bytes,
-                     "avg_launch_ms": rr_ms,
-                     "algorithmic_bytes_per_launch": rr_bytes,
-                     "intermediate_bytes": rr_inter,
-                     "accounting": "SURVEY 8(d) terms only -- rerank+select: 4*nCand + 4*LP*nCand + 8k per query; traversal: 4*D + 8*Bb per query; "
-                                   "intermediate_bytes (L1virt and candidate-list round trips between the two launches) are listed, not priced",
-                     "timing": "mean of the kernel's own duration over the %d of the %d timed steps that carry events: start/stop HIP events attached to "
-                               "the dispatch (hipExtLaunchKernel) on the launch stream, read after the closing barrier" % (len(timed_in_region), args.steps),
-                     "other_kernels": {kname[n_]: {"avg_launch_ms": float(stage[n_]), "algorithmic_bytes_per_launch": kb[n_][0], "intermediate_bytes": kb[n_][1],
-                                                   "GBps": kb[n_][0] / max(stage[n_], 1e-9) / 1e6, "frac": kb[n_][0] / max(stage[n_], 1e-9) / 1e6 / HBM_PEAK_GBS}
-                                       for n_ in kname if n_ != dominant}},
-    }
-    if resident == "infinity_cache":
-        out["roofline"]["note"] = ("the %d MB line store of this workload stays in the 256 MiB Infinity Cache across batches: `frac` is priced against the HBM "
-                                   "peak but is not an HBM-bound result; the HBM-roofline configuration is --workload synth100m (BASELINE configs[2])" % (store_bytes >> 20))
-
-    # ---- measured stream bandwidth of this device (device-to-device copy of 1 GiB: read + write), reported beside the nominal
-    # peak the fractions above are priced with
+    # ---- measured read bandwidth of this device (read-only streaming kernel over 4 GiB, the access shape of the group-major
+    # rerank), reported beside the nominal peak the fractions above are priced with
     if mode == "single":
         try:
-            a_ = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-            b_ = torch.empty_like(a_)
-            a_.fill_(1.0)
-            for _ in range(2):
-                b_.copy_(a_)
-            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0_.record()
-            for _ in range(5):
-                b_.copy_(a_)
-            e1_.record()
-            torch.cuda.synchronize(dev)
-            gbs_ = 5 * 2 * a_.numel() * 4 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9
+            gbs_ = ctx.pkg.stream_read_GBps(4 << 30, 5, dev.index or 0)
             out["roofline"]["measured_stream_GBps"] = gbs_
-            out["roofline"]["frac_of_measured_stream"] = rr_gbs / gbs_
-            del a_, b_
-            torch.cuda.empty_cache()
+            out["roofline"]["measured_stream_what"] = "read-only kernel, 16-byte loads, every byte of a 4 GiB buffer once (pqt_debug_stream_read)"
+            out["roofline"]["frac_of_measured_stream"] = out["roofline"]["achieved"] / gbs_
         except Exception as e:
             out["roofline"]["measured_stream_GBps"] = None
 
@@ -620,8 +768,8 @@ def main():
         i2 = oi_.to(torch.int64) & 0xffffffff
         kb_ = kernel_bytes(w, qn, k_, st_["bins_visited"] / max(1, st_["queries"]), st_["candidates"], k_ <= 128)
         return {"queries_per_sec": qn / t2, "ms_per_step": t2 * 1e3, "k": k_, "recall@1": recall_at(i2, gt, 1), "recall@100": recall_at(i2, gt, 100),
-                "mean_candidates": float(out_cnt.float().mean()),
-                "stage_ms": dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), h_)),
+                "mean_candidates": float(out_cnt.float().mean()), "kernel_path": idx.last_path(),
+                "stage_ms": dict(zip(STAGES, h_)),
                 "rerank_select_GBps": kb_["rerank_select"][0] / max(h_[3], 1e-9) / 1e6,
                 "rerank_select_frac": kb_["rerank_select"][0] / max(h_[3], 1e-9) / 1e6 / HBM_PEAK_GBS}, oi_, od_
 
@@ -634,7 +782,7 @@ def main():
             leg["launch_structure"] = "fused traversal in wide mode (boundBins > 512: rows in blocks of 512, populated rows listed) + fused rerank/select"
             out["config"]["knobs_4096_4096"] = leg
             leg, _, _ = side_leg(4096, 4096, 4096, reps=3)  # the reference front-end's own call: queryKNN(..., 4096) (tool_query.cpp:155)
-            leg["launch_structure"] = "fused traversal (wide mode) + workgroup-per-query fused rerank/select for 128 < k <= 4096 (distances stay on chip)"
+            leg["launch_structure"] = "fused traversal (wide mode) + fused rerank/select for 128 < k <= 4096 (distances stay on chip)"
             out["config"]["knobs_4096_4096_k4096"] = leg
             idx.set_option("fused", 0)
             leg, _, _ = side_leg(4096, 4096, 4096, reps=3)
@@ -648,9 +796,9 @@ def main():
 
     # ---- batch split over two handles on two streams (same index data): the traversal of one half overlaps the rerank of
     # the other.  Reported beside the headline (never as `value`: the per-kernel roofline accounting above is single-stream)
-    if mode == "single" and not chunked and not os.environ.get("PQT_BENCH_NO_PIPELINE") and not args.option:
+    if mode == "single" and not W["chunked"] and not os.environ.get("PQT_BENCH_NO_PIPELINE") and not args.option:
         try:
-            idx2 = pkg.PqtIndex(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], device=dev.index or 0)
+            idx2 = ctx.pkg.PqtIndex(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], device=dev.index or 0)
             idx2.set_codebooks(meta["cb1"], meta["cb2"])
             idx2.build_heuristic(max(args.bb, 1))
             idx2.set_bins(meta["bin_ids"], meta["sizes"], meta["members"])
@@ -683,7 +831,7 @@ def main():
             out["config"]["two_handles_two_streams"] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
-    if mode == "single" and not args.no_cpu and not chunked:
+    if mode == "single" and not args.no_cpu and not W["chunked"]:
         from oracle import Oracle
         # the checker builds its OWN heuristic table (prepareHeuristic restatement) -- it is compared with the library's below
         o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=max(args.bb, 1))
@@ -722,44 +870,174 @@ def main():
                                          % (reps, qn, cpu_t),
                                "single_thread_qps": s1 / cpu1_t, "single_thread_ms_per_query": cpu1_t / s1 * 1e3,
                                "result_lists_identical_frac": same, "heuristic_table_identical": heur_same}
-    elif mode == "single" and not args.no_cpu and chunked and n <= 20_000_000:
-        out["cpu_baseline"] = cpu_baseline_chunked(pkg, idx, w, meta, queries, args, out_idx, out_dist, k)
+        del o, codes_host
+    elif mode == "single" and not args.no_cpu and W["chunked"] and n <= 20_000_000:
+        out["cpu_baseline"] = cpu_baseline_chunked(ctx.pkg, idx, w, meta, queries, args, out_idx, out_dist, k)
 
-    # ---- range-sharded run: the SAME database on ONE GPU (rank 0 builds it whole and times the single-GPU path while the
-    # others wait), so the line carries the denominator of its own strong-scaling ratio
     if mode == "shard_db":
-        ref1 = None
-        try:
-            if not args.no_ref1 and n <= 200_000_000:
-                if rank == 0:
-                    ridx, _, rmeta = build_index(pkg, w, local_rank, codebooks=(meta["cb1"], meta["cb2"]))
-                    ridx.build_heuristic(max(args.bb, 1))
-                    for ov in args.option:
-                        ridx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
-                    ro = (torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty((qn, k), dtype=torch.float32, device=dev), torch.empty(qn, dtype=torch.int32, device=dev))
-                    nst = max(3, min(args.steps, 10))
-                    t1g = time_steps(lambda: ridx.query_dev(queries, args.bv, args.bb, k, ro[0], ro[1], ro[2], stream=stream),
-                                     lambda: torch.cuda.synchronize(dev), 2, nst)
-                    same = bool(torch.equal(ro[0], out_idx) and torch.equal(ro[1], out_dist) and torch.equal(ro[2], out_cnt))
-                    h1 = ridx.stage_ms_history(nst).mean(0).tolist()
-                    ref1 = {"queries_per_sec": qn * nst / t1g, "ms_per_step": t1g / nst * 1e3, "results_identical_to_sharded": same,
-                            "stage_ms": dict(zip(("tables", "traverse", "gap", "rerank_select", "select"), h1)),
-                            "speedup_of_this_run": qps / (qn * nst / t1g)}
-                    ridx.close()
-                dist.barrier()
-        except Exception as e:
-            ref1 = {"error": repr(e)[:300]}
-        out["config"]["same_workload_1gpu"] = ref1
-        # every rank must hold the same merged result
-        chk = (sbuf.out_idx.to(torch.int64) & 0xffffffff).sum().reshape(1)
-        lo_c, hi_c = chk.clone(), chk.clone()
-        dist.all_reduce(lo_c, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi_c, op=dist.ReduceOp.MAX)
-        out["config"]["ranks_agree"] = bool(lo_c.item() == hi_c.item())
+        out["config"]["same_workload_1gpu"] = ref1 = same_workload_1gpu(ctx, args, W, R)
+        out["config"]["ranks_agree"] = ranks_agree(ctx, R)  # every rank must hold the same merged result
+        if W["name"] == SWEEP_WL and ref1 and "speedup_of_this_run" in ref1:
+            out["scaling_vs_1gpu"] = ref1["speedup_of_this_run"]
+            out["scaling_vs_1gpu_what"] = "this line's queries/sec / the same 100 M-vector database and batch on ONE GPU (config.same_workload_1gpu, timed on rank 0 in this run)"
+        if W["name"] != SWEEP_WL and not args.workload and not args.no_scaling_leg:
+            # --gpus 8: `value` above is configs[3]'s size; the sweep's own workload (100 M vectors, configs[2]) rides beside it so that
+            # N = 2, 4, 8 all carry the ratio against ONE GPU on ONE workload
+            idx.close()
+            del W, R, idx, queries, out_idx, out_dist, out_cnt
+            torch.cuda.empty_cache()
+            W2 = build_workload(ctx, args, SWEEP_WL, mode, codebooks=(meta["cb1"], meta["cb2"]))
+            R2 = time_path(ctx, args, W2, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period)
+            l2 = make_line(ctx, args, W2, R2)
+            ref2 = same_workload_1gpu(ctx, args, W2, R2)
+            out["config"]["strong_scaling_leg"] = {"workload": l2["config"]["workload"], "queries_per_sec": l2["value"], "ms_per_step": l2["ms_per_step"],
+                                                   "stage_ms": l2["config"]["stage_ms"], "recall@1": l2["config"]["recall@1"], "mean_candidates_this_rank": l2["config"]["mean_candidates_this_rank"],
+                                                   "roofline": {k_: l2["roofline"][k_] for k_ in ("kernel", "achieved", "frac", "avg_launch_ms")},
+                                                   "same_workload_1gpu": ref2, "ranks_agree": ranks_agree(ctx, R2)}
+            if ref2 and "speedup_of_this_run" in ref2:
+                out["scaling_vs_1gpu"] = ref2["speedup_of_this_run"]
+                out["scaling_vs_1gpu_what"] = ("strong scaling of the sweep's workload (config.strong_scaling_leg: 100 M vectors range-sharded over this run's GPUs / the same database "
+                                               "on ONE GPU); `value` is the 1 B-vector configuration, which does not fit one GPU")
+            W2["idx"].close()
+    elif mode == "single":
+        out["scaling_note"] = ("N = 1 line = BASELINE configs[1]; the strong-scaling sweep (N >= 2) runs ONE workload, the 100 M-vector configs[2] database, and every N >= 2 "
+                               "line carries its own one-GPU denominator (config.same_workload_1gpu) and the ratio (scaling_vs_1gpu); this line's config.hbm_roofline_leg "
+                               "is that workload on this GPU")
+        if not args.no_hbm_leg and not args.workload:
+            try:
+                idx.close()
+                del W, R, idx, queries, out_idx, out_dist, out_cnt, raw_u8
+                torch.cuda.empty_cache()
+                out["config"]["hbm_roofline_leg"] = hbm_roofline_leg(ctx, args)
+            except Exception as e:
+                out["config"]["hbm_roofline_leg"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1 or force_shard:
+    if ctx.collectives:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
+# real data (BASELINE.md 2 "Real SIFT1M/SIFT1B"): the reference's own pipeline -- convert -> tool_createdb -> query -> recall
+# (scripts/prepare_data.sh:3, tool_createdb.cpp:73-114, cpu_version/tools/query.cpp:29-82) -- on the files of --dataset-dir
+# ------------------------------------------------------------------------------------------------------
+def read_vecs(path, limit=None):
+    """.fvecs / .bvecs / .ivecs (TEXMEX layout: per vector an int32 dimension followed by dim values)."""
+    ext = os.path.splitext(path)[1]
+    item = {".fvecs": np.float32, ".ivecs": np.int32, ".bvecs": np.uint8}[ext]
+    raw = np.memmap(path, dtype=np.uint8, mode="r")
+    dim = int(np.frombuffer(raw[:4].tobytes(), np.int32)[0])
+    rec = 4 + dim * np.dtype(item).itemsize
+    nvec = raw.shape[0] // rec
+    if limit is not None:
+        nvec = min(nvec, limit)
+    body = np.ascontiguousarray(raw[:nvec * rec].reshape(nvec, rec)[:, 4:])
+    return body.view(item).reshape(nvec, dim)
+
+
+def find_vecs(d, stem):
+    for ext in (".fvecs", ".bvecs", ".ivecs"):
+        for pre in ("sift_", "bigann_", ""):
+            p = os.path.join(d, pre + stem + ext)
+            if os.path.exists(p):
+                return p
+    return None
+
+
+def run_dataset_dir(ctx, args):
+    import subprocess
+    import tempfile
+    d = args.dataset_dir
+    pb, pl, pq, pg = find_vecs(d, "base"), find_vecs(d, "learn"), find_vecs(d, "query"), find_vecs(d, "groundtruth")
+    if not (pb and pq and pg):
+        raise SystemExit("--dataset-dir %s: need sift_base.{fvecs,bvecs}, sift_query.{fvecs,bvecs} and sift_groundtruth.ivecs (sift_learn optional)" % d)
+    wl = dict(WORKLOADS["sift1m"])  # BASELINE configs[0]/[1] parameters
+    D, P, C1, C2, Wc, LP = (wl[k_] for k_ in ("D", "P", "C1", "C2", "W", "LP"))
+    base = read_vecs(pb).astype(np.float32)
+    queries_h = read_vecs(pq).astype(np.float32)
+    gt_h = read_vecs(pg)[:, 0].astype(np.int64)
+    learn = read_vecs(pl, args.dataset_train).astype(np.float32) if pl else base[:args.dataset_train]
+    assert base.shape[1] == D and queries_h.shape[1] == D, "SIFT dimension expected"
+    n, qn = base.shape[0], queries_h.shape[0]
+    host = os.path.join(ROOT, "product-quantization-tree_amd", "host")
+    tmp = tempfile.mkdtemp(prefix="pqt_real_")
+    t0 = time.time()
+
+    def write_umem(path, a):  # the reference's .umem container: ASCII "<num>\n<dim>\n" padded to 20 bytes + uint8 payload
+        hdr = ("%d\n%d\n" % a.shape).encode().ljust(20, b"\0")
+        with open(path, "wb") as f:
+            f.write(hdr)
+            f.write(np.ascontiguousarray(a, np.uint8).tobytes())
+    # learn vectors first, base after them: tool_createdb trains on the first --train rows of --dataset; a second call with the
+    # finished codebook builds the database from the base file
+    write_umem(os.path.join(tmp, "learn.umem"), learn)
+    write_umem(os.path.join(tmp, "base.umem"), base)
+    common = ["--dim", str(D), "--p", str(P), "--c1", str(C1), "--c2", str(C2), "--lineparts", str(LP), "--w", str(Wc), "--basename", os.path.join(tmp, "real"),
+              "--device", str(ctx.dev.index or 0), "--hashed", "0"]
+    r = subprocess.run([os.path.join(host, "tool_createdb")] + common + ["--dataset", os.path.join(tmp, "learn.umem"), "--train", str(learn.shape[0])], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("tool_createdb (training) failed: " + r.stderr[-2000:] + r.stdout[-2000:])
+    t_train = time.time() - t0
+    r = subprocess.run([os.path.join(host, "tool_createdb")] + common + ["--dataset", os.path.join(tmp, "base.umem")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit("tool_createdb (database) failed: " + r.stderr[-2000:] + r.stdout[-2000:])
+    t_db = time.time() - t0 - t_train
+    pre = os.path.join(tmp, "real_%d_%d_%d_%d" % (D, P, C1, C2))
+    # .ppqt: ASCII header dim p p2 c1 c2 ndbs, then cb1, cb2 (PerturbationProTree.cu:60-220)
+    with open(pre + ".ppqt", "rb") as f:
+        hdr = [int(f.readline()) for _ in range(6)]
+        cb1 = np.frombuffer(f.read(4 * C1 * D), np.float32).reshape(C1, D).copy()
+        cb2 = np.frombuffer(f.read(4 * P * C1 * C2 * (D // P)), np.float32).reshape(P, C1, C2, D // P).copy()
+    assert hdr[0] == D and hdr[1] == P and hdr[3] == C1 and hdr[4] == C2
+    # .bins (treequantizer.hpp:745-774): nbins, then {id, size, members...}, then len, lp, codes
+    raw = np.fromfile(pre + ".bins", np.uint32)
+    nb, o = int(raw[0]), 1
+    ids_, sizes_, mem_ = np.empty(nb, np.uint32), np.empty(nb, np.uint32), []
+    for b in range(nb):
+        ids_[b], sizes_[b] = raw[o], raw[o + 1]
+        mem_.append(raw[o + 2:o + 2 + int(raw[o + 1])])
+        o += 2 + int(raw[o + 1])
+    members = np.concatenate(mem_) if mem_ else np.empty(0, np.uint32)
+    assert int(raw[o]) == n and int(raw[o + 1]) == LP
+    codes = raw[o + 2:o + 2 + n * LP].reshape(n, LP)
+    idx = ctx.pkg.PqtIndex(D, P, C1, C2, Wc, LP, device=ctx.dev.index or 0)
+    idx.set_codebooks(cb1, cb2)
+    idx.build_heuristic(max(args.bb, 1))
+    idx.set_bins(ids_, sizes_, members)
+    idx.set_lines(codes)
+    k = args.k
+    q = torch.from_numpy(queries_h).to(ctx.dev)
+    oi = torch.empty((qn, k), dtype=torch.int32, device=ctx.dev)
+    od = torch.empty((qn, k), dtype=torch.float32, device=ctx.dev)
+    oc = torch.empty(qn, dtype=torch.int32, device=ctx.dev)
+    torch.cuda.synchronize(ctx.dev)
+    elapsed = time_steps(lambda: idx.query_dev(q, args.bv, args.bb, k, oi, od, oc, stream=ctx.stream), lambda: torch.cuda.synchronize(ctx.dev), args.warmup, args.steps)
+    gt = torch.from_numpy(gt_h).to(ctx.dev)
+    it = oi.to(torch.int64) & 0xffffffff
+    rec = {"recall@1": recall_at(it, gt, 1), "recall@10": recall_at(it, gt, 10), "recall@100": recall_at(it, gt, 100)}
+    # the checker on the same index: recall by the reference's definition (cpu_version/tools/query.cpp:29-82: GT[0] at rank < R of the sorted candidate list)
+    from oracle import Oracle
+    o_ = Oracle(D, P, C1, C2, Wc, LP, heur_keep=max(args.bb, 1))
+    o_.set_codebooks(cb1, cb2)
+    o_.import_bins(ids_, sizes_, members)
+    o_.import_codes(codes)
+    o_.set_sort_mode(1)
+    ci, cd, cc = o_.query_batch(queries_h, args.bv, args.bb, k, nthreads=usable_cores(o_.max_threads()))
+    ct = torch.from_numpy(ci.astype(np.int64))
+    gtc = gt.cpu()
+    orec = {"recall@1": recall_at(ct, gtc, 1), "recall@10": recall_at(ct, gtc, 10), "recall@100": recall_at(ct, gtc, 100)}
+    gi = oi.cpu().numpy().view(np.uint32)
+    same = float(np.mean([np.array_equal(gi[i], ci[i]) for i in range(qn)]))
+    idx.close()
+    return {"metric": "queries/sec + recall@1/@100, SIFT1M (1 GPU) and SIFT1B (8 GPUs)", "value": qn * args.steps / elapsed, "unit": "queries/sec", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "real: %s (%d base, %d queries, tree trained on %d vectors by tool_createdb)" % (d, n, qn, learn.shape[0]),
+            "config": {"workload": "real data N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, query(boundVectors=%d, boundBins=%d), k=%d"
+                                   % (n, D, P, C1, C2, Wc, LP, qn, args.bv, args.bb, k),
+                       "built_by": "product front-end: tool_createdb (createTree on the learn set, buildKBestDB chunks + CSR merge), dumps .ppqt + .bins read back here",
+                       "train_s": t_train, "build_db_s": t_db, "mean_candidates": float(oc.to(torch.int64).float().mean()),
+                       "engine": rec, "checker_on_same_index": orec, "id_lists_identical_frac": same,
+                       "recall_definition": "cpu_version/tools/query.cpp:29-82: fraction of queries whose ground-truth nearest neighbour appears at rank < R"}}
 
 
 def cpu_baseline_chunked(pkg, idx, w, meta, queries, args, out_idx, out_dist, k):

@@ -243,9 +243,19 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt_host, float*
  * table of 2^log2_rows rows (choose it far above the 256 MiB Infinity Cache); known bytes = gathers*row_bytes.  Run it
  * under `rocprofv3 --pmc FETCH_SIZE` (scripts/pmc_calibrate.sh) to get the counter-to-bytes ratio of this access shape. */
 int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_bytes, uint64_t gathers, float* out_ms);
+/* Read-only streaming probe: `reps` launches of a kernel that reads every 16-byte piece of a `bytes`-sized buffer once
+ * (coalesced, four loads per lane in flight); *out_ms = mean launch time.  bench.py reports bytes / time beside the nominal
+ * HBM peak (choose bytes far above the 256 MiB Infinity Cache). */
+int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms);
 int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
-/* duration (ms) of each launch of the dominant kernel (rerank) in the last call, via HIP events on the
- * stream it ran on; returns the number of launches written (<= cap). */
+/* Which kernels the last pqt_query* call launched, as text (tests assert the path taken, not only the result):
+ * "traverse=<fused|fused-wide|staged>[-shape1|-shape2|-p2|-generic] rerank=<lds-table|l2-table|mode1-nwN|mode2-nwN|wg-gG|
+ * big-*|staged-*>[-runs] chunks=<n>".  Returns the length written (<= cap - 1, NUL terminated). */
+int pqt_get_last_path(const pqt_index* idx, char* out, int cap);
+/* duration (ms) of each launch of the dominant kernel (rerank) in the most recent query call that carried per-kernel events
+ * (with "stage_timing" = N > 1 not every call does; 0 launches are reported when none of the last 32 calls did), via HIP
+ * events on the stream it ran on; returns the number of launches written (<= cap).  pqt_get_stats reports its ms_* fields
+ * for the same call. */
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out_ms, int cap);
 /* per-stage device times of the most recent query calls (ring of 32), oldest first: out[n][5] = {tables, traversal/bins,
  * gap, rerank(+select when fused), select} in ms; returns n (<= cap).  On the fused path the start/stop timestamps ride

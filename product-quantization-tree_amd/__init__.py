@@ -47,13 +47,13 @@ EXPORTS = [
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
-    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle",
+    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read",
 ]
 
 
 def build(force=False):
     """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", CSRC, "libpqt_hip.so"])
@@ -107,6 +107,8 @@ def lib():
     L.pqt_get_stats.argtypes = [C.c_void_p, C.POINTER(pqt_stats)]
     L.pqt_get_rerank_launch_ms.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_get_stage_ms_history.argtypes = [C.c_void_p, f32p, C.c_int]
+    L.pqt_get_last_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.pqt_debug_stream_read.argtypes = [C.c_int, C.c_uint64, C.c_int, f32p]
     L.pqt_dev_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_uint16), f32p, C.c_int]
     _LIB = L
     return L
@@ -255,6 +257,12 @@ class PqtIndex:
         _chk(self.L.pqt_get_stats(self.h, C.byref(s)))
         return s.as_dict()
 
+    def last_path(self):
+        """Kernel variants of the last query call, e.g. 'traverse=fused-shape2 rerank=mode2-nw12-runs chunks=1'."""
+        buf = C.create_string_buffer(256)
+        _chk(self.L.pqt_get_last_path(self.h, buf, 256))
+        return buf.value.decode()
+
     def stage_ms_history(self, cap=32):
         """[n][5] per-call device ms of {tables, traversal, gap between the fused kernels, rerank(+select), select}, oldest first."""
         out = np.zeros((cap, 5), np.float32)
@@ -278,6 +286,13 @@ class PqtIndex:
         _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p), _p(sb, u32p),
                                    _p(ci, u32p) if cands else None, _p(cd, f32p) if cands else None, _p(nc, u32p)))
         return dict(l1virt=l1, seg_d2=sd, seg_bin=sb, ncand=nc, cand_idx=ci, cand_dist=cd, stride=stride)
+
+
+def stream_read_GBps(nbytes=4 << 30, reps=5, device=0):
+    """GB/s of a read-only streaming kernel over nbytes of device memory (measured beside the nominal HBM peak)."""
+    ms = C.c_float(0)
+    _chk(lib().pqt_debug_stream_read(device, nbytes, reps, C.byref(ms)))
+    return nbytes / (ms.value * 1e-3) / 1e9
 
 
 def dev_triangle(a, b, c, l, device=0):

@@ -95,6 +95,8 @@ struct pqt_index {
   size_t scratchBudget = (size_t)24 << 30;
   // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
+  bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
+  std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
   int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = -1 /* auto */; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
 };
 
@@ -437,6 +439,17 @@ int stageMs(const pqt_index* idx, int slot, int ch, float st[5]) {
   return prev;
 }
 
+// ring slot of the most recent query call that carried per-kernel events (option "stage_timing" = N > 1: not every call
+// does), or -1
+int lastTimedSlot(const pqt_index* idx) {
+  const int have = (int)std::min<unsigned long long>(idx->calls, (unsigned long long)kRing);
+  for (int b = 1; b <= have; ++b) {
+    const int slot = (int)((idx->calls - b) % kRing);
+    if (idx->ringChunks[slot] > 0 && (idx->evMask[slot][0] & 1u)) return slot;
+  }
+  return -1;
+}
+
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
               uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
   if (!idx) return fail(PQT_ERR_INVALID, "null index");
@@ -545,7 +558,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   if (wgG && (size_t)wgG * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8 > kMaxLds) wgG = 0;
   // a shape whose fused kernel does not fit the LDS (e.g. C1 = 256 with >= 16 line parts) runs the staged rerank/select,
   // which needs LP*C1*4 bytes only
-  if (fused && !wgG && lFused > kMaxLds) fused = false;
+  if (fused && !wgG && !useBias && lFused > kMaxLds) fused = false;  // (useBias implies lBias6 <= kMaxLds: the 6- or 12-wave filter kernel is the one launched)
   // bin runs instead of a candidate list: fused traversal -> MODE 0 rerank with the LDS table (the SIFT1M shapes)
   // bin runs instead of a candidate list.  MODE 0 with the LDS table (SIFT1M shape): only on request (measured a net loss);
   // MODE 2 at the configs[2]/[3] shape (long bins, few runs per query: 64 slots per wave): on unless switched off.
@@ -598,6 +611,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     const int balance = idx->balance >= 0 ? idx->balance : ((size_t)idx->nIds * d.LP * 4 > ((size_t)256 << 20) ? 2 : 1);
     const bool useSched = severalPerWave && balance == 2;
     uint32_t* const schedCntArg = useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr;
+    if (useSched) {
+      // the registration counts of this block are zeroed by the previous rerank launch; a call that failed between its
+      // traversal and its rerank left them dirty: clear the block before it is registered into again
+      if (idx->poolDirty) HIPCHK(hipMemsetAsync(poolBlock(idx, idx->poolPos), 0, kPoolWords * sizeof(uint32_t), st));
+      idx->poolDirty = true;
+    }
     idx->curSchedCap = (nq + 7) / 8;  // entries a (pool, class) list can be asked to hold: a pool's queries
     if (useSched && (uint64_t)idx->curSchedCap > idx->schedCapQ) {
       if ((rc = devAlloc(&idx->d_schedList, (size_t)8 * PQT_SCHED_CLASSES * idx->curSchedCap))) return rc;
@@ -698,6 +717,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
 #undef PQT_LAUNCH_BIAS1
 #undef PQT_LAUNCH_BIAS
         if (rc) return rc;
+        idx->poolDirty = false;  // the launch consumes this chunk's registrations and zeroes the next block
       } else if (wgG) {
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         rc = wgG == 4 ? launchRSWG<4>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
@@ -709,6 +729,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         nextZeroed = true;
         if ((rc = launchRerankSelect(idx, coarseLds, grid, emitRuns ? lRuns : lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                      stride, k, nq, oI, oD, oP))) return rc;
+        idx->poolDirty = false;
       }
       if (!leanEvents) PQT_REC(EV_RERANK);
     } else if (bigK) {
@@ -766,6 +787,23 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
   idx->lastFilter = useFilter;
   idx->lastRuns = emitRuns;
+  {
+    // which kernels ran (pqt_get_last_path): tests assert the path, not only the result
+    std::string tp = !travFused ? "traverse=staged" : (travWide ? "traverse=fused-wide" : "traverse=fused");
+    if (travFused) {
+      const bool twoOk = idx->d_heur4 && idx->d_filter && !(idx->dbg & (4096u | 2048u | 32u)) && !d.hashMod;
+      const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
+      tp += shape ? (shape == 1 ? "-shape1" : "-shape2") : (travP2 ? "-p2" : "-generic");
+    }
+    std::string rp;
+    if (fused) {
+      if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "");
+      else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
+      else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "");
+    } else if (bigK) rp = bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table";
+    else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
+    idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks);
+  }
   idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
@@ -1141,7 +1179,7 @@ int pqt_build_assign_encode(pqt_index* idx, const float* vecs_dev, uint64_t n, u
   for (uint64_t v0 = 0; v0 < n; v0 += maxGrid) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(maxGrid, n - v0);
     hipLaunchKernelGGL(pqt_k_assign_encode, dim3(nb), dim3(PQT_BLOCK), lds, st, vecs_dev + v0 * idx->dp.D, idx->d_cb1, idx->d_cb2,
-                       idx->d_coarse, idx->dp, out_bin + v0, out_codes + v0 * idx->dp.LP);
+                       idx->d_coarse, idx->dp, out_bin + v0, out_codes + v0 * idx->dp.LP, (idx->dbg >> 13) & 1u);
   }
   HIPCHK(hipGetLastError());
   if (!stream) HIPCHK(hipStreamSynchronize(st));
@@ -1336,6 +1374,38 @@ int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_byte
   return PQT_OK;
 }
 
+int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms) {
+  if (bytes < (1u << 20) || reps < 1 || !out_ms) return fail(PQT_ERR_INVALID, "bytes >= 1 MiB, reps >= 1");
+  HIPCHK(hipSetDevice(device));
+  void* buf = nullptr; unsigned long long* sink = nullptr;
+  HIPCHK(hipMalloc(&buf, bytes));
+  if (hipMalloc((void**)&sink, 8) != hipSuccess) { (void)hipFree(buf); return fail(PQT_ERR_DEVICE, "allocation failed"); }
+  hipDeviceProp_t prop;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0;
+  hipError_t e = hipMemset(buf, 1, bytes);
+  if (e == hipSuccess) e = hipMemset(sink, 0, 8);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) {
+    const unsigned grid = (unsigned)std::max(1, prop.multiProcessorCount) * 16u;
+    hipLaunchKernelGGL(pqt_k_stream_read, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);  // warm-up
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, 0);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(pqt_k_stream_read, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);
+    if (e == hipSuccess) e = hipEventRecord(e1, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(buf); (void)hipFree(sink);
+  if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
+  *out_ms = ms / (float)reps;
+  return PQT_OK;
+}
+
 int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   if (!cidx || !out) return fail(PQT_ERR_INVALID, "null argument");
   pqt_index* idx = const_cast<pqt_index*>(cidx);
@@ -1358,19 +1428,30 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
     for (uint32_t v : ni) s.bins_nonempty += v;
     s.bins_visited = (uint64_t)idx->lastHe * idx->lastQn;
   }
+  // stage times: those of the last call when it carried events, else of the most recent call that did (stage_timing = N > 1)
   int lastEv = -1;
-  for (int ch = 0; ch < idx->nChunks; ++ch) {
+  const int tslot = lastTimedSlot(idx);
+  const int tchunks = tslot >= 0 ? idx->ringChunks[tslot] : 0;
+  for (int ch = 0; ch < tchunks; ++ch) {
     float st[5] = {0, 0, 0, 0, 0};
-    lastEv = stageMs(idx, idx->ringPos, ch, st);
+    lastEv = stageMs(idx, tslot, ch, st);
     s.ms_tables += st[0]; s.ms_bins += st[1]; s.ms_rerank += st[2] + st[3]; s.ms_select += st[4];
   }
-  if (idx->nChunks > 0 && lastEv > 0) {
+  if (tchunks > 0 && lastEv > 0) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, idx->evRing[idx->ringPos][0][EV_BEGIN], idx->evRing[idx->ringPos][idx->nChunks - 1][lastEv]) == hipSuccess) s.ms_total = ms;
+    if (hipEventElapsedTime(&ms, idx->evRing[tslot][0][EV_BEGIN], idx->evRing[tslot][tchunks - 1][lastEv]) == hipSuccess) s.ms_total = ms;
   }
   idx->stats = s;
   *out = s;
   return PQT_OK;
+}
+
+int pqt_get_last_path(const pqt_index* idx, char* out, int cap) {
+  if (!idx || !out || cap < 1) return fail(PQT_ERR_INVALID, "null argument");
+  const size_t n = std::min<size_t>(idx->lastPath.size(), (size_t)cap - 1);
+  memcpy(out, idx->lastPath.data(), n);
+  out[n] = 0;
+  return (int)n;
 }
 
 int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
@@ -1395,10 +1476,13 @@ int pqt_get_stage_ms_history(const pqt_index* idx, float* out, int cap) {
 int pqt_get_rerank_launch_ms(const pqt_index* idx, float* out, int cap) {
   if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
   if (hipSetDevice(idx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(PQT_ERR_DEVICE, "sync failed");
+  // the last call when it carried events, else the most recent call that did (stage_timing = N > 1); 0 launches when no
+  // call of the ring was timed (stage_timing = 0)
+  const int tslot = lastTimedSlot(idx);
   int n = 0;
-  for (int ch = 0; ch < idx->nChunks && n < cap; ++ch) {
+  for (int ch = 0; tslot >= 0 && ch < idx->ringChunks[tslot] && n < cap; ++ch) {
     float st[5] = {0, 0, 0, 0, 0};
-    if (stageMs(idx, idx->ringPos, ch, st) < 0) return fail(PQT_ERR_DEVICE, "event read failed");
+    if (stageMs(idx, tslot, ch, st) < 0) return fail(PQT_ERR_DEVICE, "event read failed");
     const float ms = st[3];
     out[n++] = ms;
   }

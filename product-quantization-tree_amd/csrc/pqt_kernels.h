@@ -529,7 +529,8 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
     const float* __restrict__ X, const float* __restrict__ cb1, const float* __restrict__ cb2,
-    const float* __restrict__ coarse, PqtDevParams prm, uint32_t* __restrict__ outBin, uint32_t* __restrict__ outCodes) {
+    const float* __restrict__ coarse, PqtDevParams prm, uint32_t* __restrict__ outBin, uint32_t* __restrict__ outCodes,
+    uint32_t dbgSkipPairs /* measurement only (debug_bits 8192): no pair search, codes are written as 0 */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const uint32_t D = prm.D, P = prm.P, C1 = prm.C1, C2 = prm.C2, LP = prm.LP, S = prm.S, SS = prm.SS, R = prm.R;
   float* sX = smem;
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
     if (e < npairs) { while (rem >= C1 - 1 - A) { rem -= C1 - 1 - A; ++A; } }
     pairAB[i] = A | ((A + 1 + rem) << 16);
   }
+  if (dbgSkipPairs) { for (uint32_t lp = tid; lp < LP; lp += PQT_BLOCK) outCodes[v * LP + lp] = 0; return; }
   for (uint32_t lp = 0; lp < LP; ++lp) {
     uint64_t best = ~0ull;
     auto eval = [&](const uint32_t e, const uint32_t A, const uint32_t B) {
@@ -2280,6 +2282,20 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restric
   uint32_t acc = 0;
 #pragma unroll
   for (int v = 0; v < ROWV; ++v) { const uint4 x = table[row * ROWV + v]; acc ^= x.x ^ x.y ^ x.z ^ x.w; }
+  if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
+}
+
+// read-only streaming probe: every 16-byte piece of a buffer exactly once, four independent loads per lane in flight (the
+// access shape of the group-major rerank: 64 lanes = one contiguous KB).  bench.py reports its GB/s beside the nominal peak.
+__global__ __launch_bounds__(256) void pqt_k_stream_read(const uint4* __restrict__ p, uint64_t n16, unsigned long long* __restrict__ sink) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  }
+  for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
 }
 

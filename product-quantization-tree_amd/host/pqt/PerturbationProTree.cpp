@@ -27,7 +27,7 @@ void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
     : ProTree(_dim, _p, _p2), d_idx(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
-      d_hashCounts(nullptr), d_hashSizeHeld(0), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
+      d_hashCounts(nullptr), d_hashSizeHeld(0), d_lineById(nullptr), d_lineByIdValid(false), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
 
 void PerturbationProTree::releaseDeviceScratch() {
@@ -35,7 +35,9 @@ void PerturbationProTree::releaseDeviceScratch() {
   if (d_resDist) (void)hipFree(d_resDist);
   if (d_hashPrefix) (void)hipFree(d_hashPrefix);
   if (d_hashCounts) (void)hipFree(d_hashCounts);
+  if (d_lineById) (void)hipFree(d_lineById);
   d_resIdx = nullptr; d_resDist = nullptr; d_resCap = 0; d_hashPrefix = d_hashCounts = nullptr; d_hashSizeHeld = 0;
+  d_lineById = nullptr; d_lineByIdValid = false;
 }
 
 PerturbationProTree::~PerturbationProTree() {
@@ -280,6 +282,9 @@ void PerturbationProTree::setBins(size_t _nbins, const uint* _ids, const uint* _
 
 void PerturbationProTree::setDB(uint _N, const uint* _prefix, const uint* _counts, const uint* _dbIdx, uint _hashSize) {
   d_N = _N;
+  // the exact bin ids are not recoverable from the hashed form: the exact-bin state (and the dense getters cached from it) go
+  h_binIds.clear(); h_binSizes.clear(); h_members.clear();
+  d_hashSizeHeld = 0;
   check(pqt_index_set_db_hashed(handle(), _N, _prefix, _counts, _dbIdx, _hashSize), "pqt_index_set_db_hashed");
 }
 
@@ -291,6 +296,7 @@ void PerturbationProTree::prepareEmptyLambda(uint _N, uint _lParts) {
 
 void PerturbationProTree::setLines(const lineDescr* _lines, size_t _N) {
   h_lines.assign(_lines, _lines + _N * d_lineParts);
+  d_lineByIdValid = false;
   check(pqt_index_set_lines_host(handle(), reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
 }
 
@@ -367,6 +373,7 @@ void PerturbationProTree::finishDB() {
   for (auto& kv : bins) { ids.push_back(kv.first); sizes.push_back((uint)kv.second.size()); members.insert(members.end(), kv.second.begin(), kv.second.end()); }
   setBins(ids.size(), ids.data(), sizes.data(), members.data());
   check(pqt_index_set_lines_host(h, reinterpret_cast<const uint32_t*>(h_lines.data()), n, 0), "pqt_index_set_lines_host");
+  d_lineByIdValid = false;
   h_binOfVec.clear();
   h_binOfVec.shrink_to_fit();
 }
@@ -442,12 +449,27 @@ const uint* PerturbationProTree::getDBIdx() {
 }
 
 const lineDescr* PerturbationProTree::getLine() {
+  handle();
+  if (h_lines.empty()) throw std::runtime_error("getLine: no line codes held");
+  if (!d_lineByIdValid) {
+    if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+    if (d_lineById) (void)hipFree(d_lineById);
+    d_lineById = nullptr;
+    if (hipMalloc((void**)&d_lineById, h_lines.size() * sizeof(lineDescr)) != hipSuccess) throw std::runtime_error("device allocation failed");
+    h2d(d_lineById, h_lines.data(), h_lines.size() * sizeof(lineDescr));
+    d_lineByIdValid = true;
+  }
+  return d_lineById;
+}
+
+const lineDescr* PerturbationProTree::getLineBinOrder() {
   const uint32_t* codes = nullptr;
   check(pqt_index_device_arrays(handle(), nullptr, &codes, nullptr), "pqt_index_device_arrays");
   return reinterpret_cast<const lineDescr*>(codes);
 }
 
 const uint* PerturbationProTree::getBinPrefix(uint _hashSize) {
+  if (h_binIds.empty()) throw std::runtime_error("getBinPrefix/getBinCounts: no exact bins held (setBins / loadBins / buildKBestDB first; a hashed setDB cannot be re-hashed)");
   if (d_hashSizeHeld != _hashSize) {
     if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
     std::vector<uint> prefix, counts, dbIdx;

@@ -139,11 +139,16 @@ class PerturbationProTree : public ProTree {
   void exportHashed(uint _hashSize, std::vector<uint>& _prefix, std::vector<uint>& _counts, std::vector<uint>& _dbIdx) const;
 
   /** DEVICE pointers like the reference's getters (PerturbationProTree.hh:97-103).  getDBIdx(): vector ids grouped by
-   *  bin; getLine(): the line codes in the same order (row i belongs to getDBIdx()[i]); getBinPrefix()/getBinCounts():
-   *  the dense hashed arrays of _hashSize entries, materialised on the first call (the engine itself keeps a compact
-   *  two-choice table of the non-empty bins instead of these 2 x 1.6 GB). */
+   *  bin.  getLine(): the line codes indexed by VECTOR ID like the reference's d_lineLambda (PerturbationProTree.cu:5134;
+   *  row i = code of vector i, the order of the .lines dump) -- an id-ordered device copy materialised from the host
+   *  copy on the first call after the lines changed (the engine itself reads a bin-ordered store).  getLineBinOrder(): that
+   *  bin-ordered store (row i belongs to getDBIdx()[i]).  getBinPrefix()/getBinCounts(): the dense hashed arrays of
+   *  _hashSize entries, materialised on the first call after the bins changed (the engine keeps a compact two-choice
+   *  table of the non-empty bins instead of these 2 x 1.6 GB); they need the exact bins (setBins / loadBins /
+   *  buildKBestDB) and throw after setDB / loadHashedDB, whose bin ids are not recoverable. */
   const uint* getDBIdx();
   const lineDescr* getLine();
+  const lineDescr* getLineBinOrder();
   const uint* getBinPrefix(uint _hashSize = 400000000u);
   const uint* getBinCounts(uint _hashSize = 400000000u);
 
@@ -163,6 +168,7 @@ class PerturbationProTree : public ProTree {
   // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
   uint* d_resIdx; float* d_resDist; size_t d_resCap;
   uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;
+  lineDescr* d_lineById; bool d_lineByIdValid;  // id-ordered device copy behind getLine()
   std::vector<uint> h_binOfVec;  // chunked build: bin id of every vector seen so far
   int d_device;
   uint d_w, d_lineParts, d_boundVectors, d_boundBins, d_heurRows;

@@ -74,9 +74,10 @@ int main(int argc, char** argv) {
       t2.saveBins(out + ".devbuild.bins");
       t2.saveHashedDB(out + ".h", hs);
       // getters hand out DEVICE arrays (PerturbationProTree.hh:97-103)
-      std::vector<uint> dbidx(n), prefix(hs), counts(hs), codes((size_t)n * lp);
+      std::vector<uint> dbidx(n), prefix(hs), counts(hs), codes((size_t)n * lp), codesBin((size_t)n * lp);
       if (hipMemcpy(dbidx.data(), t2.getDBIdx(), (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
           hipMemcpy(codes.data(), t2.getLine(), codes.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(codesBin.data(), t2.getLineBinOrder(), codesBin.size() * 4, hipMemcpyDeviceToHost) != hipSuccess ||
           hipMemcpy(prefix.data(), t2.getBinPrefix(hs), (size_t)hs * 4, hipMemcpyDeviceToHost) != hipSuccess ||
           hipMemcpy(counts.data(), t2.getBinCounts(hs), (size_t)hs * 4, hipMemcpyDeviceToHost) != hipSuccess)
         throw std::runtime_error("getter read-back failed");
@@ -85,6 +86,18 @@ int main(int argc, char** argv) {
       g.write((const char*)codes.data(), codes.size() * 4);
       g.write((const char*)prefix.data(), prefix.size() * 4);
       g.write((const char*)counts.data(), counts.size() * 4);
+      g.write((const char*)codesBin.data(), codesBin.size() * 4);
+      // after a hashed load the exact bin ids are gone: the dense getters must refuse instead of handing out stale arrays
+      PerturbationProTree t3(dim, p, p);
+      t3.setW(w);
+      t3.prepareEmptyLambda(0, lp);
+      t3.loadTree(tree);
+      t3.loadBins(bins);
+      (void)t3.getBinPrefix(hs);
+      t3.loadHashedDB(out + ".h", n, hs);
+      bool refused = false;
+      try { (void)t3.getBinPrefix(hs); } catch (const std::runtime_error&) { refused = true; }
+      if (!refused) throw std::runtime_error("getBinPrefix after loadHashedDB returned a stale array");
     }
     std::cout << "ok " << t.getNClusters() << " " << t.getClusters2() << std::endl;
   } catch (const std::exception& e) {

@@ -1,0 +1,97 @@
+"""BASELINE.json configs[2] at its REAL size: 100 M vectors (d=128 p=4 c1=c2=64 lineparts=32, 12.8 GB of line codes in HBM),
+chunk-built by the product's own build kernel exactly as bench.py's hbm_roofline_leg / `--workload synth100m` builds it.
+
+  * oracle check: 64 queries of the bench batch against the checker loaded with the same 100 M-vector index -- candidate counts,
+    ids and distance bits, at the reference-default knobs (20000, 500) and the CUDA library's (4096, 4096);
+  * variant identity on 2000 queries (more than 256 CUs x 12 wavefronts, so the dynamic rerank schedules are in play): the
+    band-filtered exact rerank with bin runs (the default) == workgroup-per-query exact kernel == candidate-list variant ==
+    every rerank schedule;
+  * size-independent properties on the whole result (sortedness, padding, count identity, cut-rule bound, prefix property).
+Takes ~1.5 minutes and ~45 GB of HBM (scripts/r02_verify_100m.py of round 2, promoted into the suite)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [(20000, 500), (4096, 4096)]
+
+
+@pytest.fixture(scope="module")
+def big100m():
+    import importlib
+    import torch
+    import bench
+    pkg = importlib.import_module("product-quantization-tree_amd")
+    w = bench.WORKLOADS["synth100m"]
+    idx, base, meta = bench.build_index(pkg, w, 0)
+    assert base is None
+    idx.build_heuristic(4096)
+    queries = bench.sift_like(2000, w["D"], 0xC0DE03, torch.device("cuda", 0))  # the first 2000 queries of the bench batch
+    torch.cuda.synchronize()
+    assert meta["max_bin"] < 200000, "degenerate database (data synthesis and build kernel out of order?)"
+    yield pkg, w, idx, meta, queries
+    idx.close()
+
+
+def run(idx, q, bv, bb, k):
+    import torch
+    qn = q.shape[0]
+    oi = torch.empty((qn, k), dtype=torch.int32, device=q.device)
+    od = torch.empty((qn, k), dtype=torch.float32, device=q.device)
+    oc = torch.empty(qn, dtype=torch.int32, device=q.device)
+    torch.cuda.synchronize()
+    idx.query_dev(q, bv, bb, k, oi, od, oc, sync=True)
+    return oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("bv,bb", KNOBS)
+def test_cfg3_100m_properties_and_variant_identity(big100m, bv, bb):
+    pkg, w, idx, meta, queries = big100m
+    ids, dist, cnt = run(idx, queries, bv, bb, 100)
+    path = idx.last_path()
+    assert "rerank=mode2-nw12-runs" in path.split() and "traverse=fused" in path, path
+    st = idx.stats()
+    assert st["filter_fallbacks"] == 0
+    assert int(cnt.astype(np.int64).sum()) == st["candidates"]
+    assert int(cnt.max()) <= bv + meta["max_bin"] and int(cnt.min()) > min(bv, 1000)  # the rerank really works on long lists
+    n_valid = np.minimum(cnt, 100)
+    for qi in range(0, ids.shape[0], 5):
+        n = int(n_valid[qi])
+        d = dist[qi, :n]
+        assert np.all(d[1:] >= d[:-1])
+        assert np.all(ids[qi, n:] == 0xffffffff) and np.all(np.isinf(dist[qi, n:]))
+        assert ids[qi, :n].max(initial=0) < w["n_base"]
+    ids10, dist10, cnt10 = run(idx, queries, bv, bb, 10)
+    assert np.array_equal(ids10, ids[:, :10]) and np.array_equal(dist10.view(np.uint32), dist[:, :10].view(np.uint32)) and np.array_equal(cnt10, cnt)
+    for opt, val, back, expect in (("exact_filter", 0, 1, "rerank=wg-g"), ("bin_runs", 0, -1, "rerank=mode2-nw12"), ("balance", 0, -1, None), ("balance", 1, -1, None),
+                                   ("balance", 2, -1, None)):
+        idx.set_option(opt, val)
+        try:
+            b = run(idx, queries, bv, bb, 100)
+            if expect:
+                assert any(t.startswith(expect) for t in idx.last_path().split()) and "-runs" not in idx.last_path(), idx.last_path()
+        finally:
+            idx.set_option(opt, back)
+        assert np.array_equal(ids, b[0]) and np.array_equal(dist.view(np.uint32), b[1].view(np.uint32)) and np.array_equal(cnt, b[2]), (opt, val)
+
+
+def test_cfg3_100m_oracle_spot_check(big100m):
+    """64 of 64 queries identical to the checker loaded with the same 100 M-vector index (its own heuristic table), both knob sets."""
+    from oracle import Oracle
+    pkg, w, idx, meta, queries = big100m
+    o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=4096)
+    assert np.array_equal(o.heuristic(4096), idx.heuristic(4096))
+    o.set_codebooks(meta["cb1"], meta["cb2"])
+    o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])
+    o.import_codes(idx._keep[0].cpu().numpy().view(np.uint32))
+    o.set_sort_mode(1)
+    qh = queries[:64].cpu().numpy()
+    for bv, bb in KNOBS:
+        ids, dist, cnt = run(idx, queries[:64], bv, bb, 100)
+        ok = 0
+        for i in range(64):
+            s_ids, s_d = o.query(qh[i], bv, bb)
+            n = min(100, len(s_ids))
+            ok += int(int(cnt[i]) == len(s_ids) and np.array_equal(ids[i, :n], s_ids[:n]) and np.array_equal(dist[i, :n].view(np.uint32), s_d[:n].view(np.uint32)))
+        print("100 M vectors, knobs (%d, %d): %d/64 queries identical to the oracle" % (bv, bb, ok))
+        assert ok == 64, (bv, bb, ok)

@@ -865,3 +865,107 @@ def test_rerank_schedules_agree_on_large_batches(name, knobs, opts):
     finally:
         for h in [idx] + shards:
             h.close()
+
+
+# ---- round 3: the path taken is asserted, not only the result -------------------------------------------
+@pytest.mark.parametrize("shape,expect,expect_bias", [
+    # C1 = 128, LP = 32: 16 KB of L1virt per wave -> the 6-wave MODE 2 / MODE 1 kernels (used to fall to the staged rerank
+    # silently because the 12-wave LDS size was tested)
+    ((64, 2, 128, 4, 2, 32), "rerank=mode2-nw6", "rerank=mode1-nw6"),
+    # C1 = 256, LP = 16: same L1virt size per wave
+    ((64, 2, 256, 4, 2, 16), "rerank=mode2-nw6", "rerank=mode1-nw6"),
+    # BASELINE configs[2]/[3] shape: 12 waves + bin runs
+    ((128, 4, 64, 64, 1, 32), "rerank=mode2-nw12-runs", "rerank=mode1-nw12-runs"),
+    # BASELINE configs[1] shape: the coarse table lives in LDS
+    ((128, 4, 32, 32, 2, 16), "rerank=lds-table", "rerank=mode1-nw12"),
+])
+def test_kernel_path_taken_is_the_documented_one(shape, expect, expect_bias):
+    from common import Fixture
+    D, P, C1, C2, W, LP = shape
+    f = Fixture(D=D, P=P, C1=C1, C2=C2, W=W, LP=LP, n_base=5000, n_query=8, seed=4242 + C1 + LP, heur_rows=64, train=2500)
+    idx = f.hip_index()
+    try:
+        ids, dist, cnt = idx.query(f.queries, 600, 64, 33)
+        path = idx.last_path()
+        assert "traverse=fused" in path and expect in path.split(), path
+        st = idx.stats()
+        if "mode2" in expect:
+            assert st["filter_fallbacks"] == 0
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, 600, 64)
+                kk = min(33, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])) and np.array_equal(ids[qi, :kk], s_ids[:kk]), (path, qi)
+        finally:
+            f.oracle.set_sort_mode(0)
+        idx.set_option("adc_bias", 1)
+        ids_b, dist_b, cnt_b = idx.query(f.queries, 600, 64, 33)
+        pb = idx.last_path()
+        assert expect_bias in pb.split(), pb
+        assert np.array_equal(cnt_b, cnt)
+        # same candidate sets; distances follow MODE 1's own association: close to the reference's, not bit-equal in general
+        assert np.allclose(np.where(np.isinf(dist_b), 0, dist_b), np.where(np.isinf(dist), 0, dist), rtol=1e-4, atol=1e-2)
+        idx.set_option("adc_bias", 0)
+        idx.set_option("fused", 0)
+        idx.query(f.queries, 600, 64, 33)
+        assert "traverse=staged" in idx.last_path() and "rerank=staged-select" in idx.last_path()
+    finally:
+        idx.close()
+
+
+def test_stage_timing_period_getters_fall_back_to_the_last_timed_call():
+    """stage_timing = N > 1: untimed calls record no events; pqt_get_rerank_launch_ms / pqt_get_stats report the most recent
+    timed call instead of failing / returning zeros."""
+    f = fixture("cfg2_small")
+    idx = f.hip_index()
+    try:
+        idx.set_option("stage_timing", 4)
+        for i in range(3):  # call 0 is timed, calls 1 and 2 are not
+            idx.query(f.queries, 300, 500, 10)
+        ms = idx.rerank_launch_ms()
+        assert len(ms) == 1 and ms[0] > 0
+        st = idx.stats()
+        assert st["ms_total"] > 0 and st["ms_rerank"] > 0
+        assert idx.stage_ms_history(8).shape[0] == 1
+        idx.set_option("stage_timing", 0)
+        for i in range(40):  # the whole ring untimed: nothing to report, but no error
+            idx.query(f.queries[:2], 300, 500, 10)
+        assert len(idx.rerank_launch_ms()) == 0 and idx.stats()["ms_total"] == 0
+    finally:
+        idx.close()
+
+
+def test_query_candidates_entry_point_returns_the_whole_sorted_list():
+    """pqt_query_candidates by name (oracle-parity entry): the reference's whole sorted candidate list per query,
+    true lengths in out_count, lists longer than cap cut after cap entries; a missing out_count is rejected."""
+    import ctypes as C
+    import torch
+    pkg = pqt_pkg()
+    f = fixture("tools_default")
+    idx = f.hip_index()
+    try:
+        Bv, Bb = BV_BB["tools_default"]
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        for cap in (8192, 64):
+            oi = torch.empty((qn, cap), dtype=torch.int32, device="cuda")
+            od = torch.empty((qn, cap), dtype=torch.float32, device="cuda")
+            oc = torch.empty(qn, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            idx.query_candidates_dev(q, Bv, Bb, cap, oi, od, oc, sync=True)
+            gi, gd, gc = oi.cpu().numpy().view(np.uint32), od.cpu().numpy(), oc.cpu().numpy().view(np.uint32)
+            f.oracle.set_sort_mode(1)
+            try:
+                for qi in range(qn):
+                    s_ids, s_d = f.oracle.query(f.queries[qi], Bv, Bb)
+                    assert int(gc[qi]) == len(s_ids)
+                    n = min(cap, len(s_ids))
+                    assert np.array_equal(gi[qi, :n], s_ids[:n]) and np.array_equal(bits(gd[qi, :n]), bits(s_d[:n]))
+            finally:
+                f.oracle.set_sort_mode(0)
+        rc = pkg.lib().pqt_query_candidates(idx.h, q.data_ptr(), qn, Bv, Bb, 64, oi.data_ptr(), od.data_ptr(), None, None, 1)
+        assert rc == -1 and b"out_count" in pkg.lib().pqt_last_error()
+    finally:
+        idx.close()

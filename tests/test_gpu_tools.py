@@ -261,7 +261,10 @@ def test_class_surface_device_pointers_and_getters(tmp_path):
     assert open("res.bin.h.dbIdx", "rb").read() == dbidx.tobytes()
     g = np.fromfile("res.bin.getters", np.uint32)
     g_dbidx, g_codes = g[:n], g[n:n + n * c["LP"]].reshape(n, c["LP"])
-    g_prefix, g_counts = g[n + n * c["LP"]:n + n * c["LP"] + hs], g[n + n * c["LP"] + hs:]
+    o2 = n + n * c["LP"] + 2 * hs
+    g_prefix, g_counts = g[n + n * c["LP"]:n + n * c["LP"] + hs], g[n + n * c["LP"] + hs:o2]
+    g_codes_bin = g[o2:o2 + n * c["LP"]].reshape(n, c["LP"])
     assert np.array_equal(g_dbidx, f.members)  # ids grouped by bin, bins in ascending id order (std::map order)
-    assert np.array_equal(g_codes, f.codes[f.members])  # row i = code of getDBIdx()[i]
+    assert np.array_equal(g_codes, f.codes)  # getLine(): row i = code of VECTOR i, like the reference's d_lineLambda and the .lines dump
+    assert np.array_equal(g_codes_bin, f.codes[f.members])  # getLineBinOrder(): row i = code of getDBIdx()[i]
     assert np.array_equal(g_prefix, prefix) and np.array_equal(g_counts, counts)
