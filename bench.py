@@ -679,7 +679,7 @@ def main():
     ctx = init_ctx(args)
     world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
     if args.traversal is None:
-        args.traversal = os.environ.get("PQT_BENCH_TRAVERSAL", "replicated")  # TODO(phase 2): sharded
+        args.traversal = os.environ.get("PQT_BENCH_TRAVERSAL", "sharded")
     GEN.update(iso_noise=args.iso_noise, lat_noise=args.lat_noise, n_centers=args.centers, center_scale=args.center_scale)
     if args.dataset_dir:
         out = run_dataset_dir(ctx, args)
@@ -696,7 +696,7 @@ def main():
     st = R["st"]
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
-        ts = np.zeros((qn, 16), np.uint64)
+        ts = np.zeros((qn, 24), np.uint64)
         L = ctx.pkg.lib()
         L.pqt_debug_tstamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         if L.pqt_debug_tstamps(idx.h, ts.ctypes.data, qn) == 0:
@@ -709,6 +709,8 @@ def main():
             log("[tstamp] rerank_select per query (shader clocks): total median %d p90 %d max %d | rows wait %d  adc+filter %d  flush %d (medians)"
                 % (np.median(tot), np.percentile(tot, 90), tot.max(), np.median(r[:, 1]), np.median(r[:, 2]), np.median(r[:, 3])))
             log("[tstamp] sum of per-query clocks / 3072 wave slots: %d" % (tot.sum() // 3072))
+            x = ts[:, 16:20].astype(np.int64)
+            log("[tstamp] rerank_select detail (medians): set-up %d  band re-evaluation %d  result write-out %d  | candidates %d" % tuple(np.median(x, axis=0).astype(int).tolist()))
     if os.environ.get("PQT_DBG_SWEEP"):
         # debug: stage times with parts of the kernels switched off (results wrong), same index, no rebuild
         for v in os.environ["PQT_DBG_SWEEP"].split(","):
@@ -877,9 +879,9 @@ def main():
     if mode == "shard_db":
         out["config"]["same_workload_1gpu"] = ref1 = same_workload_1gpu(ctx, args, W, R)
         out["config"]["ranks_agree"] = ranks_agree(ctx, R)  # every rank must hold the same merged result
-        if W["name"] == SWEEP_WL and ref1 and "speedup_of_this_run" in ref1:
+        if ref1 and "speedup_of_this_run" in ref1:
             out["scaling_vs_1gpu"] = ref1["speedup_of_this_run"]
-            out["scaling_vs_1gpu_what"] = "this line's queries/sec / the same 100 M-vector database and batch on ONE GPU (config.same_workload_1gpu, timed on rank 0 in this run)"
+            out["scaling_vs_1gpu_what"] = "this line's queries/sec / the same database and batch on ONE GPU (config.same_workload_1gpu, timed on rank 0 in this run)"
         if W["name"] != SWEEP_WL and not args.workload and not args.no_scaling_leg:
             # --gpus 8: `value` above is configs[3]'s size; the sweep's own workload (100 M vectors, configs[2]) rides beside it so that
             # N = 2, 4, 8 all carry the ratio against ONE GPU on ONE workload

@@ -225,6 +225,60 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bo
                     uint32_t bound_bins, uint32_t k, uint32_t* out_idx_dev, float* out_dist_dev,
                     uint32_t* out_pos_dev, uint32_t* out_count_dev, void* hip_stream, int sync);
 
+/* ---- query-sharded traversal (multi-GPU) -------------------------------------------------------------------
+ * The traversal (stages a1..a6 up to the cut) does not depend on which vectors a shard holds, so W shards need not all run it
+ * for all queries: shard r runs pqt_traverse_bins for QN/W queries, the results are exchanged (one all-gather of <= (cap + 1)
+ * x 8 bytes per query) and every shard reranks its own slice of the database from them with pqt_query_shard_bins.  The
+ * reference has no counterpart (one device: cudaSetDevice(FLAGS_device), tool_query.cpp:74); the stages are those of
+ * treequantizer::query (treequantizer.hpp:323-350): id + segmentInfo + orderBins + the cut of rerankVectors (:450-477).
+ *   out_bins_dev[qn][cap + 1] u64, shard independent: entry i of a row = bin id | (global visiting position of the bin's first
+ *   member << 32) of the i-th included populated bin in visiting order; the trailer word [cap] = number of entries | (global
+ *   candidate count << 32).  A count of 0xffffffff marks a query whose list does not fit `cap` entries (1 <= cap <= 128), or
+ *   that the fused traversal could not finish: pqt_query_shard_bins traverses such queries itself.  Sharded indices only. */
+int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t cap,
+                      unsigned long long* out_bins_dev, void* hip_stream, int sync);
+/* pqt_query_shard with the traversal results handed in (bins_dev[qn][cap + 1] as written by pqt_traverse_bins on any shard of
+ * the same database): distance tables for all queries, the listed bins resolved against this shard's bin table, ADC rerank of
+ * the local members, top-k with global visiting positions.  Identical output to pqt_query_shard. */
+int pqt_query_shard_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t k,
+                         const unsigned long long* bins_dev, uint32_t cap, uint32_t* out_idx_dev, float* out_dist_dev,
+                         uint32_t* out_pos_dev, uint32_t* out_count_dev, void* hip_stream, int sync);
+
+/* ---- one handle over a range-sharded database (SURVEY 8b "multi-GPU handle fans out internally", 8e) ---------------------
+ * N shard indices on N devices of one node inside ONE process (csrc/pqt_multi.cpp).  The reference has no counterpart: its
+ * classes drive one device (cudaSetDevice(FLAGS_device), tool_query.cpp:74; queryKNN PerturbationProTree.hh:72).  Shard s owns
+ * the vector ids [s*N/S, (s+1)*N/S): its rows of the line store and its members of every bin; tree, heuristic and every bin's
+ * global population are replicated.  pqt_multi_query fans a batch out on the shards' streams -- shard s traverses query slice
+ * s (pqt_traverse_bins), the bin lists are exchanged by peer copies (xGMI), every shard reranks its slice of the database
+ * (pqt_query_shard_bins), the per-shard top-k lists are copied to the first device and merged by (distance, global visiting
+ * position) (pqt_merge_topk) -- ordered by events, no host synchronisation inside a batch.  The result is the unsharded
+ * engine's, bit for bit.  devices[s] = HIP device of shard s (NULL: 0, 1, ...; the same device may appear more than once).
+ * Errors: as above, text in pqt_multi_last_error(). */
+typedef struct pqt_multi pqt_multi;
+const char* pqt_multi_last_error(void);
+int pqt_multi_create(const pqt_params* prm, int nshards, const int* devices, pqt_multi** out);
+void pqt_multi_destroy(pqt_multi* m);
+int pqt_multi_shards(const pqt_multi* m);
+pqt_index* pqt_multi_shard(pqt_multi* m, int s);  /* the shard's own handle (statistics, options, debug read-back) */
+int pqt_multi_shard_range(const pqt_multi* m, int s, uint64_t* id_lo, uint64_t* id_hi);
+/* pqt_index_set_option on every shard; "replicated_traversal" = 1 makes every shard traverse the whole batch itself */
+int pqt_multi_set_option(pqt_multi* m, const char* name, int64_t value);
+int pqt_multi_set_codebooks(pqt_multi* m, const float* cb1_host, const float* cb2_host);   /* = pqt_index_set_codebooks */
+int pqt_multi_build_heuristic(pqt_multi* m, uint64_t rows);                                /* = pqt_index_build_heuristic */
+int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows);
+/* the WHOLE database as for pqt_index_set_bins (members of a bin in ascending id order = the reference's insertion order);
+ * every shard keeps its id range.  n_total = number of vectors (0: the sum of the bin sizes). */
+int pqt_multi_set_bins(pqt_multi* m, uint64_t nbins, const uint32_t* bin_ids_host, const uint32_t* bin_sizes_host,
+                       const uint32_t* members_host, uint64_t n_total);
+/* codes[nvec][LP] of the whole database (row r = vector id r); every shard copies its rows */
+int pqt_multi_set_lines_host(pqt_multi* m, const uint32_t* codes_host, uint64_t nvec);
+/* = pqt_query for the sharded database: q / out_* live on the FIRST shard's device; hip_stream: a stream of that device or
+ * NULL (the handle's own) */
+int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t k,
+                    uint32_t* out_idx_dev0, float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync);
+int pqt_multi_query_host(pqt_multi* m, const float* q_host, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t k,
+                         uint32_t* out_idx_host, float* out_dist_host, uint32_t* out_count_host);
+
 /* ---- stage-level read-back (parity tests; not a fast path) ------------------------------------------
  * After a pqt_query* call the handle still holds the intermediates of that batch:
  *   l1virt[QN][LP][C1]                      = _L1distancesVirtual   (treequantizer.hpp:914)
@@ -233,7 +287,8 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bo
  * Each pointer may be NULL.  Host pointers.  stride is returned by pqt_debug_stride(). */
 uint64_t pqt_debug_stride(const pqt_index* idx);
 /* per-query phase timestamps of the fused traversal kernel (only when the process runs with PQT_TSTAMP=1):
- * out[qn][16] shader-clock ticks */
+ * out[qn][24] shader-clock ticks (0-8 traversal phase stamps, 9-14 rerank: start, row wait, ADC + filter, flushes, total | wall
+ * clock, slot; 15 traversal hw id; 16-19 rerank detail: set-up, exact re-evaluation of the band, result write-out, candidates) */
 int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out_host, uint32_t qn);
 int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt_host, float* seg_d2_host,
                    uint32_t* seg_bin_host, uint32_t* cand_idx_host, float* cand_dist_host,

@@ -47,13 +47,16 @@ EXPORTS = [
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
-    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read",
+    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_traverse_bins", "pqt_query_shard_bins",
+    "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
+    "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
+    "pqt_multi_query_host",
 ]
 
 
 def build(force=False):
     """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h", "Makefile")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h", "pqt_multi.cpp", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", CSRC, "libpqt_hip.so"])
@@ -93,6 +96,9 @@ def lib():
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_query_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_traverse_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_query_shard_bins.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_query_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_index_device_arrays.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
@@ -109,6 +115,22 @@ def lib():
     L.pqt_get_stage_ms_history.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_get_last_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.pqt_debug_stream_read.argtypes = [C.c_int, C.c_uint64, C.c_int, f32p]
+    L.pqt_multi_last_error.restype = C.c_char_p
+    L.pqt_multi_create.argtypes = [C.POINTER(pqt_params), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+    L.pqt_multi_destroy.argtypes = [C.c_void_p]
+    L.pqt_multi_destroy.restype = None
+    L.pqt_multi_shards.argtypes = [C.c_void_p]
+    L.pqt_multi_shard.argtypes = [C.c_void_p, C.c_int]
+    L.pqt_multi_shard.restype = C.c_void_p
+    L.pqt_multi_shard_range.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pqt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.pqt_multi_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
+    L.pqt_multi_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
+    L.pqt_multi_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
+    L.pqt_multi_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint64]
+    L.pqt_multi_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64]
+    L.pqt_multi_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_multi_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.pqt_dev_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_uint16), f32p, C.c_int]
     _LIB = L
     return L
@@ -227,6 +249,15 @@ class PqtIndex:
                                     out_pos.data_ptr(), out_count.data_ptr() if out_count is not None else None,
                                     stream, int(sync)))
 
+    def traverse_bins_dev(self, q, Bv, Bb, cap, out_bins, stream=None, sync=False):
+        """Query-sharded traversal: out_bins int64 [qn][cap + 1] (bin id | global start << 32 ..., trailer = count | nCand << 32)."""
+        assert out_bins.element_size() == 8 and out_bins.is_contiguous() and out_bins.numel() >= q.shape[0] * (cap + 1)
+        _chk(self.L.pqt_traverse_bins(self.h, q.data_ptr(), q.shape[0], Bv, Bb, cap, out_bins.data_ptr(), stream, int(sync)))
+
+    def query_shard_bins_dev(self, q, Bv, Bb, k, bins, cap, out_idx, out_dist, out_pos, out_count=None, stream=None, sync=False):
+        _chk(self.L.pqt_query_shard_bins(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, bins.data_ptr(), cap, out_idx.data_ptr(), out_dist.data_ptr(),
+                                         out_pos.data_ptr(), out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
+
     def merge_topk_dev(self, nshards, qn, k, idx_all, dist_all, pos_all, out_idx, out_dist, stream=None, sync=False, shard_stride=0):
         _chk(self.L.pqt_merge_topk(self.h, nshards, qn, k, idx_all.data_ptr(), dist_all.data_ptr(), pos_all.data_ptr(), shard_stride,
                                    out_idx.data_ptr(), out_dist.data_ptr(), stream, int(sync)))
@@ -286,6 +317,81 @@ class PqtIndex:
         _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p), _p(sb, u32p),
                                    _p(ci, u32p) if cands else None, _p(cd, f32p) if cands else None, _p(nc, u32p)))
         return dict(l1virt=l1, seg_d2=sd, seg_bin=sb, ncand=nc, cand_idx=ci, cand_dist=cd, stride=stride)
+
+
+class PqtMulti:
+    """One handle over a range-sharded database: N shards on N devices of one process (include/pqt_hip.h: pqt_multi_*)."""
+
+    def __init__(self, D, P, C1, C2, W, LP, devices):
+        self.L = lib()
+        self.D, self.P, self.C1, self.C2, self.W, self.LP = D, P, C1, C2, W, LP
+        self.h = C.c_void_p()
+        prm = pqt_params(D, P, C1, C2, W, LP)
+        devs = (C.c_int * len(devices))(*devices)
+        self._chk(self.L.pqt_multi_create(C.byref(prm), len(devices), devs, C.byref(self.h)))
+        self.n = len(devices)
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise PqtError("pqt_multi error %d: %s" % (rc, self.L.pqt_multi_last_error().decode()))
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.pqt_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        self._chk(self.L.pqt_multi_set_option(self.h, name.encode(), int(value)))
+
+    def set_codebooks(self, cb1, cb2):
+        cb1 = _np(cb1, np.float32).reshape(self.C1, self.D)
+        cb2 = _np(cb2, np.float32).reshape(self.P, self.C1, self.C2, self.D // self.P)
+        self._chk(self.L.pqt_multi_set_codebooks(self.h, _p(cb1, f32p), _p(cb2, f32p)))
+
+    def build_heuristic(self, rows):
+        self._chk(self.L.pqt_multi_build_heuristic(self.h, rows))
+
+    def set_heuristic(self, tuples):
+        t = _np(tuples, np.uint32).reshape(-1, self.P)
+        self._chk(self.L.pqt_multi_set_heuristic(self.h, _p(t, u32p), t.shape[0]))
+
+    def set_bins(self, ids, sizes, members, n_total=0):
+        ids, sizes, members = _np(ids, np.uint32), _np(sizes, np.uint32), _np(members, np.uint32)
+        self._chk(self.L.pqt_multi_set_bins(self.h, ids.shape[0], _p(ids, u32p), _p(sizes, u32p), _p(members, u32p), n_total))
+
+    def set_lines(self, codes):
+        codes = _np(codes, np.uint32).reshape(-1, self.LP)
+        self._chk(self.L.pqt_multi_set_lines_host(self.h, _p(codes, u32p), codes.shape[0]))
+
+    def shard_range(self, s):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.pqt_multi_shard_range(self.h, s, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def shard_last_path(self, s):
+        buf = C.create_string_buffer(256)
+        _chk(self.L.pqt_get_last_path(self.L.pqt_multi_shard(self.h, s), buf, 256))
+        return buf.value.decode()
+
+    def query_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_count=None, stream=None, sync=False):
+        self._chk(self.L.pqt_multi_query(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
+                                         out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
+
+    def query(self, Q, Bv, Bb, k):
+        Q = _np(Q, np.float32).reshape(-1, self.D)
+        qn = Q.shape[0]
+        idx = np.zeros((qn, k), np.uint32)
+        dist = np.zeros((qn, k), np.float32)
+        cnt = np.zeros(qn, np.uint32)
+        self._chk(self.L.pqt_multi_query_host(self.h, _p(Q, f32p), qn, Bv, Bb, k, _p(idx, u32p), _p(dist, f32p), _p(cnt, u32p)))
+        return idx, dist, cnt
 
 
 def stream_read_GBps(nbytes=4 << 30, reps=5, device=0):

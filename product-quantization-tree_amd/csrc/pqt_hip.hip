@@ -70,6 +70,7 @@ struct pqt_index {
   float* d_bias = nullptr; bool biasReady = false; bool adcBias = false; bool exactFilter = true; float coarseMax = 0.f;
   unsigned long long* d_runs = nullptr; uint32_t* d_runGpos = nullptr; uint32_t* d_nRuns = nullptr; uint64_t runsCap = 0; int useRuns = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastRuns = false; uint32_t curRunCap = 0;
   uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
+  uint32_t* d_tvList = nullptr; uint32_t* d_tvCount = nullptr;  // pqt_query_shard_bins: queries whose exchanged bin list overflowed (traversed here)
    // opt-in adc_bias mode: per-row query-independent part of the ADC sum
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
@@ -129,6 +130,8 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
   if ((rc = devAlloc(&idx->d_fbList, (size_t)qn))) return rc;
   if (!idx->d_fbCount && (rc = devAlloc(&idx->d_fbCount, (size_t)2))) return rc;
+  if ((rc = devAlloc(&idx->d_tvList, (size_t)qn))) return rc;
+  if (!idx->d_tvCount && (rc = devAlloc(&idx->d_tvCount, (size_t)2))) return rc;
   idx->qCap = qn;
   return PQT_OK;
 }
@@ -439,6 +442,69 @@ int stageMs(const pqt_index* idx, int slot, int ch, float st[5]) {
   return prev;
 }
 
+// ---- fused traversal (pqt_k_traverse): LDS plan and launch, shared by pqt_query*, pqt_traverse_bins and pqt_query_shard_bins
+struct TravPlan { bool fused = false, wide = false, p2 = false; size_t lTrav = 0; uint32_t perWave = 0; };
+int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp) {
+  const PqtDevParams& d = idx->dp;
+  int rc;
+  // fused traversal (wave per query) when the bin list fits the in-register sorter
+  tp.fused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
+  tp.wide = tp.fused && He > 512;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
+  const size_t travR0 = (std::max<size_t>(tp.wide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
+  tp.perWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
+  tp.lTrav = (size_t)kTravWaves * tp.perWave;
+  const size_t lTrav = tp.lTrav;
+  auto isP2 = [](uint32_t x) { return x != 0 && (x & (x - 1)) == 0; };
+  // all layout strides powers of two (every BASELINE shape): the traversal uses shifts and masks
+  tp.p2 = isP2(d.C1) && isP2(d.C2) && isP2(d.W) && isP2(d.LP) && isP2(d.D) && isP2(d.S) && isP2(d.SS) && isP2(d.R) && d.S >= 4;
+  if (tp.fused && lTrav > 64 * 1024) {
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, false>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 1>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 1>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 2>, lTrav))) return rc;
+    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 2>, lTrav))) return rc;
+  }
+  return PQT_OK;
+}
+// compile-time-shape instantiation the traversal of this index runs (0: run-time shape): the two BASELINE shapes, two-phase
+// enumeration only (packed heuristic rows and the presence bitmap must be there, no modulo hashing, no order-all-rows switch)
+int travShape(const pqt_index* idx, const PqtTravArgs& targs) {
+  const bool twoOk = targs.heur4 && targs.filter && !idx->dp.hashMod && !((idx->dbg >> 5) & 1u);
+  return (idx->noShape || !twoOk) ? 0 : pqt_shape_of(idx->dp);
+}
+// a1..a6 in one launch, one wavefront per query (`waves` of them); ev0 / ev1 ride on the dispatch when given
+void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& tp, uint32_t waves, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  const PqtDevParams& d = idx->dp;
+  const uint32_t grid = (waves + kTravWaves - 1) / kTravWaves;
+  const size_t lTrav = tp.lTrav;
+  const uint32_t travPerWave = tp.perWave;
+  const bool travP2 = tp.p2;
+#define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
+  hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, \
+                        targs, travPerWave)
+#define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
+                                else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
+  const int shape = travShape(idx, targs);
+  if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
+                    else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
+  else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
+                         else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
+  else if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
+#undef PQT_LAUNCH_TR
+#undef PQT_LAUNCH_TR1
+}
+
 // ring slot of the most recent query call that carried per-kernel events (option "stage_timing" = N > 1: not every call
 // does), or -1
 int lastTimedSlot(const pqt_index* idx) {
@@ -450,8 +516,11 @@ int lastTimedSlot(const pqt_index* idx) {
   return -1;
 }
 
+// binsIn != null (pqt_query_shard_bins): the traversal of every query ran elsewhere (pqt_traverse_bins) and arrives as
+// binsIn[qn][binsCap + 1]; this shard resolves the listed bins against its own table instead of traversing
 int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
-              uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
+              uint32_t* outIdx, float* outDist, uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync,
+              const unsigned long long* binsIn = nullptr, uint32_t binsCap = 0) {
   if (!idx) return fail(PQT_ERR_INVALID, "null index");
   if (!idx->haveTree || !idx->haveBins || !(idx->d_codes || idx->binOrdered) || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic, bins and line codes before querying");
   if (qn == 0) return PQT_OK;
@@ -506,36 +575,15 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t lSel = ldsSelect(kP2);
   if (!fullSort) { if (idx->sharded) { if ((rc = allowLds(pqt_k_select<true>, lSel))) return rc; } else { if ((rc = allowLds(pqt_k_select<false>, lSel))) return rc; } }
 
-  // fused traversal (wave per query) when the bin list fits the in-register sorter
-  const bool travFused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
-  const bool travWide = travFused && He > 512;
+  TravPlan tplan;
+  if ((rc = planTraversal(idx, He, tplan))) return rc;
+  const bool travFused = tplan.fused, travWide = tplan.wide, travP2 = tplan.p2;
+  // the exchanged bin lists are only used together with the fused traversal (which re-traverses the overflowed queries); other
+  // shapes / bounds traverse every query here
+  if (binsIn && (!travFused || !idx->sharded || binsCap > PQT_GBIN_MAX)) binsIn = nullptr;
   // the short fused traversal writes the caller's candidate counts itself (no device-to-device copy on the stream); the wide
   // one can hand queries to pqt_k_bins, which fills them in later: copy at the end
-  const bool countDirect = outCount && travFused && !travWide;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
-  const size_t travR0 = (std::max<size_t>(travWide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
-  const uint32_t travPerWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
-  const size_t lTrav = (size_t)kTravWaves * travPerWave;
-  auto isP2 = [](uint32_t x) { return x != 0 && (x & (x - 1)) == 0; };
-  // all layout strides powers of two (every BASELINE shape): the traversal uses shifts and masks
-  const bool travP2 = isP2(d.C1) && isP2(d.C2) && isP2(d.W) && isP2(d.LP) && isP2(d.D) && isP2(d.S) && isP2(d.SS) && isP2(d.R) && d.S >= 4;
-  if (travFused && lTrav > 64 * 1024) {
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 1>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 1>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 2>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 2>, lTrav))) return rc;
-  }
+  const bool countDirect = outCount && travFused && !travWide;
   // fused rerank+select (wave per query) whenever the result list fits the in-register selector
   bool fused = (k <= PQT_RS_BEST) && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !idx->forceUnfused;
   const size_t coarseBytes = (size_t)d.LP * d.C1 * d.C1 * 4;
@@ -625,31 +673,31 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
-      const uint32_t grid = (nq + kTravWaves - 1) / kTravWaves;
-      const PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, (idx->dbg & 4096u) ? nullptr : idx->d_heur4, He, Bv,
-                              idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
-                              idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
-                              idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
-                              (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
-                              emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
-                              countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u,
-                              schedCntArg, idx->d_schedList, idx->curSchedCap};
-#define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
-      hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, \
-                            targs, travPerWave)
-#define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
-                                else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
-      // the two BASELINE shapes run compile-time-shape instantiations (two-phase enumeration only: packed heuristic rows and
-      // the presence bitmap must be there, no modulo hashing, no order-all-rows debug switch)
-      const bool twoOk = targs.heur4 && targs.filter && !d.hashMod && !((idx->dbg >> 5) & 1u);
-      const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
-      if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);
-                        else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave); }
-      else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave);
-                             else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, idx->lev0, idx->lev1, 0u, targs, travPerWave); }
-      else if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
-#undef PQT_LAUNCH_TR
-#undef PQT_LAUNCH_TR1
+      PqtTravArgs targs{q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, (idx->dbg & 4096u) ? nullptr : idx->d_heur4, He, Bv,
+                        idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, nq, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_cand,
+                        idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0, stride, idx->ctr, tstamp,
+                        idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
+                        (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
+                        emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
+                        countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u,
+                        schedCntArg, idx->d_schedList, idx->curSchedCap, nullptr, nullptr, nullptr, 0u};
+      if (binsIn) {
+        // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
+        // shard's table, and the (normally empty) list of queries whose list overflowed at the sender traversed here
+        HIPCHK(hipMemsetAsync(idx->d_tvCount, 0, 4, st));
+        if ((rc = allowLds(pqt_k_l1virt, (size_t)d.D * 4))) return rc;
+        hipExtLaunchKernelGGL(pqt_k_l1virt, dim3(nq), dim3(PQT_BLOCK), (uint32_t)(d.D * 4), st, idx->lev0, nullptr, 0u, q_dev + (size_t)q0 * d.D, idx->d_cb1, d,
+                              idx->d_qL1virt + (size_t)q0 * d.LP * d.C1);
+        const PqtResolveArgs rargs{binsIn + (size_t)q0 * (binsCap + 1u), binsCap, idx->d_table, idx->d_lower, idx->tableBits, d.tableSeed, nq,
+                                   idx->d_cand, idx->d_candPos, stride, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
+                                   emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
+                                   countDirect ? outCount + q0 : nullptr, idx->d_tvList, idx->d_tvCount, schedCntArg, idx->d_schedList, idx->curSchedCap};
+        hipLaunchKernelGGL(pqt_k_resolve_bins<4>, dim3((nq + 3) / 4), dim3(256), 0, st, rargs);
+        targs.qlist = idx->d_tvList; targs.qcount = idx->d_tvCount;
+        launchFusedTraversal(idx, targs, tplan, nq, st, nullptr, idx->lev1);
+      } else {
+        launchFusedTraversal(idx, targs, tplan, nq, st, idx->lev0, idx->lev1);
+      }
       if (travWide) {
         // queries with more than 512 populated rows queued themselves: workgroup-per-query kernel with an He-sized arena
         // on that (usually empty) list, from the sorted lists the traversal left in segD/segBin
@@ -790,6 +838,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   {
     // which kernels ran (pqt_get_last_path): tests assert the path, not only the result
     std::string tp = !travFused ? "traverse=staged" : (travWide ? "traverse=fused-wide" : "traverse=fused");
+    if (binsIn) tp = "traverse=bins-resolved+" + tp.substr(9);
     if (travFused) {
       const bool twoOk = idx->d_heur4 && idx->d_filter && !(idx->dbg & (4096u | 2048u | 32u)) && !d.hashMod;
       const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
@@ -858,7 +907,7 @@ int pqt_index_create(const pqt_params* prm, int device, pqt_index** out) {
   idx->forceUnfused = getenv("PQT_FORCE_UNFUSED") != nullptr;
   if (getenv("PQT_DBG")) idx->dbg = (uint32_t)atoi(getenv("PQT_DBG"));
   if (getenv("PQT_BALANCE")) idx->balance = std::max(-1, std::min(2, atoi(getenv("PQT_BALANCE"))));
-  if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * 16 * 8) != hipSuccess) idx->d_tstamp = nullptr; }
+  if (getenv("PQT_TSTAMP")) { if (hipMalloc((void**)&idx->d_tstamp, (size_t)(1 << 16) * PQT_TS_WORDS * 8) != hipSuccess) idx->d_tstamp = nullptr; }
   if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) idx->scratchBudget = std::min<size_t>(idx->scratchBudget, totalB / 8);
   *out = idx;
   return PQT_OK;
@@ -870,7 +919,7 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -1238,6 +1287,49 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv
   return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync);
 }
 
+int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t cap,
+                      unsigned long long* out_bins_dev, void* stream, int sync) {
+  if (!idx || !out_bins_dev || (qn && !q_dev)) return fail(PQT_ERR_INVALID, "null argument");
+  if (!idx->sharded) return fail(PQT_ERR_INVALID, "pqt_traverse_bins needs a range-sharded index (pqt_index_set_bins_shard / _local)");
+  if (cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_LIMIT, "bin-list capacity must be 1..128");
+  if (!idx->haveTree || !idx->haveBins || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic and bins before traversing");
+  if (qn == 0) return PQT_OK;
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
+  const PqtDevParams& d = idx->dp;
+  const uint64_t He64 = std::min<uint64_t>(Bb, idx->maxMultiIndex);
+  if (He64 > idx->heurRows) return fail(PQT_ERR_STATE, "bound_bins exceeds the heuristic rows held by the index (build/set a longer prefix)");
+  const uint32_t He = (uint32_t)He64;
+  TravPlan tp;
+  if ((rc = planTraversal(idx, He, tp))) return rc;
+  if (!tp.fused) {
+    // bounds / shapes outside the fused traversal: every receiver traverses every query itself (correct, not fast)
+    hipLaunchKernelGGL(pqt_k_gbins_overflow, dim3((qn + 255) / 256), dim3(256), 0, st, out_bins_dev, cap, qn);
+  } else {
+    if ((rc = ensureQueryScratch(idx, qn))) return rc;
+    const PqtTravArgs targs{q_dev, idx->d_cb1, idx->d_cb2, (const float4*)idx->d_cb2T, d, (const uint4*)idx->d_heur8, (idx->dbg & 4096u) ? nullptr : idx->d_heur4, He, Bv,
+                            idx->d_table, idx->d_lower, idx->tableBits, idx->d_ids, qn, idx->d_qL1virt, idx->d_cand,
+                            idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, 0, idx->d_counters + 8 * kCtrRing /* spare statistics block */, nullptr,
+                            idx->d_segD, idx->d_segBin, idx->d_ovList, idx->d_ovCount,
+                            (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
+                            nullptr, nullptr, nullptr, 0u, nullptr, (idx->dbg >> 5) & 1u,
+                            nullptr, nullptr, 0u, nullptr, nullptr, out_bins_dev, cap};
+    launchFusedTraversal(idx, targs, tp, qn, st, nullptr, nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
+int pqt_query_shard_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
+                         const unsigned long long* bins_dev, uint32_t cap, uint32_t* outIdx, float* outDist, uint32_t* outPos,
+                         uint32_t* outCount, void* stream, int sync) {
+  if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard / _local");
+  if (!bins_dev || cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_INVALID, "bin lists missing or capacity outside 1..128");
+  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync, bins_dev, cap);
+}
+
 int pqt_query_host(pqt_index* idx, const float* q, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
                    float* outDist, uint32_t* outCount) {
   if (!idx || !q || !outIdx || !outDist) return fail(PQT_ERR_INVALID, "null argument");
@@ -1337,7 +1429,7 @@ int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd
 int pqt_debug_tstamps(const pqt_index* idx, unsigned long long* out, uint32_t qn) {
   if (!idx || !idx->d_tstamp || qn > (1u << 16)) return fail(PQT_ERR_STATE, "timestamps not enabled (PQT_TSTAMP=1)");
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, idx->d_tstamp, (size_t)qn * 16 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, idx->d_tstamp, (size_t)qn * PQT_TS_WORDS * 8, hipMemcpyDeviceToHost));
   return PQT_OK;
 }
 

@@ -11,6 +11,7 @@
 #include "pqt_wave.h"
 
 #define PQT_BLOCK 256
+#define PQT_TS_WORDS 24  // debug timestamp words per query (PQT_TSTAMP=1): 0-8 traversal phases, 9-14 rerank, 15 traversal hw id, 16-19 rerank detail
 
 // ---------------------------------------------------------------------------------------------------
 // setup (a9): coarse[(lp*C1 + i)*C1 + j] = || cb1[i]_lp - cb1[j]_lp ||^2     (treequantizer.hpp:183-203)
@@ -777,7 +778,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   unsigned long long tsLoad = 0, tsAdc = 0, tsFlush = 0, ts0 = 0;
   unsigned long long tsStart = 0, wallStart = 0;
   if (tstamp) { tsStart = __builtin_readcyclecounter(); wallStart = wall_clock64(); }
-  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 9] = tsStart;
+  if (tstamp && lane == 0) tstamp[(size_t)q * PQT_TS_WORDS + 9] = tsStart;
   const uint32_t* cid = cand + (size_t)q * stride;
   const uint32_t* cpos = SHARDED ? candPos + (size_t)q * stride : nullptr;
   if (tstamp) ts0 = __builtin_readcyclecounter();
@@ -863,6 +864,8 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(qmax, d, 64); qmax = o > qmax ? o : qmax; }
   }
 
+  unsigned long long tsSetup = 0, tsVerify = 0, tsOut = 0;
+  if (tstamp) tsSetup = __builtin_readcyclecounter() - tsStart;
   auto flush = [&](const bool final) {
     // [best off0 (unsorted, after the first flush) | pending npend]: keep the k smallest.  More than 128 keys are cut
     // down by an exact radix select (pqt_wave_kth_u64) instead of a full sort; only the final <= 128 survivors
@@ -1072,6 +1075,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   // results: first min(k, n) entries of the best list
   const uint32_t kk = n < k ? n : k;
   uint32_t ties = 0;
+  if (tstamp) ts0 = __builtin_readcyclecounter();
   if constexpr (MODE == 2) {
     // the list holds the off0 (<= 256) smallest MODE 1 keys in ascending order: re-evaluate the band [.., d1_(k) + 2 eps]
     // with the reference association and order it by the exact key
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (tstamp) ts0 = __builtin_readcyclecounter();
+  if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsVerify = t - ts0; ts0 = t; }
   for (uint32_t i = lane; i < k; i += 64) {
     const size_t o = (size_t)q * k + i;
     if (i < kk) {
@@ -1161,12 +1165,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   }
   if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
   __builtin_amdgcn_wave_barrier();
+  if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsOut = __builtin_readcyclecounter() - ts0; }
   if (tstamp && lane == 0) {
-    tstamp[(size_t)q * 16 + 10] = tsLoad; tstamp[(size_t)q * 16 + 11] = tsAdc; tstamp[(size_t)q * 16 + 12] = tsFlush;
+    tstamp[(size_t)q * PQT_TS_WORDS + 16] = tsSetup; tstamp[(size_t)q * PQT_TS_WORDS + 17] = tsVerify; tstamp[(size_t)q * PQT_TS_WORDS + 18] = tsOut; tstamp[(size_t)q * PQT_TS_WORDS + 19] = n;
+    tstamp[(size_t)q * PQT_TS_WORDS + 10] = tsLoad; tstamp[(size_t)q * PQT_TS_WORDS + 11] = tsAdc; tstamp[(size_t)q * PQT_TS_WORDS + 12] = tsFlush;
     // [13] = shader clocks of this query | start on the 100 MHz wall clock << 32; [14] = wave slot | XCC id << 16 | end on the
     // wall clock << 32 (the cycle counters of different XCDs have different origins, the wall clock is global)
-    tstamp[(size_t)q * 16 + 13] = ((__builtin_readcyclecounter() - tsStart) & 0xffffffffull) | (wallStart << 32);
-    tstamp[(size_t)q * 16 + 14] = (unsigned long long)slot | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 16) | (wall_clock64() << 32);
+    tstamp[(size_t)q * PQT_TS_WORDS + 13] = ((__builtin_readcyclecounter() - tsStart) & 0xffffffffull) | (wallStart << 32);
+    tstamp[(size_t)q * PQT_TS_WORDS + 14] = (unsigned long long)slot | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu) << 16) | (wall_clock64() << 32);
   }
 }
 
@@ -1448,6 +1454,14 @@ struct PqtTravArgs {
   // rerank schedule 2: the query registers itself in the list of (XCD pool q % 8, size class of its local candidate count):
   // schedCnt[pool * 64 + class] entries so far, schedList[(pool * 64 + class) * schedCap + i] = i-th query; or null
   uint32_t* schedCnt; unsigned long long* schedList /* query | local candidates << 32 */; uint32_t schedCap;
+  // list mode (pqt_query_shard_bins: the queries whose exchanged bin list overflowed are traversed here after all): wavefront i
+  // takes query qlist[i], i < *qcount; or null = query i
+  const uint32_t* qlist; const uint32_t* qcount;
+  // query-sharded traversal (pqt_traverse_bins, SHARDED indices): stop after the cut and hand out the included populated bins
+  // in shard-INDEPENDENT form -- gbins[q][gbinCap + 1]: entry i = bin id | global visiting position of its first member << 32
+  // (visiting order), trailer word [gbinCap] = number of entries (0xffffffff: more than gbinCap, or the wide traversal's own
+  // overflow -- the receiving shard traverses such a query itself) | global candidate count << 32; or null
+  unsigned long long* gbins; uint32_t gbinCap;
 };
 
 // the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
@@ -1485,7 +1499,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   // presence bitmap, no modulo hashing and without the order-all-rows debug switch), so the single-pass code is not compiled in
   constexpr bool TWO = SHAPE != 0;
   const uint32_t forceFullOrder = TWO ? 0u : (tdbg & 1u);
-#define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define PQT_TS(i) do { if (tstamp && lane == 0) tstamp[(size_t)q * PQT_TS_WORDS + (i)] = __builtin_readcyclecounter(); } while (0)
   using SH = PqtShape<SHAPE>;
   static_assert(SHAPE == 0 || (P2 && WCR == 1), "compile-time shapes are power-of-two shapes with W*C2 == 64");
   const uint32_t D = SHAPE ? SH::D : prm.D, P = SHAPE ? SH::P : prm.P, C1 = SHAPE ? SH::C1 : prm.C1, C2 = SHAPE ? SH::C2 : prm.C2,
@@ -1975,6 +1989,26 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       // (one more round trip, only for included populated bins) and build the LOCAL candidate list together with each
       // candidate's global visiting position = global start of its bin + members held by lower shards + offset.
       const uint4* table4 = reinterpret_cast<const uint4*>(table);
+      if (A.gbins) {
+        // query-sharded traversal: the included populated bins as (bin id, global start) in visiting order; every shard resolves
+        // its own members from its own table (pqt_k_resolve_bins)
+        uint32_t kv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) kv[r] = g8[r] ? table4[ls8[r]].x : 0u;
+        const uint32_t neIncl = pqt_wave_incl_scan(myNonEmpty);
+        const uint32_t m = __shfl(neIncl, 63, 64);
+        uint32_t wpos = neIncl - myNonEmpty;
+        unsigned long long* const row = A.gbins + (size_t)q * (A.gbinCap + 1u);
+        if (m <= A.gbinCap) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) if (g8[r]) { row[wpos] = (unsigned long long)kv[r] | ((unsigned long long)ex8[r] << 32); ++wpos; }
+        }
+        if (lane == 0) {
+          row[A.gbinCap] = (unsigned long long)(m <= A.gbinCap ? m : 0xffffffffu) | ((unsigned long long)totCand << 32);
+          nCand[q] = totCand; nLocal[q] = 0; if (A.outCount) A.outCount[q] = totCand;
+        }
+        return totNe;
+      }
       uint32_t lc8[R], gp8[R];
       uint32_t myLocal = 0, myLocalBins = 0;
 #pragma unroll
@@ -2109,6 +2143,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
       __builtin_amdgcn_wave_barrier();
       if (nwork > 512) {  // more "maybe" rows than the list holds: workgroup-per-query kernel with the full-size arena
+        if (A.gbins) { if (lane == 0) { A.gbins[(size_t)q * (A.gbinCap + 1u) + A.gbinCap] = 0xffffffffull; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; } return; }
         if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
         return;
       }
@@ -2141,6 +2176,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     }
     __builtin_amdgcn_wave_barrier();
     if (npop > 512) {
+      if (A.gbins) { if (lane == 0) { A.gbins[(size_t)q * (A.gbinCap + 1u) + A.gbinCap] = 0xffffffffull; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; } return; }
       if (lane == 0) { ovList[atomicAdd(ovCount, 1u)] = q; nCand[q] = 0; nLocal[q] = 0; nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
       return;
     }
@@ -2221,7 +2257,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   }
   if (lane == 0) nIncl[q] = totIncl;
   PQT_TS(8);
-  if (tstamp && lane == 0) tstamp[(size_t)q * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  if (tstamp && lane == 0) tstamp[(size_t)q * PQT_TS_WORDS + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);
 #undef PQT_TS
 #undef PQT_MUL
 #undef PQT_DIV
@@ -2235,9 +2271,141 @@ template <int NW, int WCR, bool SHARDED, bool P2, int SHAPE = 0>
 __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtTravArgs A /* kernel-argument segment: scalar loads */, uint32_t perWaveBytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t wave = threadIdx.x >> 6;
+  uint32_t q = blockIdx.x * NW + wave;
+  if (q >= A.qn) return;
+  if (A.qlist) { if (q >= *A.qcount) return; q = A.qlist[q]; }
+  pqt_traverse_query<WCR, SHARDED, P2, SHAPE>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Query-sharded traversal, receiving side (pqt_query_shard_bins).  The traversal of a query ran on ANOTHER shard
+// (pqt_traverse_bins) and arrives as its list of included populated bins (bin id | global start << 32, visiting order).
+//   pqt_k_l1virt       a1 only: L1virt[lp][c] of every query (the rerank's distance table), same sums as the traversal.
+//   pqt_k_resolve_bins one wavefront per query: looks every listed bin up in THIS shard's table (local start, local members,
+//                      members on lower shards), scans the local populations, and leaves exactly what the SHARDED traversal's
+//                      finish step leaves -- bin runs (first local visiting position | first store row << 32, global position of
+//                      the first local member) or the expanded candidate list, nLocal, the schedule registration.  A query whose
+//                      list overflowed at the sender (trailer count 0xffffffff) is appended to tvList and traversed here by the
+//                      list-mode traversal kernel.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_l1virt(const float* __restrict__ Q, const float* __restrict__ cb1, PqtDevParams prm,
+                                                         float* __restrict__ qL1virt) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t D = prm.D, C1 = prm.C1, LP = prm.LP, SS = prm.SS;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t i = tid; i < D; i += PQT_BLOCK) smem[i] = Q[(size_t)q * D + i];
+  __syncthreads();
+  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) {
+    const uint32_t lp = t / C1, c = t % C1;  // consecutive threads -> consecutive outputs
+    const float* cen = cb1 + (size_t)c * D + lp * SS;
+    const float* qq = smem + lp * SS;
+    float s = 0.f;
+    for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+    qL1virt[(size_t)q * LP * C1 + t] = s;
+  }
+}
+
+struct PqtResolveArgs {
+  const unsigned long long* gbins; uint32_t gbinCap;  // [qn][gbinCap + 1], see PqtTravArgs
+  const PqtBinEntry* table; const uint32_t* lower; uint32_t tableBits, tableSeed;
+  uint32_t qn;
+  uint32_t* cand; uint32_t* candPos; uint64_t stride;
+  uint32_t* nCand; uint32_t* nLocal; uint32_t* nIncl;
+  unsigned long long* runs; uint32_t* runGpos; uint32_t* nRuns; uint32_t runCap;
+  uint32_t* outCount;
+  uint32_t* tvList; uint32_t* tvCount;
+  uint32_t* schedCnt; unsigned long long* schedList; uint32_t schedCap;
+};
+#define PQT_GBIN_MAX 128  // largest per-query list pqt_k_resolve_bins accepts (2 entries per lane)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void pqt_k_resolve_bins(const PqtResolveArgs A) {
+  __shared__ unsigned long long sBinAll[NW][PQT_GBIN_MAX];
+  __shared__ uint32_t sGposAll[NW][PQT_GBIN_MAX];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blockIdx.x * NW + wave;
   if (q >= A.qn) return;
-  pqt_traverse_query<WCR, SHARDED, P2, SHAPE>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
+  unsigned long long* const sBin = sBinAll[wave];
+  uint32_t* const sGpos = sGposAll[wave];
+  const unsigned long long* row = A.gbins + (size_t)q * (A.gbinCap + 1u);
+  const unsigned long long trailer = row[A.gbinCap];
+  const uint32_t m = (uint32_t)trailer, cnt = (uint32_t)(trailer >> 32);
+  if (m == 0xffffffffu) {  // the sender could not list this query's bins: traverse it here
+    if (lane == 0) { A.tvList[atomicAdd(A.tvCount, 1u)] = q; A.nCand[q] = 0; A.nLocal[q] = 0; A.nIncl[q] = 0; if (A.nRuns) A.nRuns[q] = 0xffffffffu; }
+    return;
+  }
+  const uint4* table4 = reinterpret_cast<const uint4*>(A.table);
+  uint32_t ls[2], lc[2], gp[2];
+  uint32_t myLocal = 0, myBins = 0;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t e = lane * 2 + r;  // blocked: the wave scans below run in entry (= visiting) order
+    ls[r] = 0; lc[r] = 0; gp[r] = 0;
+    if (e < m) {
+      const unsigned long long ent = row[e];
+      uint32_t slot = 0;
+      const uint4 x = pqt_table_lookup(table4, (uint32_t)ent, A.tableBits, A.tableSeed, &slot);
+      if (x.y) { ls[r] = x.z; lc[r] = x.w; gp[r] = (uint32_t)(ent >> 32) + A.lower[slot]; }
+    }
+    myLocal += lc[r];
+    myBins += lc[r] ? 1u : 0u;
+  }
+  const uint32_t locIncl = pqt_wave_incl_scan(myLocal);
+  const uint32_t totLocal = __shfl(locIncl, 63, 64);
+  uint32_t lrun = locIncl - myLocal;
+  const uint32_t nbIncl = pqt_wave_incl_scan(myBins);
+  const uint32_t mL = __shfl(nbIncl, 63, 64);  // listed bins with members on this shard
+  uint32_t wpos = nbIncl - myBins;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    if (lc[r]) { sBin[wpos] = (unsigned long long)lrun | ((unsigned long long)ls[r] << 32); sGpos[wpos] = gp[r]; ++wpos; lrun += lc[r]; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint32_t schedSlot = 0, schedPos = 0;
+  if (lane == 0) {
+    A.nCand[q] = cnt; A.nLocal[q] = totLocal; A.nIncl[q] = m;
+    if (A.outCount) A.outCount[q] = cnt;
+    if (A.schedCnt) {
+      schedSlot = (q & 7u) * PQT_SCHED_CLASSES + pqt_sched_class(totLocal);
+      schedPos = __hip_atomic_fetch_add(&A.schedCnt[schedSlot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (schedPos < A.schedCap) A.schedList[(size_t)schedSlot * A.schedCap + schedPos] = (unsigned long long)q | ((unsigned long long)totLocal << 32);
+    }
+  }
+  if (A.runs) {
+    if (mL <= A.runCap) {
+      for (uint32_t i = lane; i < mL; i += 64) { A.runs[(size_t)q * PQT_RUNCAP + i] = sBin[i]; A.runGpos[(size_t)q * PQT_RUNCAP + i] = sGpos[i]; }
+      if (lane == 0) A.nRuns[q] = mL;
+      return;
+    }
+    if (lane == 0) A.nRuns[q] = 0xffffffffu;
+  }
+  uint32_t* const out = A.cand + (size_t)q * A.stride;
+  uint32_t* const outP = A.candPos + (size_t)q * A.stride;
+  if (totLocal >= 32u * mL) {  // long bins: walk the listed bins with coalesced stores
+    for (uint32_t b = 0; b < mL; ++b) {
+      const unsigned long long be = sBin[b];
+      const uint32_t s0 = (uint32_t)be, l0 = (uint32_t)(be >> 32), g0 = sGpos[b];
+      const uint32_t e0 = b + 1 < mL ? (uint32_t)sBin[b + 1] : totLocal;
+      for (uint32_t j = s0 + lane; j < e0; j += 64) { out[j] = l0 + (j - s0); outP[j] = g0 + (j - s0); }
+    }
+  } else {
+    for (uint32_t j = lane; j < totLocal; j += 64) {
+      uint32_t lo = 0, hi = mL;  // last entry with start <= j
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)sBin[mid] <= j) lo = mid; else hi = mid;
+      }
+      const unsigned long long be = sBin[lo];
+      const uint32_t off = j - (uint32_t)be;
+      out[j] = (uint32_t)(be >> 32) + off;
+      outP[j] = sGpos[lo] + off;
+    }
+  }
+}
+
+// marks every query of a pqt_traverse_bins request as "traverse it yourself" (shapes the fused traversal does not cover)
+__global__ __launch_bounds__(256) void pqt_k_gbins_overflow(unsigned long long* __restrict__ gbins, uint32_t cap, uint32_t qn) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q < qn) gbins[(size_t)q * (cap + 1u) + cap] = 0xffffffffull;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,298 @@
+// pqt_multi.cpp -- the range-sharded database behind ONE handle (include/pqt_hip.h: pqt_multi_*): N shard indices on N
+// devices of one node inside one process, a query batch fanned out on N streams.  Host code only: everything it does goes
+// through the public single-shard C-ABI (pqt_traverse_bins, pqt_query_shard_bins, pqt_merge_topk) and peer copies
+// (hipMemcpyPeerAsync: xGMI between the GPUs of an MI355X node), ordered by events -- no host synchronisation inside a batch.
+// The multi-PROCESS deployment (one rank per GPU, bench.py / sharding.py) runs the same protocol with RCCL collectives in
+// place of the peer copies.
+//
+// Reference counterpart: none -- pqt::PerturbationProTree is single-device (cudaSetDevice(FLAGS_device), tool_query.cpp:74);
+// SURVEY.md 8(b) "multi-GPU handle fans out internally", 8(e).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pqt_hip.h"
+
+namespace {
+constexpr uint32_t kBinCap = 128;  // per-query capacity of the exchanged bin lists (pqt_traverse_bins: 1..128)
+
+// error text of this translation unit; pqt_multi_last_error() falls back to pqt_last_error() for failures of the shard calls
+thread_local std::string g_merr;
+int mfail(int code, const std::string& msg) { g_merr = msg; return code; }
+#define MHIP(expr)                                                                                  \
+  do {                                                                                              \
+    hipError_t e_ = (expr);                                                                         \
+    if (e_ != hipSuccess) return mfail(PQT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define MPQT(expr)                                                                                  \
+  do {                                                                                              \
+    int rc_ = (expr);                                                                               \
+    if (rc_ != PQT_OK) { g_merr = std::string(#expr) + ": " + pqt_last_error(); return rc_; }       \
+  } while (0)
+}  // namespace
+
+struct pqt_multi {
+  pqt_params prm{};
+  int n = 0;
+  std::vector<pqt_index*> sh;
+  std::vector<int> dev;
+  std::vector<hipStream_t> st;
+  std::vector<hipEvent_t> evT, evR;  // traversal of the shard's query slice done / shard's top-k done
+  hipEvent_t evIn = nullptr;
+  uint64_t nTotal = 0;
+  std::vector<uint64_t> lo, hi;      // id range of every shard
+  // per-shard device buffers, grown on demand
+  std::vector<float*> dQ; std::vector<unsigned long long*> dBins; std::vector<uint32_t*> dPack; std::vector<uint32_t*> dCount;
+  std::vector<size_t> capQ, capBins, capPack, capCount;
+  uint32_t* dGather = nullptr; size_t capGather = 0;  // on device 0: [n][3][qn][k]
+  float* hQ = nullptr; uint32_t* hI = nullptr; float* hD = nullptr; uint32_t* hC = nullptr;  // staging of pqt_multi_query_host (device 0)
+  size_t capHQ = 0, capHK = 0, capHC = 0;
+  bool replicatedTraversal = false;
+};
+
+namespace {
+template <class T>
+int growDev(int device, T** p, size_t* cap, size_t want) {
+  if (want <= *cap) return PQT_OK;
+  MHIP(hipSetDevice(device));
+  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  MHIP(hipMalloc((void**)p, std::max<size_t>(want, 1) * sizeof(T)));
+  *cap = want;
+  return PQT_OK;
+}
+// dst on device dd <- src on device sd, enqueued on `st` (a stream of device dd)
+int peerCopy(void* dst, int dd, const void* src, int sd, size_t bytes, hipStream_t st) {
+  if (!bytes) return PQT_OK;
+  if (dd == sd) MHIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+  else MHIP(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, st));
+  return PQT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* pqt_multi_last_error(void) { return g_merr.c_str(); }
+
+int pqt_multi_create(const pqt_params* prm, int nshards, const int* devices, pqt_multi** out) {
+  if (!prm || !out || nshards < 1 || nshards > 64) return mfail(PQT_ERR_INVALID, "bad arguments (1 <= nshards <= 64)");
+  pqt_multi* m = new pqt_multi();
+  m->prm = *prm; m->n = nshards;
+  m->sh.assign(nshards, nullptr); m->dev.resize(nshards); m->st.assign(nshards, nullptr);
+  m->evT.assign(nshards, nullptr); m->evR.assign(nshards, nullptr);
+  m->lo.assign(nshards, 0); m->hi.assign(nshards, 0);
+  m->dQ.assign(nshards, nullptr); m->dBins.assign(nshards, nullptr); m->dPack.assign(nshards, nullptr); m->dCount.assign(nshards, nullptr);
+  m->capQ.assign(nshards, 0); m->capBins.assign(nshards, 0); m->capPack.assign(nshards, 0); m->capCount.assign(nshards, 0);
+  for (int s = 0; s < nshards; ++s) {
+    m->dev[s] = devices ? devices[s] : s;
+    int rc = pqt_index_create(prm, m->dev[s], &m->sh[s]);
+    if (rc == PQT_OK && (hipSetDevice(m->dev[s]) != hipSuccess || hipStreamCreateWithFlags(&m->st[s], hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&m->evT[s], hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&m->evR[s], hipEventDisableTiming) != hipSuccess)) {
+      rc = PQT_ERR_DEVICE; g_merr = "stream / event creation failed";
+    } else if (rc != PQT_OK) g_merr = pqt_last_error();
+    if (rc != PQT_OK) { pqt_multi_destroy(m); return rc; }
+  }
+  // peer access between the devices (xGMI): without it hipMemcpyPeerAsync stages through the host
+  for (int a = 0; a < nshards; ++a)
+    for (int b = 0; b < nshards; ++b)
+      if (m->dev[a] != m->dev[b]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, m->dev[a], m->dev[b]) == hipSuccess && can) {
+          (void)hipSetDevice(m->dev[a]);
+          (void)hipDeviceEnablePeerAccess(m->dev[b], 0);  // "already enabled" is fine
+          (void)hipGetLastError();
+        }
+      }
+  if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventCreateWithFlags(&m->evIn, hipEventDisableTiming) != hipSuccess) {
+    pqt_multi_destroy(m);
+    return mfail(PQT_ERR_DEVICE, "event creation failed");
+  }
+  *out = m;
+  return PQT_OK;
+}
+
+void pqt_multi_destroy(pqt_multi* m) {
+  if (!m) return;
+  for (int s = 0; s < m->n; ++s) {
+    (void)hipSetDevice(m->dev[s]);
+    if (m->st[s]) (void)hipStreamSynchronize(m->st[s]);
+    for (void* p : {(void*)m->dQ[s], (void*)m->dBins[s], (void*)m->dPack[s], (void*)m->dCount[s]}) if (p) (void)hipFree(p);
+    if (m->evT[s]) (void)hipEventDestroy(m->evT[s]);
+    if (m->evR[s]) (void)hipEventDestroy(m->evR[s]);
+    if (m->st[s]) (void)hipStreamDestroy(m->st[s]);
+    if (m->sh[s]) pqt_index_destroy(m->sh[s]);
+  }
+  if (m->n) (void)hipSetDevice(m->dev[0]);
+  for (void* p : {(void*)m->dGather, (void*)m->hQ, (void*)m->hI, (void*)m->hD, (void*)m->hC}) if (p) (void)hipFree(p);
+  if (m->evIn) (void)hipEventDestroy(m->evIn);
+  delete m;
+}
+
+int pqt_multi_shards(const pqt_multi* m) { return m ? m->n : 0; }
+pqt_index* pqt_multi_shard(pqt_multi* m, int s) { return (m && s >= 0 && s < m->n) ? m->sh[s] : nullptr; }
+
+int pqt_multi_shard_range(const pqt_multi* m, int s, uint64_t* id_lo, uint64_t* id_hi) {
+  if (!m || s < 0 || s >= m->n) return mfail(PQT_ERR_INVALID, "no such shard");
+  if (id_lo) *id_lo = m->lo[s];
+  if (id_hi) *id_hi = m->hi[s];
+  return PQT_OK;
+}
+
+int pqt_multi_set_option(pqt_multi* m, const char* name, int64_t value) {
+  if (!m || !name) return mfail(PQT_ERR_INVALID, "null argument");
+  // "replicated_traversal" = 1: every shard traverses the whole batch itself (no exchange of bin lists); results are identical
+  if (strcmp(name, "replicated_traversal") == 0) { m->replicatedTraversal = value != 0; return PQT_OK; }
+  for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_option(m->sh[s], name, value));
+  return PQT_OK;
+}
+
+int pqt_multi_set_codebooks(pqt_multi* m, const float* cb1_host, const float* cb2_host) {
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_codebooks(m->sh[s], cb1_host, cb2_host));
+  return PQT_OK;
+}
+
+int pqt_multi_build_heuristic(pqt_multi* m, uint64_t rows) {
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  // the table is built once (the reference's sort of all (W*C2)^P tuples) and handed to the other shards as a prefix
+  MPQT(pqt_index_build_heuristic(m->sh[0], rows));
+  if (m->n > 1) {
+    std::vector<uint32_t> t((size_t)rows * m->prm.p);
+    uint64_t have = rows;
+    // the shard keeps min(rows, (W*C2)^P) rows: ask for what it holds
+    std::fill(t.begin(), t.end(), 0xffffffffu);
+    MPQT(pqt_index_get_heuristic(m->sh[0], t.data(), rows));
+    while (have > 0 && t[(have - 1) * m->prm.p] == 0xffffffffu) --have;  // rows beyond the table were not written
+    for (int s = 1; s < m->n; ++s) MPQT(pqt_index_set_heuristic(m->sh[s], t.data(), have));
+  }
+  return PQT_OK;
+}
+
+int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows) {
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_heuristic(m->sh[s], tuples_host, rows));
+  return PQT_OK;
+}
+
+int pqt_multi_set_bins(pqt_multi* m, uint64_t nbins, const uint32_t* bin_ids_host, const uint32_t* bin_sizes_host, const uint32_t* members_host,
+                       uint64_t n_total) {
+  if (!m || (nbins && (!bin_ids_host || !bin_sizes_host || !members_host))) return mfail(PQT_ERR_INVALID, "null argument");
+  if (n_total == 0) for (uint64_t b = 0; b < nbins; ++b) n_total += bin_sizes_host[b];  // a complete database: ids 0 .. N-1
+  if (n_total > 0xffffffffull) return mfail(PQT_ERR_LIMIT, "vector ids are 32-bit");
+  m->nTotal = n_total;
+  for (int s = 0; s < m->n; ++s) {
+    m->lo[s] = n_total * (uint64_t)s / (uint64_t)m->n;
+    m->hi[s] = n_total * (uint64_t)(s + 1) / (uint64_t)m->n;
+    MPQT(pqt_index_set_bins_shard(m->sh[s], nbins, bin_ids_host, bin_sizes_host, members_host, (uint32_t)m->lo[s], (uint32_t)m->hi[s]));
+  }
+  return PQT_OK;
+}
+
+int pqt_multi_set_lines_host(pqt_multi* m, const uint32_t* codes_host, uint64_t nvec) {
+  if (!m || (!codes_host && nvec)) return mfail(PQT_ERR_INVALID, "null argument");
+  if (nvec != m->nTotal) return mfail(PQT_ERR_STATE, "line codes must cover the database handed to pqt_multi_set_bins (same number of vectors)");
+  for (int s = 0; s < m->n; ++s)
+    MPQT(pqt_index_set_lines_host(m->sh[s], codes_host + m->lo[s] * m->prm.lp, m->hi[s] - m->lo[s], m->lo[s]));
+  return PQT_OK;
+}
+
+int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* out_idx_dev0,
+                    float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync) {
+  if (!m || !out_idx_dev0 || !out_dist_dev0 || (qn && !q_dev0) || !k) return mfail(PQT_ERR_INVALID, "bad query arguments");
+  if (qn == 0) return PQT_OK;
+  const int n = m->n;
+  const uint32_t D = m->prm.dim;
+  const size_t wordsPack = (size_t)3 * qn * k, wordsBins = (size_t)qn * (kBinCap + 1);
+  for (int s = 0; s < n; ++s) {
+    int rc;
+    if (s > 0 && (rc = growDev(m->dev[s], &m->dQ[s], &m->capQ[s], (size_t)qn * D))) return rc;
+    if ((rc = growDev(m->dev[s], &m->dBins[s], &m->capBins[s], wordsBins))) return rc;
+    if ((rc = growDev(m->dev[s], &m->dPack[s], &m->capPack[s], wordsPack))) return rc;
+    if ((rc = growDev(m->dev[s], &m->dCount[s], &m->capCount[s], (size_t)qn))) return rc;
+  }
+  { int rc; if ((rc = growDev(m->dev[0], &m->dGather, &m->capGather, (size_t)n * wordsPack))) return rc; }
+  MHIP(hipSetDevice(m->dev[0]));
+  hipStream_t st0 = hip_stream ? (hipStream_t)hip_stream : m->st[0];
+  // the batch is ready (and the previous batch of this handle fully merged) once everything enqueued on st0 so far has run
+  MHIP(hipEventRecord(m->evIn, st0));
+  const uint32_t qs = (qn + (uint32_t)n - 1) / (uint32_t)n;
+  // 1. queries to every shard, traversal of the shard's own query slice
+  for (int s = 0; s < n; ++s) {
+    MHIP(hipSetDevice(m->dev[s]));
+    hipStream_t st = s == 0 ? st0 : m->st[s];
+    const float* q = q_dev0;
+    if (s > 0) {
+      MHIP(hipStreamWaitEvent(st, m->evIn, 0));
+      int rc = peerCopy(m->dQ[s], m->dev[s], q_dev0, m->dev[0], (size_t)qn * D * 4, st);
+      if (rc) return rc;
+      q = m->dQ[s];
+    }
+    if (!m->replicatedTraversal) {
+      const uint32_t a = std::min<uint32_t>((uint32_t)s * qs, qn), b = std::min<uint32_t>((uint32_t)(s + 1) * qs, qn);
+      if (b > a) MPQT(pqt_traverse_bins(m->sh[s], q + (size_t)a * D, b - a, Bv, Bb, kBinCap, m->dBins[s] + (size_t)a * (kBinCap + 1), st, 0));
+      MHIP(hipEventRecord(m->evT[s], st));
+    }
+  }
+  // 2. every shard pulls the other slices' bin lists (the all-gather), reranks its slice of the database
+  for (int d = 0; d < n; ++d) {
+    MHIP(hipSetDevice(m->dev[d]));
+    hipStream_t st = d == 0 ? st0 : m->st[d];
+    const float* q = d == 0 ? q_dev0 : m->dQ[d];
+    uint32_t* pk = m->dPack[d];
+    if (m->replicatedTraversal) {
+      MPQT(pqt_query_shard(m->sh[d], q, qn, Bv, Bb, k, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k, m->dCount[d], st, 0));
+    } else {
+      for (int s = 0; s < n; ++s) {
+        if (s == d) continue;
+        const uint32_t a = std::min<uint32_t>((uint32_t)s * qs, qn), b = std::min<uint32_t>((uint32_t)(s + 1) * qs, qn);
+        if (b <= a) continue;
+        MHIP(hipStreamWaitEvent(st, m->evT[s], 0));
+        int rc = peerCopy(m->dBins[d] + (size_t)a * (kBinCap + 1), m->dev[d], m->dBins[s] + (size_t)a * (kBinCap + 1), m->dev[s],
+                          (size_t)(b - a) * (kBinCap + 1) * 8, st);
+        if (rc) return rc;
+      }
+      MPQT(pqt_query_shard_bins(m->sh[d], q, qn, Bv, Bb, k, m->dBins[d], kBinCap, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k,
+                                m->dCount[d], st, 0));
+    }
+    MHIP(hipEventRecord(m->evR[d], st));
+  }
+  // 3. per-shard top-k to device 0, exact (distance, position) merge
+  MHIP(hipSetDevice(m->dev[0]));
+  for (int s = 0; s < n; ++s) {
+    if (s > 0) MHIP(hipStreamWaitEvent(st0, m->evR[s], 0));
+    int rc = peerCopy(m->dGather + (size_t)s * wordsPack, m->dev[0], m->dPack[s], m->dev[s], wordsPack * 4, st0);
+    if (rc) return rc;
+  }
+  MPQT(pqt_merge_topk(m->sh[0], (uint32_t)n, qn, k, m->dGather, reinterpret_cast<const float*>(m->dGather + (size_t)qn * k), m->dGather + (size_t)2 * qn * k,
+                      (uint64_t)wordsPack, out_idx_dev0, out_dist_dev0, st0, 0));
+  if (out_count_dev0) MHIP(hipMemcpyAsync(out_count_dev0, m->dCount[0], (size_t)qn * 4, hipMemcpyDeviceToDevice, st0));
+  if (sync) MHIP(hipStreamSynchronize(st0));
+  return PQT_OK;
+}
+
+int pqt_multi_query_host(pqt_multi* m, const float* q_host, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* out_idx_host,
+                         float* out_dist_host, uint32_t* out_count_host) {
+  if (!m || !q_host || !out_idx_host || !out_dist_host) return mfail(PQT_ERR_INVALID, "null argument");
+  const size_t nq = (size_t)qn * m->prm.dim, nk = (size_t)qn * k;
+  int rc;
+  if ((rc = growDev(m->dev[0], &m->hQ, &m->capHQ, nq))) return rc;
+  if (nk > m->capHK) {
+    size_t c1 = m->capHK, c2 = m->capHK;
+    if ((rc = growDev(m->dev[0], &m->hI, &c1, nk)) || (rc = growDev(m->dev[0], &m->hD, &c2, nk))) { m->capHK = 0; return rc; }
+    m->capHK = nk;
+  }
+  if ((rc = growDev(m->dev[0], &m->hC, &m->capHC, (size_t)qn))) return rc;
+  MHIP(hipSetDevice(m->dev[0]));
+  MHIP(hipMemcpyAsync(m->hQ, q_host, nq * 4, hipMemcpyHostToDevice, m->st[0]));
+  if ((rc = pqt_multi_query(m, m->hQ, qn, Bv, Bb, k, m->hI, m->hD, m->hC, m->st[0], 0))) return rc;
+  MHIP(hipMemcpyAsync(out_idx_host, m->hI, nk * 4, hipMemcpyDeviceToHost, m->st[0]));
+  MHIP(hipMemcpyAsync(out_dist_host, m->hD, nk * 4, hipMemcpyDeviceToHost, m->st[0]));
+  if (out_count_host) MHIP(hipMemcpyAsync(out_count_host, m->hC, (size_t)qn * 4, hipMemcpyDeviceToHost, m->st[0]));
+  MHIP(hipStreamSynchronize(m->st[0]));
+  return PQT_OK;
+}
+
+}  // extern "C"

@@ -26,7 +26,7 @@ void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
       d_hashCounts(nullptr), d_hashSizeHeld(0), d_lineById(nullptr), d_lineByIdValid(false), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
 
@@ -44,6 +44,7 @@ PerturbationProTree::~PerturbationProTree() {
   (void)hipSetDevice(d_device);
   releaseDeviceScratch();
   if (d_idx) pqt_index_destroy(d_idx);
+  if (d_multi) pqt_multi_destroy(d_multi);
 }
 
 // result buffers of queryKNN live as long as the object and only grow (the reference allocates and frees all scratch per
@@ -63,8 +64,24 @@ void PerturbationProTree::check(int rc, const char* what) {
 }
 
 pqt_index* PerturbationProTree::handle() {
+  if (d_multi) return pqt_multi_shard(d_multi, 0);  // tree-level calls (assign + encode, statistics): the first shard's copy
   if (!d_idx) throw std::runtime_error("no tree loaded (readTreeFromFile / loadTree / setTree first)");
   return d_idx;
+}
+
+void PerturbationProTree::singleDeviceOnly(const char* what) const {
+  if (d_multi) throw std::runtime_error(std::string(what) + ": not available with several devices (setDevices); use one device");
+}
+
+void PerturbationProTree::prepareDistSequence(uint _rows) {
+  if (d_multi) { if (pqt_multi_build_heuristic(d_multi, _rows) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); return; }
+  ProTree::prepareDistSequence(_rows);
+}
+
+void PerturbationProTree::uploadLines(size_t _N) {
+  if (d_multi) { if (pqt_multi_set_lines_host(d_multi, reinterpret_cast<const uint32_t*>(h_lines.data()), _N) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
+  else check(pqt_index_set_lines_host(handle(), reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
+  d_lineByIdValid = false;
 }
 
 void PerturbationProTree::setTree(uint _c1, uint _c2, const float* _cb1, const float* _cb2) {
@@ -72,9 +89,16 @@ void PerturbationProTree::setTree(uint _c1, uint _c2, const float* _cb1, const f
   h_codeBook.assign(_cb1, _cb1 + (size_t)_c1 * d_dim);
   h_codeBook2.assign(_cb2, _cb2 + (size_t)_c1 * _c2 * d_dim);
   if (d_idx) { pqt_index_destroy(d_idx); d_idx = nullptr; }
+  if (d_multi) { pqt_multi_destroy(d_multi); d_multi = nullptr; }
   pqt_params prm = {d_dim, d_p, _c1, _c2, std::min(d_w, _c1), d_lineParts};
-  check(pqt_index_create(&prm, d_device, &d_idx), "pqt_index_create");
-  check(pqt_index_set_codebooks(d_idx, h_codeBook.data(), h_codeBook2.data()), "pqt_index_set_codebooks");
+  if (d_devices.size() > 1) {
+    if (pqt_multi_create(&prm, (int)d_devices.size(), d_devices.data(), &d_multi) != PQT_OK ||
+        pqt_multi_set_codebooks(d_multi, h_codeBook.data(), h_codeBook2.data()) != PQT_OK)
+      throw std::runtime_error(std::string("pqt_multi: ") + pqt_multi_last_error());
+  } else {
+    check(pqt_index_create(&prm, d_device, &d_idx), "pqt_index_create");
+    check(pqt_index_set_codebooks(d_idx, h_codeBook.data(), h_codeBook2.data()), "pqt_index_set_codebooks");
+  }
   d_heurRows = 0;
 }
 
@@ -277,10 +301,12 @@ void PerturbationProTree::setBins(size_t _nbins, const uint* _ids, const uint* _
   h_binIds.assign(_ids, _ids + _nbins); h_binSizes.assign(_sizes, _sizes + _nbins); h_members.assign(_members, _members + n);
   d_N = n;
   d_hashSizeHeld = 0;  // the dense hashed getters are rebuilt on demand
-  check(pqt_index_set_bins(handle(), _nbins, _ids, _sizes, _members), "pqt_index_set_bins");
+  if (d_multi) { if (pqt_multi_set_bins(d_multi, _nbins, _ids, _sizes, _members, n) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
+  else check(pqt_index_set_bins(handle(), _nbins, _ids, _sizes, _members), "pqt_index_set_bins");
 }
 
 void PerturbationProTree::setDB(uint _N, const uint* _prefix, const uint* _counts, const uint* _dbIdx, uint _hashSize) {
+  singleDeviceOnly("setDB (hashed dump family)");
   d_N = _N;
   // the exact bin ids are not recoverable from the hashed form: the exact-bin state (and the dense getters cached from it) go
   h_binIds.clear(); h_binSizes.clear(); h_members.clear();
@@ -296,8 +322,7 @@ void PerturbationProTree::prepareEmptyLambda(uint _N, uint _lParts) {
 
 void PerturbationProTree::setLines(const lineDescr* _lines, size_t _N) {
   h_lines.assign(_lines, _lines + _N * d_lineParts);
-  d_lineByIdValid = false;
-  check(pqt_index_set_lines_host(handle(), reinterpret_cast<const uint32_t*>(h_lines.data()), _N, 0), "pqt_index_set_lines_host");
+  uploadLines(_N);
 }
 
 void PerturbationProTree::loadBins(const std::string& _name) {
@@ -362,7 +387,7 @@ void PerturbationProTree::buildKBestDBChunk(const float* _A, uint _N, uint _idOf
 }
 
 void PerturbationProTree::finishDB() {
-  pqt_index* h = handle();
+  handle();
   const size_t n = h_binOfVec.size();
   // bins in ascending id order, members in insertion (= id) order: exactly what the reference's std::map holds after
   // insert() over the whole dataset (treequantizer.hpp:212-217), whatever the chunking was
@@ -372,8 +397,7 @@ void PerturbationProTree::finishDB() {
   members.reserve(n);
   for (auto& kv : bins) { ids.push_back(kv.first); sizes.push_back((uint)kv.second.size()); members.insert(members.end(), kv.second.begin(), kv.second.end()); }
   setBins(ids.size(), ids.data(), sizes.data(), members.data());
-  check(pqt_index_set_lines_host(h, reinterpret_cast<const uint32_t*>(h_lines.data()), n, 0), "pqt_index_set_lines_host");
-  d_lineByIdValid = false;
+  uploadLines(n);
   h_binOfVec.clear();
   h_binOfVec.shrink_to_fit();
 }
@@ -443,6 +467,7 @@ void PerturbationProTree::loadHashedDB(const std::string& _pre, uint _N, uint _h
 }
 
 const uint* PerturbationProTree::getDBIdx() {
+  singleDeviceOnly("getDBIdx");
   const uint32_t* ids = nullptr;
   check(pqt_index_device_arrays(handle(), &ids, nullptr, nullptr), "pqt_index_device_arrays");
   return ids;
@@ -463,6 +488,7 @@ const lineDescr* PerturbationProTree::getLine() {
 }
 
 const lineDescr* PerturbationProTree::getLineBinOrder() {
+  singleDeviceOnly("getLineBinOrder");
   const uint32_t* codes = nullptr;
   check(pqt_index_device_arrays(handle(), nullptr, &codes, nullptr), "pqt_index_device_arrays");
   return reinterpret_cast<const lineDescr*>(codes);
@@ -503,7 +529,8 @@ void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float
   if (!_QN) return;
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
   ensureResultBuffers(_resIdx.size());
-  check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1), "queryKNN");
+  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
+  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1), "queryKNN");
   d2h(_resIdx.data(), d_resIdx, _resIdx.size() * 4);
   d2h(_resDist.data(), d_resDist, _resDist.size() * 4);
 }
@@ -522,7 +549,8 @@ void PerturbationProTree::query(uint _boundVectors, uint _boundBins, const float
   std::vector<uint> idx; std::vector<float> dist; uint cnt = 0;
   for (;;) {
     idx.resize(k); dist.resize(k);
-    check(pqt_query_host(h, _vecHost, 1, _boundVectors, _boundBins, k, idx.data(), dist.data(), &cnt), "pqt_query_host");
+    if (d_multi) { if (pqt_multi_query_host(d_multi, _vecHost, 1, _boundVectors, _boundBins, k, idx.data(), dist.data(), &cnt) != PQT_OK) throw std::runtime_error(std::string("query: ") + pqt_multi_last_error()); }
+    else check(pqt_query_host(h, _vecHost, 1, _boundVectors, _boundBins, k, idx.data(), dist.data(), &cnt), "pqt_query_host");
     if (cnt <= k) break;
     k = cnt;
   }

@@ -72,7 +72,18 @@ class PerturbationProTree : public ProTree {
   ~PerturbationProTree();
 
   /** device selection (reference: cudaSetDevice(FLAGS_device), tool_query.cpp:74); call before reading a tree */
-  void setDevice(int _device) { d_device = _device; }
+  void setDevice(int _device) { d_device = _device; d_devices.clear(); }
+  /** several devices (no reference counterpart: the reference drives one device): the database is RANGE-SHARDED by vector id
+   *  over _devices (the same device may appear more than once), the object keeps ONE class surface -- loadTree / loadBins /
+   *  setBins / setLines / buildKBestDB / queryKNN / query behave as with one device and return the same results; a batch is
+   *  fanned out on the devices' streams (pqt_multi_*, include/pqt_hip.h).  _Q of queryKNN and its results live on _devices[0].
+   *  Call before reading a tree.  The hashed dump family (setDB / loadHashedDB) and the device-array getters stay
+   *  single-device. */
+  void setDevices(const std::vector<int>& _devices) { d_devices = _devices; if (!_devices.empty()) d_device = _devices[0]; }
+  size_t getNDevices() const { return d_devices.size() > 1 ? d_devices.size() : 1; }
+  /** shadows ProTree's: with several devices every shard gets the table */
+  void prepareDistSequence(uint _rows);
+  void prepareDistSequence(int _maxCluster, int _groupParts) { ProTree::prepareDistSequence(_maxCluster, _groupParts); }
   /** W of treequantizer<..,W,..> / k1 of queryKNN (PerturbationProTree.cu:8187); call before reading a tree */
   void setW(uint _w) { d_w = _w; }
   /** query bounds of treequantizer::query(boundVectors, boundBins, ..) (cpu_version/tools/query.cpp:42) */
@@ -164,7 +175,12 @@ class PerturbationProTree : public ProTree {
   void ensureResultBuffers(size_t _n);
   void releaseDeviceScratch();
 
+  void uploadLines(size_t _N);
+  void singleDeviceOnly(const char* what) const;
+
   pqt_index* d_idx;
+  pqt_multi* d_multi;           // several devices: the shards live here and d_idx stays null
+  std::vector<int> d_devices;
   // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
   uint* d_resIdx; float* d_resDist; size_t d_resCap;
   uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;

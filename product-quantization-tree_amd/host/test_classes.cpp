@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <fstream>
 #include <iostream>
 #include <vector>
@@ -54,6 +55,36 @@ int main(int argc, char** argv) {
     (void)hipFree(qd);
     fo.write((const char*)ri.data(), ri.size() * 4);
     fo.write((const char*)rd.data(), rd.size() * 4);
+    // the same dumps behind ONE object over two range shards (both on device 0 here): queryKNN and query() must return what
+    // the single-device object returned, bit for bit
+    {
+      PerturbationProTree tm(dim, p, p);
+      tm.setDevices(std::vector<int>(2, 0));
+      tm.setW(w);
+      tm.prepareEmptyLambda(0, lp);
+      tm.loadTree(tree);
+      tm.loadBins(bins);
+      tm.setBounds(bv, bb);
+      float* qd2 = nullptr;
+      if (hipMalloc((void**)&qd2, q.size() * 4) != hipSuccess || hipMemcpy(qd2, q.data(), q.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+        throw std::runtime_error("upload failed");
+      std::vector<uint> mi; std::vector<float> md;
+      tm.queryKNN(mi, md, qd2, nq, 16);
+      (void)hipFree(qd2);
+      if (mi != ri || memcmp(md.data(), rd.data(), rd.size() * 4) != 0) throw std::runtime_error("two-shard queryKNN differs from the single-device result");
+      for (uint i = 0; i < nq; ++i) {
+        std::vector<std::pair<uint, float> > a, b;
+        t.query(bv, bb, q.data() + (size_t)i * dim, a);
+        tm.query(bv, bb, q.data() + (size_t)i * dim, b);
+        if (a.size() != b.size()) throw std::runtime_error("two-shard query(): list length differs");
+        for (size_t j = 0; j < a.size(); ++j)
+          if (a[j].first != b[j].first || memcmp(&a[j].second, &b[j].second, 4) != 0) throw std::runtime_error("two-shard query(): list differs");
+      }
+      bool refused = false;
+      try { (void)tm.getDBIdx(); } catch (const std::runtime_error&) { refused = true; }
+      if (!refused) throw std::runtime_error("getDBIdx with several devices did not refuse");
+      std::cout << "multi ok " << tm.getNDevices() << std::endl;
+    }
     // optional: <base.raw f32> <n> <hashsize> -- the device-pointer overloads and the reference's device getters
     if (argc >= 15) {
       const std::string bfile = argv[12];

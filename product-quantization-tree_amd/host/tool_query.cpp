@@ -33,6 +33,8 @@ int main(int argc, char* argv[]) {
   F.def("boundbins", "500", "query(., boundBins)");
   F.def("hashed", "0", "1: load the CUDA library's dump family even when a .bins dump exists");
   F.def("nvec", "4096", "results per query (queryKNN _nVec)");
+  F.def("gpus", "1", "range-shard the database over the devices 0 .. gpus-1 of this node (one process, one handle)");
+  F.def("devices", "", "explicit device list for the shards, e.g. 0,1,2,3 (overrides --gpus / --device; a device may repeat)");
   if (!F.parse(argc, argv)) return 1;
   try {
     const uint dim = F.num("dim"), p = F.num("p"), c1 = F.num("c1"), c2 = F.num("c2"), lp = F.num("lineparts");
@@ -43,6 +45,13 @@ int main(int argc, char* argv[]) {
     std::vector<float> qh = qr.data(qn);
     PerturbationProTree ppt(dim, p, p);
     ppt.setDevice((int)F.num("device"));
+    {
+      std::vector<int> devs;
+      const std::string dl = F.str("devices");
+      for (size_t a = 0; a < dl.size();) { size_t b = dl.find(',', a); if (b == std::string::npos) b = dl.size(); if (b > a) devs.push_back(atoi(dl.substr(a, b - a).c_str())); a = b + 1; }
+      if (devs.empty() && F.num("gpus") > 1) for (int g = 0; g < (int)F.num("gpus"); ++g) devs.push_back(g);
+      if (devs.size() > 1) { ppt.setDevices(devs); std::cout << "database range-sharded over " << devs.size() << " devices" << std::endl; }
+    }
     ppt.setW((uint)F.num("w"));
     ppt.prepareEmptyLambda(0, lp);
     ppt.setBounds((uint)F.num("boundvectors"), (uint)F.num("boundbins"));
@@ -62,7 +71,7 @@ int main(int argc, char* argv[]) {
       std::cout << "read " << pre << ".prefix" << std::endl << "read " << pre << ".count" << std::endl << "read " << pre << ".dbIdx" << std::endl
                 << "read " << pre << "_" << lp << ".lines" << std::endl;
     }
-    if (hipSetDevice((int)F.num("device")) != hipSuccess) { std::cerr << "no device" << std::endl; return 1; }
+    if (hipSetDevice(ppt.getNDevices() > 1 ? (F.str("devices").empty() ? 0 : atoi(F.str("devices").c_str())) : (int)F.num("device")) != hipSuccess) { std::cerr << "no device" << std::endl; return 1; }
     float* qd = nullptr;
     if (hipMalloc((void**)&qd, qh.size() * 4) != hipSuccess || hipMemcpy(qd, qh.data(), qh.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
       std::cerr << "query upload failed" << std::endl; return 1;

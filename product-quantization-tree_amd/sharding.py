@@ -7,12 +7,25 @@ its own slice, and the per-shard top-k lists (id, distance, global visiting posi
 query slice (all-to-all) with an all-gather of the merged slices, or with ONE all-gather of the whole lists -- and merged
 by (distance, position): exactly the order of the unsharded engine.
 
+The traversal itself does not depend on which vectors a shard holds, so it is sharded by QUERIES (traversal="sharded", the
+default of bench.py): rank r traverses only the queries of its slice [r*qs, (r+1)*qs) and hands out, per query, the included
+populated bins as (bin id, global visiting position of the first member) in visiting order -- at most BIN_CAP entries of 8
+bytes plus one trailer word; ONE all-gather makes every list known everywhere, and each rank resolves the listed bins against
+its own bin table (local start, local members, members on lower ranks) before the rerank.  A query whose list does not fit is
+traversed by every rank itself.  With W ranks the replicated part of a step shrinks from a whole traversal to 1/W of it plus a
+table look-up per listed bin.
+
 The functions take an `engine` exposing
     query_shard(q, bv, bb, k, out_idx, out_dist, out_pos, out_count)
+    traverse_bins(q, bv, bb, cap, out_bins)                                  # int64 [n][cap + 1], see include/pqt_hip.h
+    query_shard_bins(q, bv, bb, k, bins, cap, out_idx, out_dist, out_pos, out_count)
     merge_topk(world, qn, k, idx0, dist0, pos0, out_idx, out_dist, shard_stride)   # shard s at +s*shard_stride words
 so the same code drives the HIP library (PqtShardEngine below) and, in the CPU test-suite, a stand-in over gloo.
 """
 import torch
+
+
+BIN_CAP = 128  # per-query capacity of the exchanged bin lists (pqt_traverse_bins accepts 1..128); a longer list falls back
 
 
 def shard_range(rank, world, n):
@@ -96,10 +109,19 @@ class ShardBuffers:
         self.out_idx_pad = torch.empty((world * qs, k), dtype=i32, device=device)
         self.out_dist_pad = torch.empty((world * qs, k), dtype=torch.float32, device=device)
         self.out_idx, self.out_dist = self.out_idx_pad[:qn], self.out_dist_pad[:qn]
+        # traversal = "sharded": this rank's bin lists of its query slice, and everybody's after the all-gather.  Rows of the
+        # padding queries beyond qn stay zero (an empty list: trailer count 0).
+        self.bins_local = torch.zeros((qs, BIN_CAP + 1), dtype=torch.int64, device=device)
+        self.bins_all = torch.zeros((world * qs, BIN_CAP + 1), dtype=torch.int64, device=device)
 
 
-def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False):
+def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False, traversal="replicated", rank=None):
     """One step of the sharded hot path.  Returns (out_idx, out_dist, count) views into `buf`.
+
+    traversal = "replicated": every rank traverses the whole batch (pqt_query_shard).
+    traversal = "sharded": rank r traverses the queries of its slice only (pqt_traverse_bins), ONE all-gather of the per-query
+        bin lists ([qs][BIN_CAP + 1] 8-byte words per rank: 10 MB in total for 10 k queries), then every rank resolves the lists
+        against its own table and reranks its slice of the database (pqt_query_shard_bins).  Same result bit for bit.
 
     exchange = "alltoall" (default): the per-shard top-k lists travel by query slice -- rank r gets from every shard only
         the rows of queries [r*qs, (r+1)*qs) (1/W of each message: on xGMI's point-to-point links every pair moves its own
@@ -110,7 +132,20 @@ def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", f
         (the protocol of round 1; same result bit for bit)."""
     qn = q.shape[0]
     qs = buf.qs
-    engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
+    if traversal == "sharded":
+        if rank is None:
+            rank = dist.get_rank() if (world > 1 or force_collectives) else 0
+        lo, hi = min(rank * qs, qn), min((rank + 1) * qs, qn)
+        if hi > lo:
+            engine.traverse_bins(q[lo:hi], bv, bb, BIN_CAP, buf.bins_local)
+        if world == 1 and not force_collectives:
+            bins = buf.bins_local
+        else:
+            dist.all_gather_into_tensor(buf.bins_all, buf.bins_local)
+            bins = buf.bins_all
+        engine.query_shard_bins(q, bv, bb, k, bins, BIN_CAP, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
+    else:
+        engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
     if world == 1 and not force_collectives:
         engine.merge_topk(1, qn, k, buf.pack[0], buf.pack[1].view(torch.float32), buf.pack[2], buf.out_idx, buf.out_dist, 3 * world * qs * k)
         return buf.out_idx, buf.out_dist, buf.count
@@ -141,6 +176,12 @@ class PqtShardEngine:
 
     def query_shard(self, q, bv, bb, k, out_idx, out_dist, out_pos, out_count):
         self.index.query_shard_dev(q, bv, bb, k, out_idx, out_dist, out_pos, out_count, stream=self._stream())
+
+    def traverse_bins(self, q, bv, bb, cap, out_bins):
+        self.index.traverse_bins_dev(q, bv, bb, cap, out_bins, stream=self._stream())
+
+    def query_shard_bins(self, q, bv, bb, k, bins, cap, out_idx, out_dist, out_pos, out_count):
+        self.index.query_shard_bins_dev(q, bv, bb, k, bins, cap, out_idx, out_dist, out_pos, out_count, stream=self._stream())
 
     def merge_topk(self, world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, shard_stride):
         self.index.merge_topk_dev(world, qn, k, all_idx, all_dist, all_pos, out_idx, out_dist, stream=self._stream(),

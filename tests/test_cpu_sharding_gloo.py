@@ -37,6 +37,64 @@ class OracleShardEngine:
             out_pos[qi, :n] = torch.from_numpy(pos[order].astype(np.int64)).to(torch.int32)
             out_count[qi] = len(m)
 
+    # ---- query-sharded traversal (include/pqt_hip.h: pqt_traverse_bins / pqt_query_shard_bins) restated over the oracle ----
+    def _bin_table(self):
+        if not hasattr(self, "_bins"):
+            fx = self.fx
+            starts = np.concatenate([[0], np.cumsum(fx.bin_sizes.astype(np.int64))])
+            self._bins = {int(b): fx.members[starts[i]:starts[i + 1]] for i, b in enumerate(fx.bin_ids)}
+        return self._bins
+
+    def traverse_bins(self, q, bv, bb, cap, out_bins):
+        """Row i: the included populated bins of query i in visiting order as bin id | global start << 32, trailer = count | nCand << 32
+        (count 0xffffffff when the list does not fit cap)."""
+        o, tab = self.fx.oracle, self._bin_table()
+        for qi in range(q.shape[0]):
+            ids, _, seq = o.stage_bins(q[qi].numpy(), bb)
+            run, ent = 0, []
+            for b in ids[seq].tolist():  # visiting order; the reference's cut: a bin is taken while the count before it is <= Bv
+                if run > bv:
+                    break
+                size = len(tab.get(b, ()))
+                if size:
+                    ent.append(b | (run << 32))
+                run += size
+            row = np.zeros(cap + 1, np.uint64)
+            if len(ent) <= cap:
+                row[:len(ent)] = np.array(ent, np.uint64)
+                row[cap] = len(ent) | (run << 32)
+            else:
+                row[cap] = 0xffffffff
+            out_bins[qi] = torch.from_numpy(row.view(np.int64))
+
+    def query_shard_bins(self, q, bv, bb, k, bins, cap, out_idx, out_dist, out_pos, out_count):
+        o, tab = self.fx.oracle, self._bin_table()
+        for qi in range(q.shape[0]):
+            row = bins[qi].numpy().view(np.uint64)
+            m, ncand = int(row[cap]) & 0xffffffff, int(row[cap]) >> 32
+            if m == 0xffffffff:  # the sender's list overflowed: this shard traverses the query itself
+                self.query_shard(q[qi:qi + 1], bv, bb, k, out_idx[qi:qi + 1], out_dist[qi:qi + 1], out_pos[qi:qi + 1], out_count[qi:qi + 1])
+                continue
+            u_ids, u_d = o.query_unsorted(q[qi].numpy(), bv, bb)  # distance of the candidate at global visiting position p = u_d[p]
+            assert ncand == len(u_ids)
+            ids, d, pos = [], [], []
+            for e in row[:m].tolist():
+                b, g0 = int(e) & 0xffffffff, int(e) >> 32
+                mem = tab[b]
+                assert np.array_equal(u_ids[g0:g0 + len(mem)], mem)  # the listed start really is the bin's place in the visiting order
+                sel = (mem >= self.lo) & (mem < self.hi)
+                ids.append(mem[sel]); d.append(u_d[g0:g0 + len(mem)][sel]); pos.append(np.arange(g0, g0 + len(mem), dtype=np.uint32)[sel])
+            ids, d, pos = (np.concatenate(a) if a else np.empty(0, t) for a, t in ((ids, np.uint32), (d, np.float32), (pos, np.uint32)))
+            order = np.lexsort((pos, d))[:k]
+            n = len(order)
+            out_idx[qi] = -1
+            out_pos[qi] = -1
+            out_dist[qi] = float("inf")
+            out_idx[qi, :n] = torch.from_numpy(ids[order].astype(np.int64)).to(torch.int32)
+            out_dist[qi, :n] = torch.from_numpy(d[order])
+            out_pos[qi, :n] = torch.from_numpy(pos[order].astype(np.int64)).to(torch.int32)
+            out_count[qi] = ncand
+
     def merge_topk(self, world, qn, k, idx0, dist0, pos0, out_idx, out_dist, shard_stride):
         # idx0/dist0/pos0 are views of shard 0's [qn][k] block inside the gathered buffer; shard s sits shard_stride
         # 32-bit words further (the same addressing the HIP merge kernel uses)
@@ -55,13 +113,15 @@ class OracleShardEngine:
             out_dist[qi] = torch.from_numpy(d[order])
 
 
-def _worker(rank, world, port, q, exchange="alltoall"):
+def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", bin_cap=None):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sh = __import__("importlib").import_module("product-quantization-tree_amd.sharding")
+        if bin_cap:
+            sh.BIN_CAP = bin_cap  # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
         fx = fixture("odd")
         n = fx.oracle.num_vectors
         lo, hi = sh.shard_range(rank, world, n)
@@ -69,7 +129,11 @@ def _worker(rank, world, port, q, exchange="alltoall"):
         queries = torch.from_numpy(fx.queries[:7])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded
         k, bv, bb = 20, 300, 100
         buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu")
-        oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange)
+        oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange, traversal=traversal)
+        if traversal == "sharded":
+            trailer = buf.bins_all[:queries.shape[0], sh.BIN_CAP].numpy().view(np.uint64) & np.uint64(0xffffffff)
+            over = int((trailer == 0xffffffff).sum())
+            assert (over > 0) == bool(bin_cap), (over, bin_cap)  # the fallback is exercised exactly when the capacity is small
         ok = True
         fx.oracle.set_sort_mode(1)
         for qi in range(queries.shape[0]):
@@ -146,6 +210,24 @@ def test_gloo_sharded_query_equals_unsharded(world, exchange):
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,exchange,bin_cap", [(2, "alltoall", None), (3, "alltoall", None), (3, "allgather", 3), (2, "alltoall", 3)])
+def test_gloo_query_sharded_traversal_equals_unsharded(world, exchange, bin_cap):
+    """The second exchange: every rank traverses only its query slice, ONE all-gather of the per-query bin lists,
+    every rank resolves them against its own slice of the database -- same result as the unsharded engine; with a small list
+    capacity the overflowed queries take the traverse-it-yourself fallback."""
+    fixture("odd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, "sharded", bin_cap)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

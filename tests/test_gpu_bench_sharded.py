@@ -15,11 +15,13 @@ from common import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_range_sharded_bench_line():
+@pytest.mark.parametrize("traversal", ["sharded", "replicated"])
+def test_two_rank_range_sharded_bench_line(traversal):
     env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    port = 29700 + os.getpid() % 200
+    port = 29700 + os.getpid() % 200 + (0 if traversal == "sharded" else 211)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "synth1m", "--steps", "3", "--warmup", "1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "synth1m", "--steps", "3", "--warmup", "1",
+           "--traversal", traversal]
     out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -28,7 +30,10 @@ def test_two_rank_range_sharded_bench_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["collective_world_size"] == 2
     assert c["ranks_agree"] is True
     assert c["same_workload_1gpu"]["results_identical_to_sharded"] is True
-    assert "range-sharded" in c["parallelism"]
+    assert "range-sharded" in c["parallelism"] and c["traversal"] == traversal
+    assert ("bins-resolved" in c["kernel_path"]) == (traversal == "sharded"), c["kernel_path"]
+    # the line carries the ratio of its own strong scaling at the top level (the two ranks share one GPU here: no speed-up expected)
+    assert d["scaling_vs_1gpu"] == c["same_workload_1gpu"]["speedup_of_this_run"] > 0
     assert d["roofline"]["frac"] > 0 and c["mean_candidates"] > 100
     # the shards partition the candidates: this rank reranked about half of them
     assert 0.2 < c["mean_candidates_this_rank"] / c["mean_candidates"] < 0.8
@@ -48,3 +53,21 @@ def test_single_rank_rccl_drives_every_collective_of_the_sharded_path(exchange):
     c = d["config"]
     assert c["collective_backend"] == "rccl" and c["exchange"] == exchange and d["scaling"] == "strong"
     assert c["ranks_agree"] is True and c["same_workload_1gpu"]["results_identical_to_sharded"] is True
+
+
+def test_default_line_carries_the_hbm_roofline_leg():
+    """`python bench.py` (N = 1): `value` is the SIFT1M-shape number and config.hbm_roofline_leg holds the configs[2] workload at both
+    knob sets with the dominant kernel's roofline fraction (here with a small stand-in workload so the test stays short)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu", "--hbm-workload", "synth1m"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, PQT_BENCH_NO_PIPELINE="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["workload_name"] == "sift1m"
+    assert d["roofline"]["traffic_source"] is None or "committed profile" in d["roofline"]["traffic_source"]
+    assert d["roofline"]["measured_stream_GBps"] > 1000
+    leg = d["config"]["hbm_roofline_leg"]
+    assert "error" not in leg, leg
+    for knobs in ("knobs_20000_500", "knobs_4096_4096"):
+        e = leg[knobs]
+        assert e["queries_per_sec"] > 0 and 0 < e["roofline"]["frac"] < 1 and e["roofline"]["kernel"].startswith("pqt_k_")
+        assert "rerank=mode2" in e["kernel_path"] and e["filter_fallbacks"] == 0

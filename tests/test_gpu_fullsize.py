@@ -268,6 +268,22 @@ def test_cfg3_fullsize_eight_way_shards_equal_unsharded(big3):
                 tot_local += sh.stats()["candidates"]
                 assert np.array_equal(Cc[s].cpu().numpy().view(np.uint32), ref_c)  # every shard sees the global count
             assert tot_local == int(ref_c.astype(np.int64).sum())  # the shards partition the candidates
+            # query-sharded traversal: shard s traverses query slice s only, the lists are concatenated (the all-gather), and every
+            # shard's pqt_query_shard_bins reproduces its pqt_query_shard output -- with the schedule-2 registration coming from
+            # the resolve kernel instead of the traversal
+            cap, qs = sharding.BIN_CAP, (qn + world - 1) // world
+            bins_all = torch.zeros((world * qs, cap + 1), dtype=torch.int64, device=dev)
+            for s, sh in enumerate(shards):
+                lo_q, hi_q = min(s * qs, qn), min((s + 1) * qs, qn)
+                if hi_q > lo_q:
+                    sh.traverse_bins_dev(q[lo_q:hi_q], bv, bb, cap, bins_all[lo_q:hi_q], sync=True)
+            assert int(((bins_all[:qn, cap] & 0xffffffff) == 0xffffffff).sum()) == 0  # no list overflows 128 bins at this shape
+            for s, sh in enumerate(shards):
+                o = [torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty((qn, k), dtype=torch.float32, device=dev),
+                     torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty(qn, dtype=torch.int32, device=dev)]
+                sh.query_shard_bins_dev(q, bv, bb, k, bins_all, cap, o[0], o[1], o[2], o[3], sync=True)
+                assert "traverse=bins-resolved" in sh.last_path()
+                assert torch.equal(o[0], pack[s, 0]) and torch.equal(o[1].view(torch.int32), pack[s, 1]) and torch.equal(o[2], pack[s, 2]) and torch.equal(o[3], Cc[s]), (bv, bb, s)
             oI = torch.empty((qn, k), dtype=torch.int32, device=dev)
             oD = torch.empty((qn, k), dtype=torch.float32, device=dev)
             shards[0].merge_topk_dev(world, qn, k, pack[0, 0], pack[0, 1].view(torch.float32), pack[0, 2], oI, oD, sync=True, shard_stride=3 * qn * k)

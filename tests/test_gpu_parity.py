@@ -969,3 +969,123 @@ def test_query_candidates_entry_point_returns_the_whole_sorted_list():
         assert rc == -1 and b"out_count" in pkg.lib().pqt_last_error()
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("name", ["tools_default", "cfg2_small", "cfg3_small", "wrap", "odd", "ties", "big_coarse"])
+@pytest.mark.parametrize("cap", [128, 3])
+def test_query_sharded_traversal_equals_replicated_traversal(name, cap):
+    """pqt_traverse_bins on ONE shard + pqt_query_shard_bins on EVERY shard == pqt_query_shard (each shard traversing itself):
+    ids, distance bits, global visiting positions, counts.  The bin lists are shard independent (every shard writes the same
+    bytes) and equal the lists derived from the oracle's traversal; a small capacity forces the traverse-it-yourself fallback;
+    bound_bins > 512 runs the wide traversal on both sides."""
+    import torch
+    from test_cpu_sharding_gloo import OracleShardEngine
+    f = fixture(name)
+    n = f.base.shape[0]
+    cuts = [0, n // 3, n]
+    shards = [f.hip_index(shard=(cuts[r], cuts[r + 1])) for r in range(2)]
+    try:
+        q = torch.from_numpy(f.queries).cuda()
+        qn, k = q.shape[0], 50
+        knobs = [BV_BB[name]]
+        if CONFIGS[name]["heur_rows"] >= 1024:
+            knobs.append((10 ** 6, 1000))  # wide traversal
+        for bv, bb in knobs:
+            lists = []
+            for sh in shards:
+                b = torch.zeros((qn, cap + 1), dtype=torch.int64, device="cuda")
+                torch.cuda.synchronize()
+                sh.traverse_bins_dev(q, bv, bb, cap, b, sync=True)
+                lists.append(b.cpu().numpy().view(np.uint64))
+            # only the used part of a row is defined
+            for qi in range(qn):
+                m = int(lists[0][qi, cap]) & 0xffffffff
+                assert lists[0][qi, cap] == lists[1][qi, cap]
+                if m != 0xffffffff:
+                    assert np.array_equal(lists[0][qi, :m], lists[1][qi, :m]), (name, bv, bb, qi)
+            st = shards[0].stats() if False else None
+            ref = []
+            for sh in shards:
+                o = [torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty((qn, k), dtype=torch.float32, device="cuda"),
+                     torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty(qn, dtype=torch.int32, device="cuda")]
+                sh.query_shard_dev(q, bv, bb, k, o[0], o[1], o[2], o[3], sync=True)
+                ref.append([t.cpu().numpy() for t in o])
+                ties = sh.stats()["ties_bins"]
+            if not ties and name != "ties":
+                exp = torch.zeros((qn, cap + 1), dtype=torch.int64)
+                OracleShardEngine(f, 0, n).traverse_bins(torch.from_numpy(f.queries), bv, bb, cap, exp)
+                exp = exp.numpy().view(np.uint64)
+                for qi in range(qn):
+                    m = int(exp[qi, cap]) & 0xffffffff
+                    assert exp[qi, cap] == lists[0][qi, cap] or (m == 0xffffffff and (int(lists[0][qi, cap]) & 0xffffffff) == 0xffffffff), (name, bv, bb, qi)
+                    if m != 0xffffffff:
+                        assert np.array_equal(exp[qi, :m], lists[0][qi, :m]), (name, bv, bb, qi)
+            over = sum(1 for qi in range(qn) if (int(lists[0][qi, cap]) & 0xffffffff) == 0xffffffff)
+            if cap == 3:
+                assert over > 0, "the small capacity was meant to overflow some lists"
+            bins_dev = torch.from_numpy(lists[0].view(np.int64)).cuda()
+            for s_, sh in enumerate(shards):
+                o = [torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty((qn, k), dtype=torch.float32, device="cuda"),
+                     torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty(qn, dtype=torch.int32, device="cuda")]
+                torch.cuda.synchronize()
+                sh.query_shard_bins_dev(q, bv, bb, k, bins_dev, cap, o[0], o[1], o[2], o[3], sync=True)
+                assert "traverse=bins-resolved" in sh.last_path(), sh.last_path()
+                got = [t.cpu().numpy() for t in o]
+                assert np.array_equal(got[3], ref[s_][3]), (name, bv, bb, s_, "counts")
+                assert np.array_equal(got[0], ref[s_][0]) and np.array_equal(got[1].view(np.uint32), ref[s_][1].view(np.uint32)), (name, bv, bb, s_)
+                assert np.array_equal(got[2], ref[s_][2]), (name, bv, bb, s_, "positions")
+    finally:
+        for sh in shards:
+            sh.close()
+
+
+@pytest.mark.parametrize("name,nsh", [("tools_default", 2), ("cfg2_small", 3), ("cfg3_small", 4), ("wrap", 5), ("odd", 2)])
+def test_multi_handle_equals_single_index(name, nsh):
+    """pqt_multi_*: ONE handle over nsh range shards in one process (all on device 0 here) -- query slices traversed by
+    different shards, bin lists exchanged by copies, per-shard top-k merged -- returns the single-index result bit for bit, with
+    the sharded and the replicated traversal, for k below and above 128, through the device- and the host-pointer entry."""
+    import torch
+    pkg = pqt_pkg()
+    f = fixture(name)
+    c = f.cfg
+    ref = f.hip_index()
+    m = pkg.PqtMulti(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], [0] * nsh)
+    try:
+        m.set_codebooks(f.cb1, f.cb2)
+        m.set_heuristic(f.heur)
+        m.set_bins(f.bin_ids, f.bin_sizes, f.members)
+        m.set_lines(f.codes)
+        n = f.base.shape[0]
+        assert [m.shard_range(s) for s in range(nsh)] == [(n * s // nsh, n * (s + 1) // nsh) for s in range(nsh)]
+        Bv, Bb = BV_BB[name]
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        for k in (10, 100, 300):
+            r_ids, r_d, r_c = ref.query(f.queries, Bv, Bb, k)
+            for rep in (0, 1):
+                m.set_option("replicated_traversal", rep)
+                oi = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+                od = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+                oc = torch.empty(qn, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                m.query_dev(q, Bv, Bb, k, oi, od, oc, sync=True)
+                assert np.array_equal(oi.cpu().numpy().view(np.uint32), r_ids), (name, k, rep)
+                assert np.array_equal(bits(od.cpu().numpy()), bits(r_d)), (name, k, rep)
+                assert np.array_equal(oc.cpu().numpy().view(np.uint32), r_c), (name, k, rep)
+                assert ("bins-resolved" in m.shard_last_path(nsh - 1)) == (rep == 0)
+            h_ids, h_d, h_c = m.query(f.queries, Bv, Bb, k)
+            assert np.array_equal(h_ids, r_ids) and np.array_equal(bits(h_d), bits(r_d)) and np.array_equal(h_c, r_c)
+        # two batches back to back without a host synchronisation in between reuse the exchange buffers correctly
+        oi2 = [torch.empty((qn, 50), dtype=torch.int32, device="cuda") for _ in range(2)]
+        od2 = [torch.empty((qn, 50), dtype=torch.float32, device="cuda") for _ in range(2)]
+        m.set_option("replicated_traversal", 0)
+        qrev = q.flip(0).contiguous()
+        torch.cuda.synchronize()
+        m.query_dev(q, Bv, Bb, 50, oi2[0], od2[0])
+        m.query_dev(qrev, Bv, Bb, 50, oi2[1], od2[1], sync=True)
+        r_ids, r_d, _ = ref.query(f.queries, Bv, Bb, 50)
+        assert np.array_equal(oi2[0].cpu().numpy().view(np.uint32), r_ids) and np.array_equal(oi2[1].cpu().numpy().view(np.uint32), r_ids[::-1])
+        assert np.array_equal(bits(od2[1].cpu().numpy()), bits(r_d[::-1]))
+    finally:
+        m.close()
+        ref.close()

@@ -63,6 +63,13 @@ def test_createdb_then_query_roundtrip(tmp_path):
         want = np.mean([gt[i, 0] in lists[i][:min(R, nvec)] for i in range(len(lists))])
         assert abs(got[R] - want) < 1e-5, (R, got[R], want)  # the tool prints 6 significant digits
     assert "avg. query time" in out.stdout
+    # the same dumps range-sharded over three handles behind the one front-end (all on device 0 here; `--gpus 8` on a node):
+    # identical recall lines
+    out3 = subprocess.run([os.path.join(HOST, "tool_query")] + args + ["--queryset", "query.umem", "--groundtruth", "gt.imem",
+                          "--boundvectors", str(bv), "--boundbins", str(bb), "--nvec", str(nvec), "--devices", "0,0,0"], capture_output=True, text=True)
+    assert out3.returncode == 0, out3.stderr + out3.stdout
+    assert "range-sharded over 3 devices" in out3.stdout
+    assert [l for l in out3.stdout.splitlines() if l.startswith("@R")] == [l for l in out.stdout.splitlines() if l.startswith("@R")]
 
 
 def test_tool_reports_missing_codebook(tmp_path):
@@ -119,7 +126,8 @@ def test_class_surface_loadtree_loadbins_query(tmp_path):
     out = subprocess.run([os.path.join(HOST, "test_classes"), str(c["D"]), str(c["P"]), str(c["LP"]), str(c["W"]), "o.tree", "o.bins",
                           "q.raw", str(nq), str(bv), str(bb), "res.bin"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
-    assert out.stdout.split()[:3] == ["ok", str(c["C1"]), str(c["C2"])]
+    assert out.stdout.splitlines()[-1].split()[:3] == ["ok", str(c["C1"]), str(c["C2"])]
+    assert "multi ok 2" in out.stdout  # the same dumps behind one object over two range shards: identical queryKNN / query() results
     assert open("res.bin.tree", "rb").read() == open("o.tree", "rb").read()
     assert open("res.bin.bins", "rb").read() == open("o.bins", "rb").read()
     raw = np.fromfile("res.bin", np.uint32)
@@ -161,7 +169,7 @@ def test_committed_dump_pair_loads_and_reproduces_expected_lists(tmp_path):
     out = subprocess.run([os.path.join(HOST, "test_classes"), str(D), str(P), str(LP), str(W), os.path.join(g, "dump_small.tree"),
                           os.path.join(g, "dump_small.bins"), "q.raw", str(nq), str(bv), str(bb), "res.bin"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
-    assert out.stdout.split()[:3] == ["ok", str(C1), str(C2)]
+    assert out.stdout.splitlines()[-1].split()[:3] == ["ok", str(C1), str(C2)]
     # the dumps survive a load/save round trip byte for byte
     assert open("res.bin.tree", "rb").read() == open(os.path.join(g, "dump_small.tree"), "rb").read()
     assert open("res.bin.bins", "rb").read() == open(os.path.join(g, "dump_small.bins"), "rb").read()
@@ -268,3 +276,40 @@ def test_class_surface_device_pointers_and_getters(tmp_path):
     assert np.array_equal(g_codes, f.codes)  # getLine(): row i = code of VECTOR i, like the reference's d_lineLambda and the .lines dump
     assert np.array_equal(g_codes_bin, f.codes[f.members])  # getLineBinOrder(): row i = code of getDBIdx()[i]
     assert np.array_equal(g_prefix, prefix) and np.array_equal(g_counts, counts)
+
+
+def test_bench_dataset_dir_real_data_leg(tmp_path):
+    """bench.py --dataset-dir: the reference's own pipeline on TEXMEX-format files (scripts/prepare_data.sh:3 fetches them; here a
+    small fabricated set in the same formats): tool_createdb trains the tree and builds the database, the engine's recall@1/@10/@100
+    (cpu_version/tools/query.cpp:29-82) equals the checker's on the same index, id lists identical."""
+    import json
+    import sys
+    from common import sift_like
+    rng = np.random.default_rng(7)
+    base, learn = sift_like(20000, 128, 901), sift_like(3000, 128, 902)
+    pick = rng.integers(0, base.shape[0], 64)
+    queries = np.clip(np.rint(base[pick] + rng.normal(0, 5, (64, 128))), 0, 255).astype(np.float32)
+    d2 = ((queries[:, None, :] - base[None, :, :]) ** 2).sum(-1)
+    gt = np.argsort(d2, axis=1, kind="stable")[:, :100].astype(np.int32)
+
+    def write_vecs(path, a, item):
+        a = np.ascontiguousarray(a, item)
+        rec = np.empty((a.shape[0], 4 + a.shape[1] * a.itemsize), np.uint8)
+        rec[:, :4] = np.frombuffer(np.int32(a.shape[1]).tobytes(), np.uint8)
+        rec[:, 4:] = a.view(np.uint8).reshape(a.shape[0], -1)
+        rec.tofile(path)
+    write_vecs(tmp_path / "sift_base.fvecs", base, np.float32)
+    write_vecs(tmp_path / "sift_learn.fvecs", learn, np.float32)
+    write_vecs(tmp_path / "sift_query.bvecs", queries, np.uint8)  # both element types are read
+    write_vecs(tmp_path / "sift_groundtruth.ivecs", gt, np.int32)
+    if not os.path.exists(os.path.join(HOST, "tool_createdb")):
+        subprocess.check_call(["make", "-C", HOST])
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dataset-dir", str(tmp_path), "--dataset-train", "3000", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["data"].startswith("real:") and d["value"] > 0
+    assert c["id_lists_identical_frac"] == 1.0
+    assert c["engine"] == c["checker_on_same_index"]
+    assert c["engine"]["recall@100"] >= c["engine"]["recall@1"] and c["engine"]["recall@100"] > 0.5
