@@ -69,7 +69,7 @@ typedef struct {
   float ms_select;           /* final sort / top-k (a8)                                  */
   float ms_total;            /* whole batch on the device                                */
   uint32_t max_bin;          /* largest bin population in the index                      */
-  uint32_t filter_fallbacks; /* queries of the last call the band-filtered exact rerank (big coarse tables) handed to the plain exact kernel */
+  uint32_t filter_fallbacks; /* queries of the last call (its last chunk) that the first rerank kernel handed to its back-up: band-filtered exact rerank (big coarse tables) -> plain exact kernel; short-list sort kernel (128 < k <= 4096) -> block-wide select kernel */
 } pqt_stats;
 
 const char* pqt_last_error(void);
@@ -85,6 +85,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
 /* tuning/debug options: "fused" = 1 (default) use the wave-per-query fused kernels (traversal; rerank+select) when
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.
+ * "small_lists" = 0: a 128 < k <= 4096 call sends every query through the block-wide select kernel (default 1: candidate lists
+ * of <= 1024 entries are evaluated and sorted by one wavefront each, pqt_k_rerank_sort_small; same results).
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
  * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache, 1
  * otherwise; 2 = per-XCD query pools in longest-first order (the traversal

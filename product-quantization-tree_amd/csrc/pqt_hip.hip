@@ -98,6 +98,7 @@ struct pqt_index {
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
   bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
   std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
+  bool smallLists = true;  // 128 < k <= 4096: lists of <= 1024 candidates go through the wave-per-query evaluate + sort kernel
   int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = -1 /* auto */; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
 };
 
@@ -630,6 +631,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const bool bigCL = coarseLds && coarseBytes + lBigBase <= kMaxLds;
   if (bigK && !bigCL && lBigBase > kMaxLds) bigK = false;
   const size_t lBig = lBigBase + (bigCL ? coarseBytes : 0);
+  bool usedSmallFirst = false;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -685,8 +687,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
         // shard's table, and the (normally empty) list of queries whose list overflowed at the sender traversed here
         HIPCHK(hipMemsetAsync(idx->d_tvCount, 0, 4, st));
-        if ((rc = allowLds(pqt_k_l1virt, (size_t)d.D * 4))) return rc;
-        hipExtLaunchKernelGGL(pqt_k_l1virt, dim3(nq), dim3(PQT_BLOCK), (uint32_t)(d.D * 4), st, idx->lev0, nullptr, 0u, q_dev + (size_t)q0 * d.D, idx->d_cb1, d,
+        if ((rc = allowLds(pqt_k_l1virt, (size_t)(d.D + d.LP * d.C1) * 4))) return rc;
+        hipExtLaunchKernelGGL(pqt_k_l1virt, dim3(nq), dim3(PQT_BLOCK), (uint32_t)((d.D + d.LP * d.C1) * 4), st, idx->lev0, nullptr, 0u, q_dev + (size_t)q0 * d.D, idx->d_cb1, d,
                               idx->d_qL1virt + (size_t)q0 * d.LP * d.C1);
         const PqtResolveArgs rargs{binsIn + (size_t)q0 * (binsCap + 1u), binsCap, idx->d_table, idx->d_lower, idx->tableBits, d.tableSeed, nq,
                                    idx->d_cand, idx->d_candPos, stride, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
@@ -782,13 +784,38 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (!leanEvents) PQT_REC(EV_RERANK);
     } else if (bigK) {
       const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
+      // short lists (n <= 1024) first: wave-per-query evaluate + sort (pqt_k_rerank_sort_small); it hands the queries with longer
+      // lists to the block-wide select kernel through fbList
+      const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32);
+      const bool smallCL = coarseLds && coarseBytes + (size_t)8 * d.LP * d.C1 * 4 + 16 <= kMaxLds;
+      usedSmallFirst = smallFirst;
+      const uint32_t* bigQl = nullptr; const uint32_t* bigQc = nullptr;
+      hipEvent_t bigEv0 = idx->lev0;
+      if (smallFirst) {
+        constexpr int SNW = 8;
+        const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * d.LP * d.C1 * 4 + 16;
+        HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
+        PqtRsArgs sa{};
+        sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;
+        sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr;
+        const uint32_t sgrid = std::min<uint32_t>((nq + SNW - 1) / SNW, (uint32_t)idx->numCUs);
+#define PQT_LAUNCH_SMALL(LPVV, CL)                                                                                            \
+        do { auto kern = pqt_k_rerank_sort_small<SNW, LPVV, CL>;                                                               \
+             if ((rc = allowLds(kern, lSmall))) return rc;                                                                      \
+             hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(SNW * 64), (uint32_t)lSmall, st, idx->lev0, nullptr, 0u, sa, idx->d_fbList, idx->d_fbCount); } while (0)
+        if (d.LP == 16) { if (smallCL) PQT_LAUNCH_SMALL(4, true); else PQT_LAUNCH_SMALL(4, false); }
+        else { if (smallCL) PQT_LAUNCH_SMALL(8, true); else PQT_LAUNCH_SMALL(8, false); }
+#undef PQT_LAUNCH_SMALL
+        bigQl = idx->d_fbList; bigQc = idx->d_fbCount;
+        bigEv0 = nullptr;
+      }
 #define PQT_LAUNCH_BIG(CL, SH, VEC)                                                                                         \
       do { auto kern = pqt_k_rerank_select_big<CL, SH, VEC>;                                                                 \
            if ((rc = allowLds(kern, lBig))) return rc;                                                                       \
            const uint32_t wgPerCu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, kMaxLds / lBig));                              \
-           hipExtLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)idx->numCUs * wgPerCu)), dim3(PQT_RSB_NT), (uint32_t)lBig, st, idx->lev0, idx->lev1, 0u, \
+           hipExtLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)idx->numCUs * wgPerCu)), dim3(PQT_RSB_NT), (uint32_t)lBig, st, bigEv0, idx->lev1, 0u, \
                                  idx->d_codesBin, idx->d_ids, v, idx->d_coarse, idx->d_cand, idx->d_candPos, idx->d_nLocal + q0, stride, k, kP2, kcap, nq, d, \
-                                 oI, oD, oP, idx->ctr); } while (0)
+                                 oI, oD, oP, idx->ctr, bigQl, bigQc); } while (0)
       if (d.LP % 4 == 0) {
         if (bigCL) { if (idx->sharded) PQT_LAUNCH_BIG(true, true, 4); else PQT_LAUNCH_BIG(true, false, 4); }
         else { if (idx->sharded) PQT_LAUNCH_BIG(false, true, 4); else PQT_LAUNCH_BIG(false, false, 4); }
@@ -833,7 +860,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   HIPCHK(hipGetLastError());
   idx->lastQn = qn; idx->lastHe = He;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
-  idx->lastFilter = useFilter;
+  idx->lastFilter = useFilter || usedSmallFirst;  // (pqt_stats.filter_fallbacks then counts the queries the short-list kernel handed to the block-wide one)
   idx->lastRuns = emitRuns;
   {
     // which kernels ran (pqt_get_last_path): tests assert the path, not only the result
@@ -849,7 +876,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "");
       else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
       else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "");
-    } else if (bigK) rp = bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table";
+    } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + ((idx->smallLists && (d.LP == 16 || d.LP == 32)) ? "+small-lists" : "");
     else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
     idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks);
   }
@@ -949,6 +976,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  if (strcmp(name, "small_lists") == 0) { idx->smallLists = (value != 0); return PQT_OK; }  // 0: every query of a 128 < k <= 4096 call through the block-wide select kernel
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
   // per-kernel start/stop events (they cost ~5 us per kernel launch): 1 = every call (default), N = every N-th call, 0 = never;

@@ -7,6 +7,7 @@
 // same keys.  Sorts are by (key, original position): the result equals any comparison sort of the
 // reference whenever no two keys are exactly equal, and is the stable order otherwise.
 #pragma once
+#include <type_traits>
 #include "pqt_device.h"
 #include "pqt_wave.h"
 
@@ -2290,19 +2291,36 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtT
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_l1virt(const float* __restrict__ Q, const float* __restrict__ cb1, PqtDevParams prm,
                                                          float* __restrict__ qL1virt) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // D + LP*C1 floats
   const uint32_t D = prm.D, C1 = prm.C1, LP = prm.LP, SS = prm.SS;
+  float* sQ = smem;
+  float* sV = smem + D;
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
-  for (uint32_t i = tid; i < D; i += PQT_BLOCK) smem[i] = Q[(size_t)q * D + i];
+  for (uint32_t i = tid; i < D; i += PQT_BLOCK) sQ[i] = Q[(size_t)q * D + i];
   __syncthreads();
-  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) {
-    const uint32_t lp = t / C1, c = t % C1;  // consecutive threads -> consecutive outputs
+  // t = c*LP + lp walks cb1 contiguously (consecutive lanes read consecutive SS-float segments of one centroid row: the first
+  // version indexed by (lp, c) and touched one cache line per lane -- 0.15 ms per 10 k queries, bound by the texture addresser);
+  // the (lp, c) transpose happens in LDS, the table leaves in coalesced stores
+  for (uint32_t t = tid; t < C1 * LP; t += PQT_BLOCK) {
+    const uint32_t c = t / LP, lp = t % LP;
     const float* cen = cb1 + (size_t)c * D + lp * SS;
-    const float* qq = smem + lp * SS;
+    const float* qq = sQ + lp * SS;
     float s = 0.f;
-    for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
-    qL1virt[(size_t)q * LP * C1 + t] = s;
+    if ((SS & 3u) == 0) {
+      for (uint32_t d = 0; d < SS; d += 4) {
+        const float4 cv = *reinterpret_cast<const float4*>(cen + d);
+        float df = qq[d] - cv.x; s = s + df * df;
+        df = qq[d + 1] - cv.y; s = s + df * df;
+        df = qq[d + 2] - cv.z; s = s + df * df;
+        df = qq[d + 3] - cv.w; s = s + df * df;
+      }
+    } else {
+      for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+    }
+    sV[lp * C1 + c] = s;
   }
+  __syncthreads();
+  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) qL1virt[(size_t)q * LP * C1 + t] = sV[t];
 }
 
 struct PqtResolveArgs {
@@ -2853,7 +2871,8 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
     const uint32_t* __restrict__ codes /* bin-ordered */, const uint32_t* __restrict__ ids, const float* __restrict__ qL1virt,
     const float* __restrict__ coarse, const uint32_t* __restrict__ cand, const uint32_t* __restrict__ candPos,
     const uint32_t* __restrict__ nLocal, uint64_t stride, uint32_t k, uint32_t kP2, uint32_t kcap, uint32_t nq, PqtDevParams prm,
-    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos, unsigned long long* __restrict__ counters) {
+    uint32_t* __restrict__ outIdx, float* __restrict__ outDist, uint32_t* __restrict__ outPos, unsigned long long* __restrict__ counters,
+    const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qcount /* the queries to process (those pqt_k_rerank_sort_small left), or null = all */) {
   constexpr int NT = PQT_RSB_NT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t C1 = prm.C1, LP = prm.LP;
@@ -2869,7 +2888,9 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
   // persistent workgroups: the LDS copy of the coarse table is loaded once and serves every query of this workgroup
   if (COARSE_LDS) for (uint32_t t = tid; t < nCoarse; t += NT) sCoarse[t] = coarse[t];
   const float* cz = COARSE_LDS ? sCoarse : coarse;
-  for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+  const uint32_t nList = qlist ? *qcount : nq;
+  for (uint32_t qe = blockIdx.x; qe < nList; qe += gridDim.x) {
+  const uint32_t q = qlist ? qlist[qe] : qe;
   const uint32_t n = nLocal[q];
   const uint32_t* cid = cand + (size_t)q * stride;
   __syncthreads();  // the previous query's readers of sVirt / sKeys are done
@@ -2950,6 +2971,144 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
     }
   }
   if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  }
+}
+
+// ===================================================================================================
+// 128 < k <= 4096 with SHORT candidate lists (n <= 1024: every list of the reference front-end's own call, queryKNN(.., 4096)
+// at maxBins = 4096, holds a few hundred candidates): one WAVEFRONT per query, no tau filter, no select -- every candidate is
+// evaluated (reference association, p ascending: bit-exact), the <= 1024 keys (f32 key << 32 | visiting position) are sorted
+// by the in-register network of the smallest fitting size (R = 2, 4, 8, 16 keys per lane) and the n results + padding are
+// written.  pqt_k_rerank_select_big spent 27 us per query on such lists (one 8-wavefront workgroup per CU, a barrier-separated
+// chain of ~6 exposed memory round trips); here NW independent wavefronts per workgroup share the LDS copy of the coarse table
+// and overlap each other's round trips.  Queries with longer lists are appended to bigList for pqt_k_rerank_select_big.
+// LDS: [coarse LP*C1*C1*4 when it fits] + NW * LP*C1*4 + 16 bytes.
+// ===================================================================================================
+#define PQT_RSS_MAXN 1024
+// (few instantiations on purpose -- the four sorting networks dominate the compile time: C1 and the sharded outputs are run-time)
+template <int NW, int LPV, bool COARSE_LDS>
+__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsArgs A, uint32_t* __restrict__ bigList, uint32_t* __restrict__ bigCount) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4;
+  const uint32_t C1 = A.prm.C1;
+  const bool C1P2 = C1 > 1 && (C1 & (C1 - 1)) == 0;  // uniform
+  const uint32_t c1sh = C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u;
+  const bool SHARDED = A.outPos != nullptr;
+  const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
+  float* sCoarse = (float*)smem_raw;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * LP * C1;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * LP * C1 * 4);
+  if (threadIdx.x == 0) sTicket[0] = 0;
+  if (COARSE_LDS) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = A.coarse[t];
+  __syncthreads();
+  const float* cz = COARSE_LDS ? sCoarse : A.coarse;
+  const uint32_t G = gridDim.x, k = A.k;
+  const uint32_t L = blockIdx.x < A.qn ? (A.qn - blockIdx.x + G - 1) / G : 0u;  // this workgroup's queries: b, b + G, ...
+
+  // candidate at store position pos: the reference's ADC sum
+  auto adc = [&](const uint4 (&row)[LPV]) -> float {
+    float acc = 0.f;
+#pragma unroll
+    for (int v = 0; v < LPV; ++v) {
+      const uint32_t w[4] = {row[v].x, row[v].y, row[v].z, row[v].w};
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const uint32_t p = v * 4 + x;
+        const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+        const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
+        const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+        const float sb = sVirt[pv + Aa], sa = sVirt[pv + Bb];
+        const float sc = cz[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
+        acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+      }
+    }
+    return acc;
+  };
+  auto run = [&](auto rtag, const uint32_t q, const uint32_t n) {
+    constexpr int R = decltype(rtag)::value;
+    const uint32_t* cid = A.cand + (size_t)q * A.stride;
+    uint64_t key[R];
+    uint32_t pos[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t j = r * 64 + lane; pos[r] = j < n ? cid[j] : 0u; }
+    constexpr int U = R < 4 ? R : 4;  // candidates per lane whose rows are in flight together
+#pragma unroll
+    for (int r0 = 0; r0 < R; r0 += U) {
+      if ((uint32_t)r0 * 64u < n) {  // uniform
+        uint4 rows[U][LPV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint4* row4 = reinterpret_cast<const uint4*>(A.codes + (size_t)pos[r0 + u] * LP);
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t j = (r0 + u) * 64 + lane;
+          const float acc = adc(rows[u]);
+          key[r0 + u] = j < n ? (((uint64_t)pqt_f2key(acc) << 32) | j) : ~0ull;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) key[r0 + u] = ~0ull;
+      }
+    }
+    pqt_wave_sort_u64<R>(key);
+    // lane L holds the sorted elements [L*R, L*R + R)
+    const uint32_t kk = n < k ? n : k;
+    uint32_t ties = 0;
+    uint32_t jj[R], idv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; jj[r] = (uint32_t)key[r]; idv[r] = e < kk ? cid[jj[r]] : 0u; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; idv[r] = e < kk ? A.ids[idv[r]] : 0xffffffffu; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t e = lane * R + r;
+      const size_t o = (size_t)q * k + e;
+      if (e < k) {
+        A.outIdx[o] = idv[r];
+        A.outDist[o] = e < kk ? pqt_key2f((uint32_t)(key[r] >> 32)) : __uint_as_float(0x7f800000u);
+        if (SHARDED) A.outPos[o] = e < kk ? A.candPos[(size_t)q * A.stride + jj[r]] : 0xffffffffu;
+      }
+      const uint32_t hi = (uint32_t)(key[r] >> 32);
+      const uint32_t nx = (r + 1 < R) ? (uint32_t)(key[(r + 1) % R] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
+      if (e + 1 < kk && hi == nx && !(r + 1 == R && lane == 63)) ++ties;
+    }
+    // padding beyond the 64*R sorted slots
+    for (uint32_t e = 64u * R + lane; e < k; e += 64) {
+      const size_t o = (size_t)q * k + e;
+      A.outIdx[o] = 0xffffffffu;
+      A.outDist[o] = __uint_as_float(0x7f800000u);
+      if (SHARDED) A.outPos[o] = 0xffffffffu;
+    }
+    if (__any(ties != 0)) { if (ties) atomicAdd(&A.counters[3], (unsigned long long)ties); }
+  };
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(sTicket, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= L) break;
+    const uint32_t q = blockIdx.x + t * G;
+    const uint32_t n = A.nLocal[q];
+    if (n > PQT_RSS_MAXN) {  // long list: the block-wide kernel takes it
+      if (lane == 0) bigList[atomicAdd(bigCount, 1u)] = q;
+      continue;
+    }
+    if ((LP * C1) % 4 == 0) {
+      const float4* src4 = reinterpret_cast<const float4*>(A.qL1virt + (size_t)q * LP * C1);
+      float4* dst4 = reinterpret_cast<float4*>(sVirt);
+      for (uint32_t i = lane; i < LP * C1 / 4; i += 64) dst4[i] = src4[i];
+    } else {
+      for (uint32_t i = lane; i < LP * C1; i += 64) sVirt[i] = A.qL1virt[(size_t)q * LP * C1 + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (n <= 128) run(std::integral_constant<int, 2>{}, q, n);
+    else if (n <= 256) run(std::integral_constant<int, 4>{}, q, n);
+    else if (n <= 512) run(std::integral_constant<int, 8>{}, q, n);
+    else run(std::integral_constant<int, 16>{}, q, n);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

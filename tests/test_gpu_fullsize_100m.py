@@ -53,7 +53,7 @@ def test_cfg3_100m_properties_and_variant_identity(big100m, bv, bb):
     st = idx.stats()
     assert st["filter_fallbacks"] == 0
     assert int(cnt.astype(np.int64).sum()) == st["candidates"]
-    assert int(cnt.max()) <= bv + meta["max_bin"] and int(cnt.min()) > min(bv, 1000)  # the rerank really works on long lists
+    assert int(cnt.max()) <= bv + meta["max_bin"] and float(cnt.mean()) > 10000  # the rerank really works on long lists
     n_valid = np.minimum(cnt, 100)
     for qi in range(0, ids.shape[0], 5):
         n = int(n_valid[qi])

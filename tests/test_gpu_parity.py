@@ -1089,3 +1089,36 @@ def test_multi_handle_equals_single_index(name, nsh):
     finally:
         m.close()
         ref.close()
+
+
+@pytest.mark.parametrize("name,bv", [("tools_default", 300), ("tools_default", 10 ** 6), ("cfg2_small", 10 ** 6), ("cfg3_small", 10 ** 6), ("odd", 400)])
+@pytest.mark.parametrize("k", [129, 600, 4096])
+def test_short_lists_sorted_by_one_wavefront_long_ones_by_the_block_kernel(name, bv, k):
+    """128 < k <= 4096: candidate lists of <= 1024 entries are evaluated and sorted by one wavefront (pqt_k_rerank_sort_small), longer
+    ones are handed to the block-wide select kernel -- both against the oracle, and identical to the block-wide kernel alone."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        bb = min(CONFIGS[name]["heur_rows"], 1024)
+        ids, dist, cnt = idx.query(f.queries, bv, bb, k)
+        path = idx.last_path()
+        handed = idx.stats()["filter_fallbacks"]
+        if CONFIGS[name]["LP"] in (16, 32):
+            assert "+small-lists" in path, path
+            assert handed == int((cnt > 1024).sum()), (handed, cnt)  # exactly the long lists went to the block-wide kernel
+        f.oracle.set_sort_mode(1)
+        try:
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, bv, bb)
+                kk = min(k, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])) and np.array_equal(ids[qi, :kk], s_ids[:kk]), (name, bv, k, qi)
+                assert np.all(ids[qi, kk:] == 0xffffffff) and np.all(np.isinf(dist[qi, kk:]))
+        finally:
+            f.oracle.set_sort_mode(0)
+        idx.set_option("small_lists", 0)
+        ids2, dist2, cnt2 = idx.query(f.queries, bv, bb, k)
+        assert "+small-lists" not in idx.last_path()
+        assert np.array_equal(ids2, ids) and np.array_equal(bits(dist2), bits(dist)) and np.array_equal(cnt2, cnt)
+    finally:
+        idx.close()
