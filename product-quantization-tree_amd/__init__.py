@@ -56,10 +56,11 @@ EXPORTS = [
 
 def build(force=False):
     """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h", "pqt_multi.cpp", "Makefile")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_rerank_launch.hip", "pqt_traverse_launch.hip", "pqt_internal.h", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h",
+                                           "pqt_multi.cpp", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-C", CSRC, "libpqt_hip.so"])
+        subprocess.check_call(["make", "-j4", "-C", CSRC, "libpqt_hip.so"])
     return LIB_PATH
 
 
@@ -305,16 +306,16 @@ class PqtIndex:
         n = _chk(self.L.pqt_get_rerank_launch_ms(self.h, _p(out, f32p), cap))
         return out[:n].copy()
 
-    def debug_read(self, qn, cands=True):
+    def debug_read(self, qn, cands=True, segs=True):
         stride = self.L.pqt_debug_stride(self.h)
         WC = self.W * self.C2
         l1 = np.zeros((qn, self.LP, self.C1), np.float32)
-        sd = np.zeros((qn, self.P, WC), np.float32)
-        sb = np.zeros((qn, self.P, WC), np.uint32)
+        sd = np.zeros((qn, self.P, WC), np.float32) if segs else None
+        sb = np.zeros((qn, self.P, WC), np.uint32) if segs else None
         nc = np.zeros(qn, np.uint32)
         ci = np.zeros((qn, stride), np.uint32) if cands else None
         cd = np.zeros((qn, stride), np.float32) if cands else None
-        _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p), _p(sb, u32p),
+        _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p) if segs else None, _p(sb, u32p) if segs else None,
                                    _p(ci, u32p) if cands else None, _p(cd, f32p) if cands else None, _p(nc, u32p)))
         return dict(l1virt=l1, seg_d2=sd, seg_bin=sb, ncand=nc, cand_idx=ci, cand_dist=cd, stride=stride)
 

@@ -1,121 +1,32 @@
 // pqt_hip.hip -- libpqt_hip.so: index management + launch logic behind the C-ABI of include/pqt_hip.h.
 // gfx950 (MI355X) only.  Build: see csrc/Makefile (hipcc --offload-arch=gfx950 -ffp-contract=off).
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <algorithm>
-#include <cmath>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/pqt_hip.h"
-#include "pqt_kernels.h"
+#define PQT_MAIN_TU 1   // the non-template kernels of pqt_kernels.h are compiled here only
+#include "pqt_internal.h"
 
 namespace {
-
 thread_local std::string g_err;
-int fail(int code, const std::string& msg) { g_err = msg; return code; }
-
-#define HIPCHK(expr)                                                                         \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess)                                                                    \
-      return fail(PQT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-  } while (0)
-
-uint32_t upow(uint32_t x, uint32_t n) { uint32_t r = 1; for (uint32_t i = 0; i < n; ++i) r = x * r; return r; }
-uint32_t np2(uint64_t x) { uint64_t r = 1; while (r < x && r < (1ull << 31)) r <<= 1; return (uint32_t)r; }
-
-enum { EV_BEGIN = 0, EV_TABLES, EV_BINS, EV_ORDER, EV_RERANK, EV_SELECT, EV_COUNT };
-constexpr int kMaxChunks = 16;
-constexpr int kRing = 32;        // per-stage event sets of the last kRing query calls
-#ifndef PQT_RS_NW
-#define PQT_RS_NW 12
-#endif
-constexpr int kFusedWaves = PQT_RS_NW;
-constexpr int kCtrRing = 4;
-constexpr int kPoolRing = 4;  // blocks of 16 draw counters + 8 x 64 registration counts behind the statistics ring (rerank schedule 2)
-constexpr size_t kPoolWords = 16 + 8 * PQT_SCHED_CLASSES;
-#ifndef PQT_TR_NW
-#define PQT_TR_NW 1
-#endif
-constexpr int kTravWaves = PQT_TR_NW;    // wavefronts (= queries) per workgroup of the fused traversal kernel  // wavefronts per workgroup of the fused rerank+select kernel
-
 }  // namespace
-
-struct pqt_index {
-  pqt_params prm{};
-  PqtDevParams dp{};
-  int device = 0;
-  hipStream_t stream = nullptr;
-  // tree
-  float* d_cb1 = nullptr; float* d_cb2 = nullptr; float* d_coarse = nullptr;
-  float* d_cb2T = nullptr;  // cb2 re-tiled per cell as [S/4][C2] 16-byte vectors (coalesced row walks), when S % 4 == 0
-  bool haveTree = false;
-  // heuristic prefix (a3)
-  std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr; uint32_t* d_heur4 = nullptr;
-  uint64_t maxMultiIndex = 0;
-  // bin store (a5)
-  PqtBinEntry* d_table = nullptr; uint32_t* d_lower = nullptr; uint32_t tableBits = 0;
-  uint32_t* d_ids = nullptr; uint64_t nIds = 0; uint32_t maxBin = 0; bool sharded = false; bool haveBins = false;
-  uint64_t nTotal = 0;  // database size (all shards)
-  // line codes (a7)
-  uint32_t* d_codes = nullptr; bool codesOwned = false; uint64_t nCodes = 0; uint64_t idBase = 0;  // as handed over (id order)
-  uint32_t* d_codesBin = nullptr; bool binOrdered = false; bool linesDropped = false;
-  float* d_bias = nullptr; bool biasReady = false; bool adcBias = false; bool exactFilter = true; float coarseMax = 0.f;
-  unsigned long long* d_runs = nullptr; uint32_t* d_runGpos = nullptr; uint32_t* d_nRuns = nullptr; uint64_t runsCap = 0; int useRuns = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastRuns = false; uint32_t curRunCap = 0;
-  uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
-  uint32_t* d_tvList = nullptr; uint32_t* d_tvCount = nullptr;  // pqt_query_shard_bins: queries whose exchanged bin list overflowed (traversed here)
-   // opt-in adc_bias mode: per-row query-independent part of the ADC sum
-  uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
-  // scratch arena
-  float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
-  uint32_t* d_cand = nullptr; float* d_candDist = nullptr; uint32_t* d_candPos = nullptr; uint64_t candCap = 0;
-  uint32_t* d_nCand = nullptr; uint32_t* d_nLocal = nullptr; uint32_t* d_nIncl = nullptr;
-  hipEvent_t lev0 = nullptr, lev1 = nullptr;  // start/stop events attached to the next fused launch (lean timing), or null
-  bool curRuns = false;  // the current chunk hands bin runs (not a candidate list) from the traversal to the rerank
-  uint32_t curDynamic = 0; unsigned long long* curZero8 = nullptr; uint32_t* curPool = nullptr; uint32_t* curPoolNext = nullptr; uint32_t poolPos = 0; unsigned long long* d_schedList = nullptr; uint64_t schedCapQ = 0; uint32_t curSchedCap = 0;  // rerank schedule and next statistics block of the current chunk
-  uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
-  uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
-  uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;
-  unsigned long long* d_counters = nullptr;  // kCtrRing blocks of 8 statistics words (one per call, the next one is zeroed on the fly) + 1 spare block
-  unsigned long long* ctr = nullptr; int ctrPos = 0;
-  unsigned long long* d_tstamp = nullptr;    // optional per-query phase timestamps (debug)
-  uint64_t stride = 0;
-  // results of the last call
-  pqt_stats stats{};
-  uint32_t lastQn = 0; uint32_t lastHe = 0; bool lastSegKept = false; bool lastDistKept = false;
-  hipEvent_t evRing[kRing][kMaxChunks][EV_COUNT]{}; int ringChunks[kRing]{}; int ringPos = 0; unsigned long long calls = 0;
-  uint32_t evMask[kRing][kMaxChunks]{};      // which events of a ring slot were recorded (an event record costs ~5 us of stream time)
-  int nChunks = 0; bool evCreated = false;
-  size_t scratchBudget = (size_t)24 << 30;
-  // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
-  float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
-  bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
-  std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
-  bool smallLists = true;  // 128 < k <= 4096: lists of <= 1024 candidates go through the wave-per-query evaluate + sort kernel
-  int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = -1 /* auto */; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
-};
+int pqtFail(int code, const std::string& msg) { g_err = msg; return code; }
 
 namespace {
-
-int setDevice(const pqt_index* idx) {
-  HIPCHK(hipSetDevice(idx->device));
+std::mutex g_ldsMu;
+std::map<std::pair<int, const void*>, size_t> g_ldsSet;
+}  // namespace
+int pqtAllowLds(const void* kernel, size_t bytes) {
+  if (bytes > kMaxLds) return fail(PQT_ERR_LIMIT, "request needs more than 160 KiB of LDS per workgroup");
+  if (bytes <= 64 * 1024) return PQT_OK;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_ldsMu);
+  size_t& have = g_ldsSet[{dev, kernel}];
+  if (bytes > have) {
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
+  }
   return PQT_OK;
 }
 
-template <class T>
-int devAlloc(T** p, size_t n) {
-  if (*p) { (void)hipFree(*p); *p = nullptr; }
-  if (n == 0) n = 1;
-  HIPCHK(hipMalloc((void**)p, n * sizeof(T)));
-  return PQT_OK;
-}
+namespace {
 
 int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if (qn <= idx->qCap) return PQT_OK;
@@ -237,73 +148,6 @@ size_t ldsSelect(uint32_t kP2) { return (size_t)kP2 * 8 + (256 + 8 + PQT_BLOCK /
 size_t ldsEncode(const PqtDevParams& d) {
   return (size_t)(d.D + d.LP * d.C1 + d.P * d.C1 + d.P + d.P * d.C2 + ((d.P * d.C2 + d.P) & 1)) * 4 + (size_t)PQT_BLOCK * 8;
 }
-constexpr size_t kMaxLds = 160 * 1024;
-
-// the dynamic-LDS ceiling of a kernel is raised once per (device, kernel, size), not on every query call
-std::mutex g_ldsMu;
-std::map<std::pair<int, const void*>, size_t> g_ldsSet;
-template <class K>
-int allowLds(K kernel, size_t bytes) {
-  if (bytes > kMaxLds) return fail(PQT_ERR_LIMIT, "request needs more than 160 KiB of LDS per workgroup");
-  if (bytes <= 64 * 1024) return PQT_OK;
-  int dev = 0;
-  HIPCHK(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lk(g_ldsMu);
-  size_t& have = g_ldsSet[{dev, (const void*)kernel}];
-  if (bytes > have) {
-    HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    have = bytes;
-  }
-  return PQT_OK;
-}
-
-// ---- fused rerank+select launcher: picks the instantiation for (LP, coarse-in-LDS, sharded) -------------------
-#ifndef PQT_RS_U16
-#define PQT_RS_U16 4   // candidates per lane in flight when LP = 16 (scaled so that U * LP/4 stays 16 code vectors)
-#endif
-static uint32_t* poolBlock(pqt_index* idx, uint32_t pos) {
-  return reinterpret_cast<uint32_t*>(idx->d_counters + 8 * (kCtrRing + 1)) + (size_t)(pos % kPoolRing) * kPoolWords;
-}
-template <int LPV, bool CL, bool SH>
-int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
-             uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
-  constexpr int U0 = (PQT_RS_U16 * 4) / LPV;
-  // 64*UV keys are appended per batch behind a best list of up to PQT_RS_BEST keys: they must fit the pending area
-  // (U = 8 at LP = 4/8 overran the wave's key slots when > 512 - k candidates of a batch beat tau)
-  constexpr int UV = U0 < 1 ? 1 : (U0 > 4 ? 4 : U0);
-  static_assert(64 * UV <= PQT_RS_PEND, "a batch of appended keys must fit the pending area");
-  const uint32_t c1 = idx->dp.C1;
-  const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
-  auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
-  if constexpr (CL) { if (c1 == 32) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5>; }  // compile-time C1 only where the table is in LDS
-  if constexpr (CL && LPV == 4) { if (c1 == 32 && idx->curRuns) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5, 0, true>; }  // experimental bin-runs variant
-  int rc = allowLds(kern, lds);
-  if (rc) return rc;
-  // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
-  const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic, idx->curZero8,
-                        nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
-                        (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
-  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
-  return PQT_OK;
-}
-template <int LPV>
-int launchRS1(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
-              uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
-  if (cl) return idx->sharded ? launchRS<LPV, true, true>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP)
-                              : launchRS<LPV, true, false>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-  return idx->sharded ? launchRS<LPV, false, true>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP)
-                      : launchRS<LPV, false, false>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-}
-int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
-                       uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
-  switch (idx->dp.LP / 4) {
-    case 1: return launchRS1<1>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-    case 2: return launchRS1<2>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-    case 4: return launchRS1<4>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-    default: return launchRS1<8>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
-  }
-}
 
 // permute the line store into bin order (see pqt_k_reorder_lines); afterwards the id-ordered copy is dropped if owned
 int reorderLines(pqt_index* idx) {
@@ -330,6 +174,7 @@ int reorderLines(pqt_index* idx) {
   return PQT_OK;
 }
 
+}  // namespace
 int ensureGroupMajor(pqt_index* idx, int G) {
   if (idx->d_codesGrp && idx->grpG == G) return PQT_OK;
   int rc;
@@ -342,6 +187,7 @@ int ensureGroupMajor(pqt_index* idx, int G) {
   idx->grpG = G;
   return PQT_OK;
 }
+namespace {
 
 // opt-in adc_bias mode: bias[pos] of every row of the bin-ordered store (once per index / line store)
 int ensureBias(pqt_index* idx) {
@@ -356,79 +202,6 @@ int ensureBias(pqt_index* idx) {
   return PQT_OK;
 }
 
-// fused rerank+select without the coarse table in LDS (pqt_rs_query MODE 1 = opt-in adc_bias distances, MODE 2 = reference
-// distances through the MODE 1 filter): group-major code words, NW wavefronts per workgroup
-PqtRsArgs rsArgsFilter(pqt_index* idx, const float* qL1virt, const uint32_t* nLocal, uint64_t stride, uint32_t k, uint32_t nq,
-                       uint32_t* oI, float* oD, uint32_t* oP) {
-  const double lp = idx->dp.LP;
-  const float kappa = (float)(2.02 * (lp * lp + 8.0 * lp + 2.0) / 16777216.0);
-  return PqtRsArgs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
-                   idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic, idx->curZero8,
-                   (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
-                   idx->d_fbList, idx->d_fbCount, idx->curRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
-}
-template <int NW, int LPV, bool SH, int MODE>
-int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
-                 uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
-  constexpr int UV = LPV >= 8 ? 2 : 4;
-  const uint32_t c1 = idx->dp.C1;
-  auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, MODE>
-                                                                                         : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, MODE>;
-  constexpr bool kRunsVariant = NW == 12 && LPV == 8;  // bin runs: BASELINE configs[2]/[3] shape only
-  if constexpr (kRunsVariant) { if (idx->curRuns) kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE, true>; }
-  int rc = allowLds(kern, lds);
-  if (rc) return rc;
-  const PqtRsArgs rargs = rsArgsFilter(idx, qL1virt, nLocal, stride, k, nq, oI, oD, oP);
-  if (MODE == 2) HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
-  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
-  if (MODE == 2) {
-    // queries whose near-tie band overflowed the wave's list (normally none): plain exact kernel on that list
-    constexpr int LNW = 4;
-    auto lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1>;
-    size_t llds = (size_t)LNW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
-    if constexpr (kRunsVariant) { if (idx->curRuns) { lk = pqt_k_rerank_select_list<LNW, LPV, UV, SH, 1, true>; llds = ((llds + 15) & ~(size_t)15) + (size_t)LNW * idx->curRunCap * 12; } }
-    if ((rc = allowLds(lk, llds))) return rc;
-    PqtRsArgs largs = rargs;
-    largs.tstamp = nullptr; largs.dynamic = 0; largs.zero8 = nullptr; largs.pool = nullptr; largs.poolNext = nullptr; largs.schedCnt = nullptr;
-    hipLaunchKernelGGL(lk, dim3(std::min<uint32_t>((nq + LNW - 1) / LNW, (uint32_t)idx->numCUs * 2)), dim3(LNW * 64), llds, st, largs);
-  }
-  return PQT_OK;
-}
-
-// ---- workgroup-per-query rerank+select for coarse tables that do not fit LDS (pqt_k_rerank_select_wg) ----------
-template <int G>
-int launchRSWG(pqt_index* idx, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
-               uint32_t* oI, float* oD, uint32_t* oP) {
-  const PqtDevParams& d = idx->dp;
-  int rc0 = ensureGroupMajor(idx, G);
-  if (rc0) return rc0;
-  const size_t lds = (size_t)G * d.C1 * d.C1 * 4 + (size_t)d.LP * d.C1 * 4 + (size_t)PQT_RS2_NW * PQT_RS2_KEYS * 8;
-  const bool p2 = (d.C1 & (d.C1 - 1)) == 0;
-  const uint32_t c1v = idx->dp.C1;
-  auto kern = idx->sharded ? (c1v == 64 ? pqt_k_rerank_select_wg<G, true, 6> : c1v == 128 ? pqt_k_rerank_select_wg<G, true, 7>
-                              : p2 ? pqt_k_rerank_select_wg<G, true, 1> : pqt_k_rerank_select_wg<G, true, 0>)
-                           : (c1v == 64 ? pqt_k_rerank_select_wg<G, false, 6> : c1v == 128 ? pqt_k_rerank_select_wg<G, false, 7>
-                              : p2 ? pqt_k_rerank_select_wg<G, false, 1> : pqt_k_rerank_select_wg<G, false, 0>);
-  int rc = allowLds(kern, lds);
-  if (rc) return rc;
-  hipExtLaunchKernelGGL(kern, dim3(nq), dim3(PQT_RS2_NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_ids, v,
-                        idx->d_coarse, idx->d_cand, idx->d_candPos, nl, stride, k, d, oI, oD, oP, idx->ctr, idx->dbg);
-  return PQT_OK;
-}
-#ifndef PQT_RSWG_SLICE_KB
-#define PQT_RSWG_SLICE_KB 32   // 32 KB slices let two workgroups share a CU (one stages while the other computes)
-#endif
-constexpr size_t kRswgSlice = (size_t)PQT_RSWG_SLICE_KB * 1024;
-// line parts per staged group: the largest of 4, 2, 1 whose table slice fits the budget and divides LP; falls back to a
-// 64 KB slice (C1 = 128); 0 = unsupported
-int rswgGroup(const PqtDevParams& d) {
-  for (int g : {4, 2, 1})
-    if ((size_t)g * d.C1 * d.C1 * 4 <= kRswgSlice && d.LP % g == 0 && (d.C1 * d.C1) % 4 == 0) return g;
-  for (int g : {4, 2, 1})
-    if ((size_t)g * d.C1 * d.C1 * 4 <= 64 * 1024 && d.LP % g == 0 && (d.C1 * d.C1) % 4 == 0) return g;
-  return 0;
-}
-
 // per-stage ms of one chunk of one ring slot: the time between two consecutive RECORDED events goes to the stage the later
 // one closes ({tables, traversal, order, rerank, select}); returns the last recorded event
 int stageMs(const pqt_index* idx, int slot, int ch, float st[5]) {
@@ -441,69 +214,6 @@ int stageMs(const pqt_index* idx, int slot, int ch, float st[5]) {
     prev = e;
   }
   return prev;
-}
-
-// ---- fused traversal (pqt_k_traverse): LDS plan and launch, shared by pqt_query*, pqt_traverse_bins and pqt_query_shard_bins
-struct TravPlan { bool fused = false, wide = false, p2 = false; size_t lTrav = 0; uint32_t perWave = 0; };
-int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp) {
-  const PqtDevParams& d = idx->dp;
-  int rc;
-  // fused traversal (wave per query) when the bin list fits the in-register sorter
-  tp.fused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
-  tp.wide = tp.fused && He > 512;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
-  const size_t travR0 = (std::max<size_t>(tp.wide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
-  tp.perWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));
-  tp.lTrav = (size_t)kTravWaves * tp.perWave;
-  const size_t lTrav = tp.lTrav;
-  auto isP2 = [](uint32_t x) { return x != 0 && (x & (x - 1)) == 0; };
-  // all layout strides powers of two (every BASELINE shape): the traversal uses shifts and masks
-  tp.p2 = isP2(d.C1) && isP2(d.C2) && isP2(d.W) && isP2(d.LP) && isP2(d.D) && isP2(d.S) && isP2(d.SS) && isP2(d.R) && d.S >= 4;
-  if (tp.fused && lTrav > 64 * 1024) {
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, false>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, false, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 4, true, true>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 1>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 1>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 2>, lTrav))) return rc;
-    if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 2>, lTrav))) return rc;
-  }
-  return PQT_OK;
-}
-// compile-time-shape instantiation the traversal of this index runs (0: run-time shape): the two BASELINE shapes, two-phase
-// enumeration only (packed heuristic rows and the presence bitmap must be there, no modulo hashing, no order-all-rows switch)
-int travShape(const pqt_index* idx, const PqtTravArgs& targs) {
-  const bool twoOk = targs.heur4 && targs.filter && !idx->dp.hashMod && !((idx->dbg >> 5) & 1u);
-  return (idx->noShape || !twoOk) ? 0 : pqt_shape_of(idx->dp);
-}
-// a1..a6 in one launch, one wavefront per query (`waves` of them); ev0 / ev1 ride on the dispatch when given
-void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& tp, uint32_t waves, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
-  const PqtDevParams& d = idx->dp;
-  const uint32_t grid = (waves + kTravWaves - 1) / kTravWaves;
-  const size_t lTrav = tp.lTrav;
-  const uint32_t travPerWave = tp.perWave;
-  const bool travP2 = tp.p2;
-#define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
-  hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, \
-                        targs, travPerWave)
-#define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
-                                else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
-  const int shape = travShape(idx, targs);
-  if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
-                    else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
-  else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
-                         else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
-  else if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
-#undef PQT_LAUNCH_TR
-#undef PQT_LAUNCH_TR1
 }
 
 // ring slot of the most recent query call that carried per-kernel events (option "stage_timing" = N > 1: not every call
@@ -760,19 +470,12 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         nextZeroed = true;
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         const uint32_t* nl = idx->d_nLocal + q0;
-#define PQT_LAUNCH_BIAS1(NWV, LPVV, MD) (idx->sharded ? launchRSBias<NWV, LPVV, true, MD>(idx, grid, NWV == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP) \
-                                                      : launchRSBias<NWV, LPVV, false, MD>(idx, grid, NWV == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP))
-#define PQT_LAUNCH_BIAS(NWV, LPVV) (useFilter ? PQT_LAUNCH_BIAS1(NWV, LPVV, 2) : PQT_LAUNCH_BIAS1(NWV, LPVV, 1))
-        rc = d.LP == 16 ? (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 4) : PQT_LAUNCH_BIAS(6, 4)) : (biasNW == 12 ? PQT_LAUNCH_BIAS(12, 8) : PQT_LAUNCH_BIAS(6, 8));
-#undef PQT_LAUNCH_BIAS1
-#undef PQT_LAUNCH_BIAS
+        rc = launchRSBiasAny(idx, biasNW, useFilter, grid, biasNW == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP);
         if (rc) return rc;
         idx->poolDirty = false;  // the launch consumes this chunk's registrations and zeroes the next block
       } else if (wgG) {
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
-        rc = wgG == 4 ? launchRSWG<4>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
-           : wgG == 2 ? launchRSWG<2>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP)
-                      : launchRSWG<1>(idx, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP);
+        rc = launchRSWGAny(idx, wgG, nq, st, v, idx->d_nLocal + q0, stride, k, oI, oD, oP);
         if (rc) return rc;
       } else {
         idx->curZero8 = nextCtr;  // the kernel also zeroes the statistics block of the next call
@@ -799,31 +502,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;
         sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr;
         const uint32_t sgrid = std::min<uint32_t>((nq + SNW - 1) / SNW, (uint32_t)idx->numCUs);
-#define PQT_LAUNCH_SMALL(LPVV, CL)                                                                                            \
-        do { auto kern = pqt_k_rerank_sort_small<SNW, LPVV, CL>;                                                               \
-             if ((rc = allowLds(kern, lSmall))) return rc;                                                                      \
-             hipExtLaunchKernelGGL(kern, dim3(sgrid), dim3(SNW * 64), (uint32_t)lSmall, st, idx->lev0, nullptr, 0u, sa, idx->d_fbList, idx->d_fbCount); } while (0)
-        if (d.LP == 16) { if (smallCL) PQT_LAUNCH_SMALL(4, true); else PQT_LAUNCH_SMALL(4, false); }
-        else { if (smallCL) PQT_LAUNCH_SMALL(8, true); else PQT_LAUNCH_SMALL(8, false); }
-#undef PQT_LAUNCH_SMALL
+        if ((rc = launchSmallLists(idx, smallCL, lSmall, sgrid, st, sa, idx->lev0))) return rc;
         bigQl = idx->d_fbList; bigQc = idx->d_fbCount;
         bigEv0 = nullptr;
       }
-#define PQT_LAUNCH_BIG(CL, SH, VEC)                                                                                         \
-      do { auto kern = pqt_k_rerank_select_big<CL, SH, VEC>;                                                                 \
-           if ((rc = allowLds(kern, lBig))) return rc;                                                                       \
-           const uint32_t wgPerCu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, kMaxLds / lBig));                              \
-           hipExtLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)idx->numCUs * wgPerCu)), dim3(PQT_RSB_NT), (uint32_t)lBig, st, bigEv0, idx->lev1, 0u, \
-                                 idx->d_codesBin, idx->d_ids, v, idx->d_coarse, idx->d_cand, idx->d_candPos, idx->d_nLocal + q0, stride, k, kP2, kcap, nq, d, \
-                                 oI, oD, oP, idx->ctr, bigQl, bigQc); } while (0)
-      if (d.LP % 4 == 0) {
-        if (bigCL) { if (idx->sharded) PQT_LAUNCH_BIG(true, true, 4); else PQT_LAUNCH_BIG(true, false, 4); }
-        else { if (idx->sharded) PQT_LAUNCH_BIG(false, true, 4); else PQT_LAUNCH_BIG(false, false, 4); }
-      } else {
-        if (bigCL) { if (idx->sharded) PQT_LAUNCH_BIG(true, true, 1); else PQT_LAUNCH_BIG(true, false, 1); }
-        else { if (idx->sharded) PQT_LAUNCH_BIG(false, true, 1); else PQT_LAUNCH_BIG(false, false, 1); }
-      }
-#undef PQT_LAUNCH_BIG
+      if ((rc = launchBigK(idx, bigCL, lBig, nq, st, v, idx->d_nLocal + q0, stride, k, kP2, kcap, oI, oD, oP, bigQl, bigQc, bigEv0, idx->lev1))) return rc;
       if (!leanEvents) PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)
@@ -1411,10 +1094,16 @@ int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const 
   int rc = setDevice(idx);
   if (rc) return rc;
   hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
-  const uint32_t mP2 = np2(std::max<uint32_t>(nsh * k, 2));
+  const uint32_t mP2 = np2(std::max<uint64_t>((uint64_t)nsh * k, 2));
   const size_t lds = (size_t)mP2 * 12;
-  if ((rc = allowLds(pqt_k_merge, lds))) return rc;
-  if (qn) hipLaunchKernelGGL(pqt_k_merge, dim3(qn), dim3(PQT_BLOCK), lds, st, inIdx, inDist, inPos, nsh, qn, k, shard_stride, mP2, outIdx, outDist);
+  if (lds > kMaxLds || (uint64_t)nsh * k > (1ull << 30)) {
+    // lists too long for the LDS-resident merge (e.g. whole candidate lists, k = 8192): rank every entry by binary searches
+    if (nsh > 64) return fail(PQT_ERR_LIMIT, "at most 64 shards in a merge");
+    if (qn) hipLaunchKernelGGL(pqt_k_merge_ranked, dim3(qn), dim3(PQT_BLOCK), 0, st, inIdx, inDist, inPos, nsh, qn, k, shard_stride, outIdx, outDist);
+  } else {
+    if ((rc = allowLds(pqt_k_merge, lds))) return rc;
+    if (qn) hipLaunchKernelGGL(pqt_k_merge, dim3(qn), dim3(PQT_BLOCK), lds, st, inIdx, inDist, inPos, nsh, qn, k, shard_stride, mP2, outIdx, outDist);
+  }
   HIPCHK(hipGetLastError());
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;

@@ -19,6 +19,7 @@
 // The reference evaluates (AV - BV) with i <= j and mirrors; x-y and y-x square identically, so
 // evaluating every (i,j) directly gives the same bits.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ coarse, PqtDevParams prm) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t total = prm.LP * prm.C1 * prm.C1;
@@ -31,6 +32,7 @@ __global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ 
   for (uint32_t d = 0; d < prm.SS; ++d) { const float df = x[d] - y[d]; s = s + df * df; }
   coarse[t] = s;
 }
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // stage a1 + a2: per-query distance tables and the sorted second-level entry lists.
@@ -41,6 +43,7 @@ __global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ 
 // outputs: qL1virt[q][LP*C1] ; segD[q][P][WC] ascending ; segBin[q][P][WC] = c1*C2+h2 in the same order
 // LDS: D + LP*C1 + P*C1 + P*W + P*WC words.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
     const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb2, PqtDevParams prm,
     float* __restrict__ qL1virt, float* __restrict__ segD, uint32_t* __restrict__ segBin,
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
   }
   if (ties) atomicAdd(&counters[1], (unsigned long long)ties);
 }
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // stage a4 + a5 + a6 (staged structure): bin enumeration, probe, exact ordering, cut and candidate gather.
@@ -479,6 +483,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
 // Bitonic sort of slot indices with a (distance key, global visiting position) comparator in LDS.
 // LDS: mP2 u32 indices + m u32 keys + m u32 positions.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
     const uint32_t* __restrict__ inIdx, const float* __restrict__ inDist, const uint32_t* __restrict__ inPos,
     uint32_t nsh, uint32_t qn, uint32_t k, uint64_t shardStride /* words between the [qn][k] blocks of consecutive shards */,
@@ -521,6 +526,49 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
     outDist[(size_t)q * k + i] = d;
   }
 }
+#endif  // PQT_MAIN_TU
+
+// the same merge without the LDS-resident sort, for nsh*k beyond its 160 KiB (e.g. the class's whole-list query() through
+// pqt_multi: k = 8192): every shard's list is already ascending in (distance, position), so an entry's place in the merged
+// list is its own index plus, for every other list, the number of entries that precede it -- one binary search per other
+// list (global memory).  Keys are unique (position), equal keys of different shards cannot occur; padding sits at the tail.
+#ifdef PQT_MAIN_TU
+__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge_ranked(
+    const uint32_t* __restrict__ inIdx, const float* __restrict__ inDist, const uint32_t* __restrict__ inPos,
+    uint32_t nsh, uint32_t qn, uint32_t k, uint64_t shardStride, uint32_t* __restrict__ outIdx, float* __restrict__ outDist) {
+  __shared__ uint32_t sN[65];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t s2 = tid; s2 < nsh; s2 += PQT_BLOCK) {  // real entries of list s2: first padding slot
+    const uint32_t* li = inIdx + (size_t)s2 * shardStride + (size_t)q * k;
+    uint32_t lo = 0, hi = k;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (li[mid] != 0xffffffffu) lo = mid + 1; else hi = mid; }
+    sN[s2] = lo;
+  }
+  __syncthreads();
+  uint32_t total = 0;
+  for (uint32_t s2 = 0; s2 < nsh; ++s2) total += sN[s2];
+  for (uint32_t e = tid; e < nsh * k; e += PQT_BLOCK) {
+    const uint32_t sh = e / k, i = e % k;
+    if (i >= sN[sh]) continue;
+    const size_t o = (size_t)sh * shardStride + (size_t)q * k + i;
+    const uint64_t key = ((uint64_t)pqt_f2key(inDist[o]) << 32) | inPos[o];
+    uint32_t rank = i;
+    for (uint32_t t = 0; t < nsh; ++t) {
+      if (t == sh) continue;
+      const size_t ot = (size_t)t * shardStride + (size_t)q * k;
+      uint32_t lo = 0, hi = sN[t];  // entries of list t that precede `key` (ties, impossible for distinct positions, go to the lower shard)
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint64_t km = ((uint64_t)pqt_f2key(inDist[ot + mid]) << 32) | inPos[ot + mid];
+        if (km < key || (km == key && t < sh)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < k) { outIdx[(size_t)q * k + rank] = inIdx[o]; outDist[(size_t)q * k + rank] = inDist[o]; }
+  }
+  for (uint32_t i = total + tid; i < k; i += PQT_BLOCK) { outIdx[(size_t)q * k + i] = 0xffffffffu; outDist[(size_t)q * k + i] = __uint_as_float(0x7f800000u); }
+}
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // offline ("next" row): insert = id() + prepareReranking for a batch of database vectors.
@@ -529,6 +577,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_merge(
 //   projection error, first minimum in (A,B) scan order (:356-391).
 // LDS: D + LP*C1 + P*C1 + P + C2*P words + reduction scratch.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
     const float* __restrict__ X, const float* __restrict__ cb1, const float* __restrict__ cb2,
     const float* __restrict__ coarse, PqtDevParams prm, uint32_t* __restrict__ outBin, uint32_t* __restrict__ outCodes,
@@ -654,8 +703,10 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_assign_encode(
     __syncthreads();
   }
 }
+#endif  // PQT_MAIN_TU
 
 // line-quantisation scalars evaluated on the device (known-answer tests, run.cu:33-113)
+#ifdef PQT_MAIN_TU
 __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, const float* l, uint32_t n,
                                float* outDist, float* outRatio, uint16_t* outU16, float* outRound) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,6 +717,7 @@ __global__ void pqt_k_triangle(const float* a, const float* b, const float* c, c
   outU16[i] = (uint16_t)u;
   outRound[i] = pqt_lambda_decode(u);
 }
+#endif  // PQT_MAIN_TU
 
 // ===================================================================================================
 // Fused stage a7 + a8 (k <= 128): ADC line rerank + exact top-k, one WAVEFRONT per query.
@@ -843,7 +895,26 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     const uint32_t j = u * 64 + lane;
     idNext[u] = (n && !useRuns) ? cid[j < n ? j : n - 1] : 0u;
   }
-  if ((C1 & 3u) == 0) {  // LP*C1 floats as 16-byte pieces (both ends are 16-byte aligned)
+  float qmax = 0.f;  // MODE 2: largest entry of the query's L1virt table
+  if constexpr (C1M >= 2) {
+    // compile-time shape: the whole table is requested before the first piece is stored (the run-time loop below compiled to one
+    // load + s_waitcnt per 1 KB: 8 serialised round trips per query at the configs[2] shape, ~14 k clocks of set-up)
+    constexpr uint32_t NV = LPV * 4 * (1u << C1M) / 4;
+    constexpr uint32_t IT = (NV + 63) / 64;
+    const float4* src4 = reinterpret_cast<const float4*>(qL1virt + (size_t)q * LP * C1);
+    float4* dst4 = reinterpret_cast<float4*>(sVirt);
+    float4 tmp[IT];
+#pragma unroll
+    for (uint32_t i = 0; i < IT; ++i) { const uint32_t t = lane + 64 * i; tmp[i] = src4[t < NV ? t : 0]; }
+#pragma unroll
+    for (uint32_t i = 0; i < IT; ++i) {
+      const uint32_t t = lane + 64 * i;
+      if (t < NV) {
+        dst4[t] = tmp[i];
+        if constexpr (MODE == 2) { const float m01 = tmp[i].x > tmp[i].y ? tmp[i].x : tmp[i].y, m23 = tmp[i].z > tmp[i].w ? tmp[i].z : tmp[i].w; const float m = m01 > m23 ? m01 : m23; qmax = m > qmax ? m : qmax; }
+      }
+    }
+  } else if ((C1 & 3u) == 0) {  // LP*C1 floats as 16-byte pieces (both ends are 16-byte aligned)
     const float4* src4 = reinterpret_cast<const float4*>(qL1virt + (size_t)q * LP * C1);
     float4* dst4 = reinterpret_cast<float4*>(sVirt);
     for (uint32_t t = lane; t < LP * C1 / 4; t += 64) dst4[t] = src4[t];
@@ -858,9 +929,8 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   constexpr uint32_t SLOTS = PQT_RS_BEST + PQT_RS_PEND;
   static_assert(BESTN + 64u * UREQ <= SLOTS, "a batch of appended keys must fit behind the best list");
   const uint32_t kSel = MODE == 2 ? BESTN : k;
-  float qmax = 0.f;  // MODE 2: largest entry of the query's L1virt table
   if constexpr (MODE == 2) {
-    for (uint32_t t = lane; t < LP * C1; t += 64) { const float v = sVirt[t]; qmax = v > qmax ? v : qmax; }
+    if constexpr (C1M < 2) { for (uint32_t t = lane; t < LP * C1; t += 64) { const float v = sVirt[t]; qmax = v > qmax ? v : qmax; } }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(qmax, d, 64); qmax = o > qmax ? o : qmax; }
   }
@@ -1099,21 +1169,41 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         return;
       }
       uint64_t xk[4];
+      // (the first version evaluated an entry term by term: the compiler emitted one coarse[] gather + s_waitcnt per term, 32
+      // serialised L2 round trips per entry and 41 k clocks per query; now an entry's code row is requested first, then all its
+      // LP coarse values together, and only the sum runs in order)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const uint32_t e = r * 64 + lane;
         xk[r] = ~0ull;
-        if (e < nT) {
-          const uint32_t j = (uint32_t)sKeys[e];
-          uint32_t posj;
-          if (useRuns) { const unsigned long long rr = sRuns[runOf(j)]; posj = (uint32_t)(rr >> 32) + (j - (uint32_t)rr); }
-          else posj = cid[j];
+        if ((uint32_t)r * 64u < nT) {  // uniform
+          const uint32_t e = r * 64 + lane;
+          const bool act = e < nT;
+          const uint32_t j = act ? (uint32_t)sKeys[e] : 0u;
+          uint32_t posj = 0;
+          if (act) {
+            if (useRuns) { const unsigned long long rr = sRuns[runOf(j)]; posj = (uint32_t)(rr >> 32) + (j - (uint32_t)rr); }
+            else posj = cid[j];
+          }
           const uint4* row4 = reinterpret_cast<const uint4*>(codes + (size_t)posj * LP);
+          uint4 rv[LPV];
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) rv[v] = row4[v];
+          float scv[LP];
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) {
+            const uint32_t w[4] = {rv[v].x, rv[v].y, rv[v].z, rv[v].w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const uint32_t p = v * 4 + x;
+              const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+              const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+              scv[p] = A.coarse[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
+            }
+          }
           float acc = 0.f;
 #pragma unroll
           for (int v = 0; v < LPV; ++v) {
-            const uint4 rv = row4[v];
-            const uint32_t w[4] = {rv.x, rv.y, rv.z, rv.w};
+            const uint32_t w[4] = {rv[v].x, rv[v].y, rv[v].z, rv[v].w};
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const uint32_t p = v * 4 + x;
@@ -1121,11 +1211,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
               const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);
               const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
               const float sb = sVirt[pv + Aa], sa = sVirt[pv + Bb];
-              const float sc = A.coarse[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
-              acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+              acc = acc + pqt_extract_distance(sa, sb, scv[p], lam);
             }
           }
-          xk[r] = ((uint64_t)pqt_f2key(acc) << 32) | j;
+          if (act) xk[r] = ((uint64_t)pqt_f2key(acc) << 32) | j;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1142,26 +1231,54 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     }
   }
   if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsVerify = t - ts0; ts0 = t; }
-  for (uint32_t i = lane; i < k; i += 64) {
-    const size_t o = (size_t)q * k + i;
-    if (i < kk) {
-      const uint64_t key = sKeys[i];
-      const uint32_t j = (uint32_t)key;
-      if (useRuns) {
-        const uint32_t ri = runOf(j);
-        const unsigned long long r = sRuns[ri];
-        outIdx[o] = ids[(uint32_t)(r >> 32) + (j - (uint32_t)r)];
-        if (SHARDED) outPos[o] = sRunG[ri] + (j - (uint32_t)r);
-      } else {
-        outIdx[o] = ids[cid[j]];
-        if (SHARDED) outPos[o] = cpos[j];
+  {
+    // k <= 128: a lane owns the result slots lane and lane + 64; their store positions, then their ids (and positions) are
+    // requested together -- two round trips for the whole result list instead of two per slot
+    static_assert(PQT_RS_BEST <= 128, "two result slots per lane");
+    uint32_t sp[2] = {0u, 0u}, gp[2] = {0xffffffffu, 0xffffffffu}, dk[2] = {0u, 0u};
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = lane + 64 * u;
+      live[u] = i < kk;
+      if (live[u]) {
+        const uint64_t key = sKeys[i];
+        const uint32_t j = (uint32_t)key;
+        dk[u] = (uint32_t)(key >> 32);
+        if (useRuns) {
+          const uint32_t ri = runOf(j);
+          const unsigned long long r = sRuns[ri];
+          sp[u] = (uint32_t)(r >> 32) + (j - (uint32_t)r);
+          if (SHARDED) gp[u] = sRunG[ri] + (j - (uint32_t)r);
+        } else {
+          sp[u] = j;  // resolved through cid[] below
+        }
+        if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == dk[u]) ++ties;
       }
-      outDist[o] = pqt_key2f((uint32_t)(key >> 32));
-      if (i + 1 < kk && (uint32_t)(sKeys[i + 1] >> 32) == (uint32_t)(key >> 32)) ++ties;
-    } else {
-      outIdx[o] = 0xffffffffu;
-      outDist[o] = __uint_as_float(0x7f800000u);
-      if (SHARDED) outPos[o] = 0xffffffffu;
+    }
+    if (!useRuns) {
+      uint32_t c2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) c2[u] = live[u] ? cid[sp[u]] : 0u;
+      if (SHARDED) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (live[u]) gp[u] = cpos[sp[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) sp[u] = c2[u];
+    }
+    uint32_t idv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) idv[u] = live[u] ? ids[sp[u]] : 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t i = lane + 64 * u;
+      if (i < k) {
+        const size_t o = (size_t)q * k + i;
+        outIdx[o] = idv[u];
+        outDist[o] = live[u] ? pqt_key2f(dk[u]) : __uint_as_float(0x7f800000u);
+        if (SHARDED) outPos[o] = gp[u];
+      }
     }
   }
   if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
@@ -2289,6 +2406,7 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtT
 //                      list overflowed at the sender (trailer count 0xffffffff) is appended to tvList and traversed here by the
 //                      list-mode traversal kernel.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_l1virt(const float* __restrict__ Q, const float* __restrict__ cb1, PqtDevParams prm,
                                                          float* __restrict__ qL1virt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // D + LP*C1 floats
@@ -2322,6 +2440,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_l1virt(const float* __restric
   __syncthreads();
   for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) qL1virt[(size_t)q * LP * C1 + t] = sV[t];
 }
+#endif  // PQT_MAIN_TU
 
 struct PqtResolveArgs {
   const unsigned long long* gbins; uint32_t gbinCap;  // [qn][gbinCap + 1], see PqtTravArgs
@@ -2421,10 +2540,12 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_resolve_bins(const PqtResolveAr
 }
 
 // marks every query of a pqt_traverse_bins request as "traverse it yourself" (shapes the fused traversal does not cover)
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_gbins_overflow(unsigned long long* __restrict__ gbins, uint32_t cap, uint32_t qn) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q < qn) gbins[(size_t)q * (cap + 1u) + cap] = 0xffffffffull;
 }
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // offline ("next" row 8f-3): E step of the reference's Lloyd iterations (productquantizer.hpp:40-66,
@@ -2432,6 +2553,7 @@ __global__ __launch_bounds__(256) void pqt_k_gbins_overflow(unsigned long long* 
 // summed left to right, first minimum wins (strict '<').  lane = one row; centroids staged in LDS.
 // rows (optional) selects/gathers the rows (group(), treequantizer.hpp:140-147).
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_kmeans_assign(
     const float* __restrict__ x, uint64_t n, uint32_t dim, uint32_t ld, const uint32_t* __restrict__ rows,
     const float* __restrict__ cen, uint32_t ncen, uint32_t cenLd, uint32_t* __restrict__ outAssign,
@@ -2452,6 +2574,7 @@ __global__ __launch_bounds__(256) void pqt_k_kmeans_assign(
   outAssign[i] = best;
   outDist[i] = bd;
 }
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // PMC calibration probe (MI355X_MICROARCH.md HBM: "calibrate on a known byte count in your own access pattern"):
@@ -2473,6 +2596,7 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restric
 
 // read-only streaming probe: every 16-byte piece of a buffer exactly once, four independent loads per lane in flight (the
 // access shape of the group-major rerank: 64 lanes = one contiguous KB).  bench.py reports its GB/s beside the nominal peak.
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_stream_read(const uint4* __restrict__ p, uint64_t n16, unsigned long long* __restrict__ sink) {
   const uint64_t stride = (uint64_t)gridDim.x * 256;
   uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -2484,6 +2608,7 @@ __global__ __launch_bounds__(256) void pqt_k_stream_read(const uint4* __restrict
   for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
 }
+#endif  // PQT_MAIN_TU
 
 // the same gather with ROWV lanes per row: lane c of a group reads piece c, so a row is one contiguous ROWV*16-byte access of
 // adjacent lanes instead of ROWV separate 16-byte accesses of one lane at 16-byte steps
@@ -2505,6 +2630,7 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather_coop(const uint4* __re
 // row per candidate, the id indirection disappears from the rerank chain, and the traversal emits positions
 // without touching ids[].  lane = one 16-byte (or 4-byte) piece of a row; writes coalesced, reads gathered.
 // ---------------------------------------------------------------------------------------------------
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_reorder_lines(const uint32_t* __restrict__ codes, uint64_t idBase, uint64_t nCodes,
                                                             const uint32_t* __restrict__ ids, uint64_t nIds, uint32_t LP,
                                                             uint32_t* __restrict__ out, unsigned long long* __restrict__ bad) {
@@ -2524,6 +2650,7 @@ __global__ __launch_bounds__(256) void pqt_k_reorder_lines(const uint32_t* __res
     out[pos * LP + v] = codes[r * LP + v];
   }
 }
+#endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
 // "next" row 8f-4: exact re-rank of the first k results against the raw database vectors
@@ -3114,6 +3241,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
 
 // opt-in "adc_bias" mode: bias[pos] = sum_p (l*l*c - l*c), c = coarse[p][A][B], of the row at position pos of the
 // bin-ordered store, summed in p order (f32, separate multiply and add).  lane = one row.
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_adc_bias(const uint32_t* __restrict__ codesBin, uint64_t nIds, const float* __restrict__ coarse,
                                                        PqtDevParams prm, float* __restrict__ bias) {
   const uint64_t pos = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -3129,8 +3257,10 @@ __global__ __launch_bounds__(256) void pqt_k_adc_bias(const uint32_t* __restrict
   }
   bias[pos] = s;
 }
+#endif  // PQT_MAIN_TU
 
 // group-major copy of the bin-ordered line store for pqt_k_rerank_select_wg: out[g][pos][x] = in[pos][g*G + x]
+#ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restrict__ in, uint64_t nIds, uint32_t LP, uint32_t G,
                                                           uint32_t* __restrict__ out) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // one word each; consecutive t -> consecutive output words
@@ -3138,3 +3268,4 @@ __global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restr
   const uint64_t g = t / (nIds * G), r = t % (nIds * G), pos = r / G, x = r % G;
   out[t] = in[pos * LP + g * G + x];
 }
+#endif  // PQT_MAIN_TU

@@ -1060,7 +1060,7 @@ def test_multi_handle_equals_single_index(name, nsh):
         Bv, Bb = BV_BB[name]
         q = torch.from_numpy(f.queries).cuda()
         qn = q.shape[0]
-        for k in (10, 100, 300):
+        for k in (10, 100, 300, 5000):  # 5000: nsh * k keys do not fit the LDS merge -> the ranked merge
             r_ids, r_d, r_c = ref.query(f.queries, Bv, Bb, k)
             for rep in (0, 1):
                 m.set_option("replicated_traversal", rep)
