@@ -306,7 +306,7 @@ class PqtIndex:
         n = _chk(self.L.pqt_get_rerank_launch_ms(self.h, _p(out, f32p), cap))
         return out[:n].copy()
 
-    def debug_read(self, qn, cands=True, segs=True):
+    def debug_read(self, qn, cands=True, segs=True, dists=True):
         stride = self.L.pqt_debug_stride(self.h)
         WC = self.W * self.C2
         l1 = np.zeros((qn, self.LP, self.C1), np.float32)
@@ -314,9 +314,9 @@ class PqtIndex:
         sb = np.zeros((qn, self.P, WC), np.uint32) if segs else None
         nc = np.zeros(qn, np.uint32)
         ci = np.zeros((qn, stride), np.uint32) if cands else None
-        cd = np.zeros((qn, stride), np.float32) if cands else None
+        cd = np.zeros((qn, stride), np.float32) if (cands and dists) else None
         _chk(self.L.pqt_debug_read(self.h, qn, _p(l1, f32p), _p(sd, f32p) if segs else None, _p(sb, u32p) if segs else None,
-                                   _p(ci, u32p) if cands else None, _p(cd, f32p) if cands else None, _p(nc, u32p)))
+                                   _p(ci, u32p) if cands else None, _p(cd, f32p) if (cands and dists) else None, _p(nc, u32p)))
         return dict(l1virt=l1, seg_d2=sd, seg_bin=sb, ncand=nc, cand_idx=ci, cand_dist=cd, stride=stride)
 
 

@@ -490,13 +490,13 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       // short lists (n <= 1024) first: wave-per-query evaluate + sort (pqt_k_rerank_sort_small); it hands the queries with longer
       // lists to the block-wide select kernel through fbList
       const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32);
-      const bool smallCL = coarseLds && coarseBytes + (size_t)8 * d.LP * d.C1 * 4 + 16 <= kMaxLds;
+      const bool smallCL = coarseLds && coarseBytes + (size_t)8 * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16 <= kMaxLds;
       usedSmallFirst = smallFirst;
       const uint32_t* bigQl = nullptr; const uint32_t* bigQc = nullptr;
       hipEvent_t bigEv0 = idx->lev0;
       if (smallFirst) {
         constexpr int SNW = 8;
-        const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * d.LP * d.C1 * 4 + 16;
+        const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16;
         HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
         PqtRsArgs sa{};
         sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;

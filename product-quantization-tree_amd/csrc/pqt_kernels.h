@@ -1200,6 +1200,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
               scv[p] = A.coarse[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
             }
           }
+          // all LP gathers are in flight here: keep the compiler from sinking each one next to its use (it did, to shorten live
+          // ranges under the kernel's register budget: one gather + s_waitcnt vmcnt(0) per term again)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
           float acc = 0.f;
 #pragma unroll
           for (int v = 0; v < LPV; ++v) {
@@ -3112,7 +3116,22 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
 // LDS: [coarse LP*C1*C1*4 when it fits] + NW * LP*C1*4 + 16 bytes.
 // ===================================================================================================
 #define PQT_RSS_MAXN 1024
-// (few instantiations on purpose -- the four sorting networks dominate the compile time: C1 and the sharded outputs are run-time)
+// sorts the 64*R keys at sKey (LDS, element e of the wave at sKey[e]) in place: blocked register layout for the network
+template <int R>
+__device__ __forceinline__ void pqt_wave_sort_lds(uint64_t* sKey) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t key[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) key[r] = sKey[lane * R + r];
+  pqt_wave_sort_u64<R>(key);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < R; ++r) sKey[lane * R + r] = key[r];
+}
+// (few instantiations on purpose -- the four sorting networks dominate the compile time: C1 and the sharded outputs are run-time.
+// Three phases per query so that nothing big is live across the network: keys -> LDS (rows of 4 candidates per lane in flight),
+// sort (R keys per lane in registers, nothing else), results read back from LDS in coalesced order.  The first version kept
+// keys, positions and rows in registers across all phases: 256 VGPRs + 2 KB of scratch per lane.)
 template <int NW, int LPV, bool COARSE_LDS>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsArgs A, uint32_t* __restrict__ bigList, uint32_t* __restrict__ bigCount) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -3124,94 +3143,15 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * LP * C1;
-  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * LP * C1 * 4);
+  uint64_t* sKey = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * PQT_RSS_MAXN;
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * PQT_RSS_MAXN * 8) + (size_t)wave * LP * C1;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * PQT_RSS_MAXN * 8 + (size_t)NW * LP * C1 * 4);
   if (threadIdx.x == 0) sTicket[0] = 0;
   if (COARSE_LDS) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = A.coarse[t];
   __syncthreads();
   const float* cz = COARSE_LDS ? sCoarse : A.coarse;
   const uint32_t G = gridDim.x, k = A.k;
   const uint32_t L = blockIdx.x < A.qn ? (A.qn - blockIdx.x + G - 1) / G : 0u;  // this workgroup's queries: b, b + G, ...
-
-  // candidate at store position pos: the reference's ADC sum
-  auto adc = [&](const uint4 (&row)[LPV]) -> float {
-    float acc = 0.f;
-#pragma unroll
-    for (int v = 0; v < LPV; ++v) {
-      const uint32_t w[4] = {row[v].x, row[v].y, row[v].z, row[v].w};
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const uint32_t p = v * 4 + x;
-        const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
-        const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
-        const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
-        const float sb = sVirt[pv + Aa], sa = sVirt[pv + Bb];
-        const float sc = cz[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
-        acc = acc + pqt_extract_distance(sa, sb, sc, lam);
-      }
-    }
-    return acc;
-  };
-  auto run = [&](auto rtag, const uint32_t q, const uint32_t n) {
-    constexpr int R = decltype(rtag)::value;
-    const uint32_t* cid = A.cand + (size_t)q * A.stride;
-    uint64_t key[R];
-    uint32_t pos[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { const uint32_t j = r * 64 + lane; pos[r] = j < n ? cid[j] : 0u; }
-    constexpr int U = R < 4 ? R : 4;  // candidates per lane whose rows are in flight together
-#pragma unroll
-    for (int r0 = 0; r0 < R; r0 += U) {
-      if ((uint32_t)r0 * 64u < n) {  // uniform
-        uint4 rows[U][LPV];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint4* row4 = reinterpret_cast<const uint4*>(A.codes + (size_t)pos[r0 + u] * LP);
-#pragma unroll
-          for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t j = (r0 + u) * 64 + lane;
-          const float acc = adc(rows[u]);
-          key[r0 + u] = j < n ? (((uint64_t)pqt_f2key(acc) << 32) | j) : ~0ull;
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) key[r0 + u] = ~0ull;
-      }
-    }
-    pqt_wave_sort_u64<R>(key);
-    // lane L holds the sorted elements [L*R, L*R + R)
-    const uint32_t kk = n < k ? n : k;
-    uint32_t ties = 0;
-    uint32_t jj[R], idv[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; jj[r] = (uint32_t)key[r]; idv[r] = e < kk ? cid[jj[r]] : 0u; }
-#pragma unroll
-    for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; idv[r] = e < kk ? A.ids[idv[r]] : 0xffffffffu; }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint32_t e = lane * R + r;
-      const size_t o = (size_t)q * k + e;
-      if (e < k) {
-        A.outIdx[o] = idv[r];
-        A.outDist[o] = e < kk ? pqt_key2f((uint32_t)(key[r] >> 32)) : __uint_as_float(0x7f800000u);
-        if (SHARDED) A.outPos[o] = e < kk ? A.candPos[(size_t)q * A.stride + jj[r]] : 0xffffffffu;
-      }
-      const uint32_t hi = (uint32_t)(key[r] >> 32);
-      const uint32_t nx = (r + 1 < R) ? (uint32_t)(key[(r + 1) % R] >> 32) : __shfl_down((uint32_t)(key[0] >> 32), 1, 64);
-      if (e + 1 < kk && hi == nx && !(r + 1 == R && lane == 63)) ++ties;
-    }
-    // padding beyond the 64*R sorted slots
-    for (uint32_t e = 64u * R + lane; e < k; e += 64) {
-      const size_t o = (size_t)q * k + e;
-      A.outIdx[o] = 0xffffffffu;
-      A.outDist[o] = __uint_as_float(0x7f800000u);
-      if (SHARDED) A.outPos[o] = 0xffffffffu;
-    }
-    if (__any(ties != 0)) { if (ties) atomicAdd(&A.counters[3], (unsigned long long)ties); }
-  };
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(sTicket, 1u);
@@ -3231,10 +3171,84 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
       for (uint32_t i = lane; i < LP * C1; i += 64) sVirt[i] = A.qL1virt[(size_t)q * LP * C1 + i];
     }
     __builtin_amdgcn_wave_barrier();
-    if (n <= 128) run(std::integral_constant<int, 2>{}, q, n);
-    else if (n <= 256) run(std::integral_constant<int, 4>{}, q, n);
-    else if (n <= 512) run(std::integral_constant<int, 8>{}, q, n);
-    else run(std::integral_constant<int, 16>{}, q, n);
+    const uint32_t* cid = A.cand + (size_t)q * A.stride;
+    // ---- phase 1: every candidate's key (reference association, p ascending: bit-exact) -> LDS
+    constexpr int U = 4;  // candidates per lane whose rows are in flight together
+    for (uint32_t base = 0; base < n; base += 64 * U) {
+      uint32_t pos[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const uint32_t j = base + u * 64 + lane; pos[u] = j < n ? cid[j] : 0u; }
+      uint4 rows[U][LPV];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint4* row4 = reinterpret_cast<const uint4*>(A.codes + (size_t)pos[u] * LP);
+#pragma unroll
+        for (int v = 0; v < LPV; ++v) rows[u][v] = row4[v];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t j = base + u * 64 + lane;
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < LPV; ++v) {
+          const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const uint32_t p = v * 4 + x;
+            const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+            const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
+            const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+            const float sb = sVirt[pv + Aa], sa = sVirt[pv + Bb];
+            const float sc = cz[C1P2 ? (((pv + Aa) << c1sh) + Bb) : ((pv + Aa) * C1 + Bb)];
+            acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+          }
+        }
+        if (j < n) sKey[j] = ((uint64_t)pqt_f2key(acc) << 32) | j;
+      }
+    }
+    // ---- phase 2: pad to the network size, sort
+    const uint32_t nSort = n <= 128 ? 128u : n <= 256 ? 256u : n <= 512 ? 512u : 1024u;
+    for (uint32_t e = n + lane; e < nSort; e += 64) sKey[e] = ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (nSort == 128) pqt_wave_sort_lds<2>(sKey);
+    else if (nSort == 256) pqt_wave_sort_lds<4>(sKey);
+    else if (nSort == 512) pqt_wave_sort_lds<8>(sKey);
+    else pqt_wave_sort_lds<16>(sKey);
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 3: results in coalesced order, 4 slots per lane in flight; padding behind them
+    const uint32_t kk = n < k ? n : k;
+    uint32_t ties = 0;
+    for (uint32_t i0 = 0; i0 < kk; i0 += 256) {
+      uint32_t jj[4], sp[4], gp[4], dk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * 64 + lane;
+        const uint64_t key = i < kk ? sKey[i] : 0ull;
+        jj[u] = (uint32_t)key; dk[u] = (uint32_t)(key >> 32);
+        if (i + 1 < kk && (uint32_t)(sKey[i + 1] >> 32) == dk[u]) ++ties;
+        sp[u] = i < kk ? cid[jj[u]] : 0u;
+        gp[u] = (SHARDED && i < kk) ? A.candPos[(size_t)q * A.stride + jj[u]] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; sp[u] = i < kk ? A.ids[sp[u]] : 0xffffffffu; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * 64 + lane;
+        if (i < kk) {
+          const size_t o = (size_t)q * k + i;
+          A.outIdx[o] = sp[u];
+          A.outDist[o] = pqt_key2f(dk[u]);
+          if (SHARDED) A.outPos[o] = gp[u];
+        }
+      }
+    }
+    for (uint32_t i = kk + lane; i < k; i += 64) {
+      const size_t o = (size_t)q * k + i;
+      A.outIdx[o] = 0xffffffffu;
+      A.outDist[o] = __uint_as_float(0x7f800000u);
+      if (SHARDED) A.outPos[o] = 0xffffffffu;
+    }
+    if (__any(ties != 0)) { if (ties) atomicAdd(&A.counters[3], (unsigned long long)ties); }
     __builtin_amdgcn_wave_barrier();
   }
 }

@@ -26,7 +26,7 @@ for bv, bb in ((20000, 500), (4096, 4096)):
     oi = torch.empty((NQ, 100), dtype=torch.int32, device=dev); od = torch.empty((NQ, 100), dtype=torch.float32, device=dev); oc = torch.empty(NQ, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     idx.query_dev(queries, bv, bb, 100, oi, od, oc, sync=True)
-    dbg = idx.debug_read(NQ, segs=False)
+    dbg = idx.debug_read(NQ, segs=False, dists=False)
     schemes = {"2,4,8": (2, 4, 8), "1,2,4,8": (1, 2, 4, 8), "4,8": (4, 8), "1,2,3,4,6,8": (1, 2, 3, 4, 6, 8), "2,8": (2, 8), "3,8": (3, 8)}
     acc = {k: [0.0, 0.0] for k in schemes}
     tot = 0

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r03
 export TMPDIR=/tmp
 make -C product-quantization-tree_amd/host > gpurun_out/r03/host_make.log 2>&1 || tail -20 gpurun_out/r03/host_make.log
-QN=2000 timeout 120 python scripts/r03_dbg_k4096.py > gpurun_out/r03/dbg_k4096_2000.log 2>&1; echo "dbg2000 rc $?"; tail -30 gpurun_out/r03/dbg_k4096_2000.log
+
 QN=10000 timeout 120 python scripts/r03_dbg_k4096.py > gpurun_out/r03/dbg_k4096.log 2>&1; echo "dbg10000 rc $?"; tail -30 gpurun_out/r03/dbg_k4096.log
 timeout 1500 python -m pytest tests -m gpu -q --maxfail=12 --durations=8 > gpurun_out/r03/pytest4.log 2>&1; echo "pytest rc $?" >> gpurun_out/r03/pytest4.log
 tail -30 gpurun_out/r03/pytest4.log | cut -c1-300
