@@ -500,13 +500,15 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
         PqtRsArgs sa{};
         sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;
-        sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr;
+        sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr; sa.dbg = idx->dbg & 15u; sa.nIds = idx->nIds;
         const uint32_t sgrid = std::min<uint32_t>((nq + SNW - 1) / SNW, (uint32_t)idx->numCUs);
-        if ((rc = launchSmallLists(idx, smallCL, lSmall, sgrid, st, sa, idx->lev0))) return rc;
+        if (!(idx->dbg & 32768u)) { if ((rc = launchSmallLists(idx, smallCL, lSmall, sgrid, st, sa, idx->lev0))) return rc; }  // (debug bit: bisecting)
         bigQl = idx->d_fbList; bigQc = idx->d_fbCount;
         bigEv0 = nullptr;
       }
+      if (!(smallFirst && (idx->dbg & 16384u))) {
       if ((rc = launchBigK(idx, bigCL, lBig, nq, st, v, idx->d_nLocal + q0, stride, k, kP2, kcap, oI, oD, oP, bigQl, bigQc, bigEv0, idx->lev1))) return rc;
+      }
       if (!leanEvents) PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)

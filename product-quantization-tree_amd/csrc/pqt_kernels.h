@@ -3159,10 +3159,11 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
     if (t >= L) break;
     const uint32_t q = blockIdx.x + t * G;
     const uint32_t n = A.nLocal[q];
+    // (no `continue` in this loop: with one, hipcc 7.2 emitted a self-branch spinning on the loop-invariant `n <= 1024` mask for
+    // the long-list path -- a hang on the first query with more than 1024 candidates)
     if (n > PQT_RSS_MAXN) {  // long list: the block-wide kernel takes it
       if (lane == 0) bigList[atomicAdd(bigCount, 1u)] = q;
-      continue;
-    }
+    } else {
     if ((LP * C1) % 4 == 0) {
       const float4* src4 = reinterpret_cast<const float4*>(A.qL1virt + (size_t)q * LP * C1);
       float4* dst4 = reinterpret_cast<float4*>(sVirt);
@@ -3174,10 +3175,12 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
     const uint32_t* cid = A.cand + (size_t)q * A.stride;
     // ---- phase 1: every candidate's key (reference association, p ascending: bit-exact) -> LDS
     constexpr int U = 4;  // candidates per lane whose rows are in flight together
+    if (A.dbg & 1u) { for (uint32_t j = lane; j < n; j += 64) sKey[j] = ((uint64_t)(n - j) << 32) | j; }
+    else
     for (uint32_t base = 0; base < n; base += 64 * U) {
       uint32_t pos[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) { const uint32_t j = base + u * 64 + lane; pos[u] = j < n ? cid[j] : 0u; }
+      for (int u = 0; u < U; ++u) { const uint32_t j = base + u * 64 + lane; pos[u] = j < n ? cid[j] : 0u; if ((A.dbg & 8u) && pos[u] >= A.nIds) pos[u] = 0; }
       uint4 rows[U][LPV];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -3210,7 +3213,8 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
     const uint32_t nSort = n <= 128 ? 128u : n <= 256 ? 256u : n <= 512 ? 512u : 1024u;
     for (uint32_t e = n + lane; e < nSort; e += 64) sKey[e] = ~0ull;
     __builtin_amdgcn_wave_barrier();
-    if (nSort == 128) pqt_wave_sort_lds<2>(sKey);
+    if (A.dbg & 2u) {}
+    else if (nSort == 128) pqt_wave_sort_lds<2>(sKey);
     else if (nSort == 256) pqt_wave_sort_lds<4>(sKey);
     else if (nSort == 512) pqt_wave_sort_lds<8>(sKey);
     else pqt_wave_sort_lds<16>(sKey);
@@ -3218,19 +3222,20 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
     // ---- phase 3: results in coalesced order, 4 slots per lane in flight; padding behind them
     const uint32_t kk = n < k ? n : k;
     uint32_t ties = 0;
-    for (uint32_t i0 = 0; i0 < kk; i0 += 256) {
+    for (uint32_t i0 = 0; i0 < ((A.dbg & 4u) ? 0u : kk); i0 += 256) {
       uint32_t jj[4], sp[4], gp[4], dk[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t i = i0 + u * 64 + lane;
         const uint64_t key = i < kk ? sKey[i] : 0ull;
         jj[u] = (uint32_t)key; dk[u] = (uint32_t)(key >> 32);
+        if ((A.dbg & 8u) && jj[u] >= n) jj[u] = 0;
         if (i + 1 < kk && (uint32_t)(sKey[i + 1] >> 32) == dk[u]) ++ties;
         sp[u] = i < kk ? cid[jj[u]] : 0u;
         gp[u] = (SHARDED && i < kk) ? A.candPos[(size_t)q * A.stride + jj[u]] : 0xffffffffu;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; sp[u] = i < kk ? A.ids[sp[u]] : 0xffffffffu; }
+      for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; if ((A.dbg & 8u) && sp[u] >= A.nIds) sp[u] = 0; sp[u] = i < kk ? A.ids[sp[u]] : 0xffffffffu; }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t i = i0 + u * 64 + lane;
@@ -3242,13 +3247,14 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
         }
       }
     }
-    for (uint32_t i = kk + lane; i < k; i += 64) {
+    for (uint32_t i = ((A.dbg & 4u) ? 0u : kk) + lane; i < k; i += 64) {
       const size_t o = (size_t)q * k + i;
       A.outIdx[o] = 0xffffffffu;
       A.outDist[o] = __uint_as_float(0x7f800000u);
       if (SHARDED) A.outPos[o] = 0xffffffffu;
     }
     if (__any(ties != 0)) { if (ties) atomicAdd(&A.counters[3], (unsigned long long)ties); }
+    }
     __builtin_amdgcn_wave_barrier();
   }
 }
