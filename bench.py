@@ -687,8 +687,11 @@ def main():
             print(json.dumps(out))
         return
     mode = "single" if (world == 1 and not ctx.force_shard) else ("replica" if args.replicas else "shard_db")
-    SWEEP_WL = "synth100m"  # the one workload of the strong-scaling sweep
-    wl_name = args.workload or ("sift1m" if mode != "shard_db" else ("synth1b" if world >= 8 else SWEEP_WL))
+    # the one workload of the strong-scaling sweep, and the headline of an 8-GPU run (PQT_BENCH_SWEEP_WL / PQT_BENCH_HEAD_WL: the test-suite
+    # walks the 8-GPU code path with two ranks and small stand-ins)
+    SWEEP_WL = os.environ.get("PQT_BENCH_SWEEP_WL", "synth100m")
+    head_wl = os.environ.get("PQT_BENCH_HEAD_WL") or ("synth1b" if world >= 8 else SWEEP_WL)
+    wl_name = args.workload or ("sift1m" if mode != "shard_db" else head_wl)
     W = build_workload(ctx, args, wl_name, mode)
     w, n, qn, idx, meta, queries, k = W["w"], W["n"], W["qn"], W["idx"], W["meta"], W["queries"], args.k
     R = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period)

@@ -397,14 +397,15 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
         // shard's table, and the (normally empty) list of queries whose list overflowed at the sender traversed here
         HIPCHK(hipMemsetAsync(idx->d_tvCount, 0, 4, st));
-        if ((rc = allowLds(pqt_k_l1virt, (size_t)(d.D + d.LP * d.C1) * 4))) return rc;
-        hipExtLaunchKernelGGL(pqt_k_l1virt, dim3(nq), dim3(PQT_BLOCK), (uint32_t)((d.D + d.LP * d.C1) * 4), st, idx->lev0, nullptr, 0u, q_dev + (size_t)q0 * d.D, idx->d_cb1, d,
-                              idx->d_qL1virt + (size_t)q0 * d.LP * d.C1);
         const PqtResolveArgs rargs{binsIn + (size_t)q0 * (binsCap + 1u), binsCap, idx->d_table, idx->d_lower, idx->tableBits, d.tableSeed, nq,
                                    idx->d_cand, idx->d_candPos, stride, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
                                    emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
                                    countDirect ? outCount + q0 : nullptr, idx->d_tvList, idx->d_tvCount, schedCntArg, idx->d_schedList, idx->curSchedCap};
-        hipLaunchKernelGGL(pqt_k_resolve_bins<4>, dim3((nq + 3) / 4), dim3(256), 0, st, rargs);
+        const size_t lTR = (size_t)(PQT_L1V_QB * d.D + d.LP * d.C1) * 4;
+        if ((rc = allowLds(pqt_k_tables_resolve<4>, lTR))) return rc;
+        const uint32_t nResolve = (nq + 3) / 4, nTab = (nq + PQT_L1V_QB - 1) / PQT_L1V_QB;
+        hipExtLaunchKernelGGL(pqt_k_tables_resolve<4>, dim3(nResolve + nTab), dim3(PQT_BLOCK), (uint32_t)lTR, st, idx->lev0, nullptr, 0u, rargs, nTab,
+                              q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb1L, d, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1);
         targs.qlist = idx->d_tvList; targs.qcount = idx->d_tvCount;
         launchFusedTraversal(idx, targs, tplan, nq, st, nullptr, idx->lev1);
       } else {
@@ -629,7 +630,7 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {idx->d_cb1, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
+  void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -685,6 +686,14 @@ int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) 
   if ((rc = devAlloc(&idx->d_coarse, nc))) return rc;
   HIPCHK(hipMemcpy(idx->d_cb1, cb1, n1 * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(idx->d_cb2, cb2, n2 * 4, hipMemcpyHostToDevice));
+  {  // line-part-major copy [lp][c][SS] for the table kernel of the bins-in path (pqt_l1virt_block)
+    std::vector<float> t(n1);
+    for (uint32_t lp = 0; lp < d.LP; ++lp)
+      for (uint32_t c = 0; c < d.C1; ++c)
+        for (uint32_t e = 0; e < d.SS; ++e) t[((size_t)lp * d.C1 + c) * d.SS + e] = cb1[(size_t)c * d.D + lp * d.SS + e];
+    if ((rc = devAlloc(&idx->d_cb1L, n1))) return rc;
+    HIPCHK(hipMemcpy(idx->d_cb1L, t.data(), n1 * 4, hipMemcpyHostToDevice));
+  }
   if (idx->d_cb2T) { (void)hipFree(idx->d_cb2T); idx->d_cb2T = nullptr; }
   if (d.S % 4 == 0) {
     std::vector<float> t(n2);

@@ -55,6 +55,7 @@ struct pqt_index {
   hipStream_t stream = nullptr;
   // tree
   float* d_cb1 = nullptr; float* d_cb2 = nullptr; float* d_coarse = nullptr;
+  float* d_cb1L = nullptr;  // cb1 line-part-major [LP][C1][SS] (coalesced reads of the table kernel)
   float* d_cb2T = nullptr;  // cb2 re-tiled per cell as [S/4][C2] 16-byte vectors (coalesced row walks), when S % 4 == 0
   bool haveTree = false;
   // heuristic prefix (a3)

@@ -2113,7 +2113,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       const uint4* table4 = reinterpret_cast<const uint4*>(table);
       if (A.gbins) {
         // query-sharded traversal: the included populated bins as (bin id, global start) in visiting order; every shard resolves
-        // its own members from its own table (pqt_k_resolve_bins)
+        // its own members from its own table (pqt_k_tables_resolve)
         uint32_t kv[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) kv[r] = g8[r] ? table4[ls8[r]].x : 0u;
@@ -2402,49 +2402,94 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtT
 // ---------------------------------------------------------------------------------------------------
 // Query-sharded traversal, receiving side (pqt_query_shard_bins).  The traversal of a query ran on ANOTHER shard
 // (pqt_traverse_bins) and arrives as its list of included populated bins (bin id | global start << 32, visiting order).
-//   pqt_k_l1virt       a1 only: L1virt[lp][c] of every query (the rerank's distance table), same sums as the traversal.
-//   pqt_k_resolve_bins one wavefront per query: looks every listed bin up in THIS shard's table (local start, local members,
+//   pqt_l1virt_block   a1 only: L1virt[lp][c] of every query (the rerank's distance table), same sums as the traversal.
+//   pqt_resolve_block  one wavefront per query: looks every listed bin up in THIS shard's table (local start, local members,
 //                      members on lower shards), scans the local populations, and leaves exactly what the SHARDED traversal's
 //                      finish step leaves -- bin runs (first local visiting position | first store row << 32, global position of
 //                      the first local member) or the expanded candidate list, nLocal, the schedule registration.  A query whose
 //                      list overflowed at the sender (trailer count 0xffffffff) is appended to tvList and traversed here by the
 //                      list-mode traversal kernel.
 // ---------------------------------------------------------------------------------------------------
-#ifdef PQT_MAIN_TU
-__global__ __launch_bounds__(PQT_BLOCK) void pqt_k_l1virt(const float* __restrict__ Q, const float* __restrict__ cb1, PqtDevParams prm,
-                                                         float* __restrict__ qL1virt) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // D + LP*C1 floats
-  const uint32_t D = prm.D, C1 = prm.C1, LP = prm.LP, SS = prm.SS;
-  float* sQ = smem;
-  float* sV = smem + D;
-  const uint32_t q = blockIdx.x, tid = threadIdx.x;
-  for (uint32_t i = tid; i < D; i += PQT_BLOCK) sQ[i] = Q[(size_t)q * D + i];
-  __syncthreads();
-  // t = c*LP + lp walks cb1 contiguously (consecutive lanes read consecutive SS-float segments of one centroid row: the first
-  // version indexed by (lp, c) and touched one cache line per lane -- 0.15 ms per 10 k queries, bound by the texture addresser);
-  // the (lp, c) transpose happens in LDS, the table leaves in coalesced stores
-  for (uint32_t t = tid; t < C1 * LP; t += PQT_BLOCK) {
-    const uint32_t c = t / LP, lp = t % LP;
-    const float* cen = cb1 + (size_t)c * D + lp * SS;
-    const float* qq = sQ + lp * SS;
-    float s = 0.f;
-    if ((SS & 3u) == 0) {
-      for (uint32_t d = 0; d < SS; d += 4) {
-        const float4 cv = *reinterpret_cast<const float4*>(cen + d);
-        float df = qq[d] - cv.x; s = s + df * df;
-        df = qq[d + 1] - cv.y; s = s + df * df;
-        df = qq[d + 2] - cv.z; s = s + df * df;
-        df = qq[d + 3] - cv.w; s = s + df * df;
-      }
-    } else {
-      for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+// a1 for QB queries per workgroup (the distance table L1virt[lp][c] of the rerank, same sums as the traversal).
+// 4-dim line parts (configs[2]/[3]): a thread owns 2 x 4 consecutive table entries, keeps their centroid pieces (read coalesced from
+// the line-part-major copy cb1L[lp][c][4]) in registers across the QB queries and stores float4 results straight to HBM -- no LDS
+// transpose, no barrier in the loop.  History of this kernel per 10 k queries: (lp, c)-indexed reads of the row-major codebook 0.15 ms
+// (one cache line per lane: texture addresser); LDS transpose per query 0.045 ms, of which 0.035 the LDS pipe (8-way conflicting
+// ds_write_b32 + one ds_read_b128 per entry), measured by skipping the compute / the stores in turn; now the 80 MB of stores bound it.
+// Other shapes: one query at a time through an LDS transpose, reading the row-major codebook contiguously (t = c*LP + lp).
+template <int QB>
+__device__ __forceinline__ void pqt_l1virt_block(const float* __restrict__ Q, const float* __restrict__ cb1, const float* __restrict__ cb1L,
+                                                 const PqtDevParams& prm, float* __restrict__ qL1virt, uint32_t qn, uint32_t blk, float* smem) {
+  const uint32_t D = prm.D, C1 = prm.C1, LP = prm.LP, SS = prm.SS, N = LP * C1;
+  float* sQ = smem;            // QB * D
+  float* sV = smem + QB * D;   // N (generic path)
+  const uint32_t q0 = blk * QB, tid = threadIdx.x;
+  if (q0 >= qn) return;
+  const uint32_t nq = qn - q0 < (uint32_t)QB ? qn - q0 : (uint32_t)QB;
+  for (uint32_t i = tid; i < nq * D; i += PQT_BLOCK) sQ[i] = Q[(size_t)q0 * D + i];
+  if (cb1L && SS == 4 && (C1 & 3u) == 0 && N <= 8 * PQT_BLOCK) {
+    float4 cv[2][4];
+    uint32_t qo[2];
+    bool on[2];
+#pragma unroll
+    for (uint32_t i = 0; i < 2; ++i) {
+      const uint32_t t0 = (tid + i * PQT_BLOCK) * 4;
+      on[i] = t0 < N;
+      const uint32_t tt = on[i] ? t0 : 0u;
+      qo[i] = (tt / C1) * 4;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) cv[i][j] = reinterpret_cast<const float4*>(cb1L)[tt + j];
     }
-    sV[lp * C1 + c] = s;
+    __syncthreads();
+    for (uint32_t qi = 0; qi < nq; ++qi) {
+      float* outq = qL1virt + (size_t)(q0 + qi) * N;
+#pragma unroll
+      for (uint32_t i = 0; i < 2; ++i) {
+        if (on[i]) {
+          const float4 qq = *reinterpret_cast<const float4*>(sQ + qi * D + qo[i]);
+          float r[4];
+#pragma unroll
+          for (uint32_t j = 0; j < 4; ++j) {
+            float s = 0.f;
+            float df = qq.x - cv[i][j].x; s = s + df * df;
+            df = qq.y - cv[i][j].y; s = s + df * df;
+            df = qq.z - cv[i][j].z; s = s + df * df;
+            df = qq.w - cv[i][j].w; s = s + df * df;
+            r[j] = s;
+          }
+          *reinterpret_cast<float4*>(outq + (tid + i * PQT_BLOCK) * 4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    }
+    return;
   }
-  __syncthreads();
-  for (uint32_t t = tid; t < LP * C1; t += PQT_BLOCK) qL1virt[(size_t)q * LP * C1 + t] = sV[t];
+  for (uint32_t qi = 0; qi < nq; ++qi) {
+    const float* qv = sQ + qi * D;
+    __syncthreads();  // sQ staged / the previous query's table read out
+    for (uint32_t t = tid; t < N; t += PQT_BLOCK) {
+      const uint32_t c = t / LP, lp = t % LP;
+      const float* cen = cb1 + (size_t)c * D + lp * SS;
+      const float* qq = qv + lp * SS;
+      float s = 0.f;
+      if ((SS & 3u) == 0) {
+        for (uint32_t d = 0; d < SS; d += 4) {
+          const float4 c4 = *reinterpret_cast<const float4*>(cen + d);
+          float df = qq[d] - c4.x; s = s + df * df;
+          df = qq[d + 1] - c4.y; s = s + df * df;
+          df = qq[d + 2] - c4.z; s = s + df * df;
+          df = qq[d + 3] - c4.w; s = s + df * df;
+        }
+      } else {
+        for (uint32_t d = 0; d < SS; ++d) { const float df = qq[d] - cen[d]; s = s + df * df; }
+      }
+      sV[lp * C1 + c] = s;
+    }
+    __syncthreads();
+    float* outq = qL1virt + (size_t)(q0 + qi) * N;
+    for (uint32_t t = tid; t < N; t += PQT_BLOCK) outq[t] = sV[t];
+  }
 }
-#endif  // PQT_MAIN_TU
+#define PQT_L1V_QB 8
 
 struct PqtResolveArgs {
   const unsigned long long* gbins; uint32_t gbinCap;  // [qn][gbinCap + 1], see PqtTravArgs
@@ -2457,13 +2502,13 @@ struct PqtResolveArgs {
   uint32_t* tvList; uint32_t* tvCount;
   uint32_t* schedCnt; unsigned long long* schedList; uint32_t schedCap;
 };
-#define PQT_GBIN_MAX 128  // largest per-query list pqt_k_resolve_bins accepts (2 entries per lane)
+#define PQT_GBIN_MAX 128  // largest per-query list pqt_resolve_block accepts (2 entries per lane)
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void pqt_k_resolve_bins(const PqtResolveArgs A) {
+__device__ __forceinline__ void pqt_resolve_block(const PqtResolveArgs& A, uint32_t blk) {
   __shared__ unsigned long long sBinAll[NW][PQT_GBIN_MAX];
   __shared__ uint32_t sGposAll[NW][PQT_GBIN_MAX];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint32_t q = blockIdx.x * NW + wave;
+  const uint32_t q = blk * NW + wave;
   if (q >= A.qn) return;
   unsigned long long* const sBin = sBinAll[wave];
   uint32_t* const sGpos = sGposAll[wave];
@@ -2541,6 +2586,18 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_resolve_bins(const PqtResolveAr
       outP[j] = sGpos[lo] + off;
     }
   }
+}
+// one launch for both halves of the receiving side: the first nTab workgroups compute the distance tables (store-bound, fewer than the
+// chip holds at once), the rest resolve the bin lists (latency chains: table look-up, scans, run write-out) and start beside them --
+// two independent jobs that used to queue behind each other
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void pqt_k_tables_resolve(const PqtResolveArgs A, uint32_t nTab, const float* __restrict__ Q,
+                                                                 const float* __restrict__ cb1, const float* __restrict__ cb1L,
+                                                                 const PqtDevParams prm, float* __restrict__ qL1virt) {
+  static_assert(NW * 64 == PQT_BLOCK, "the table half strides by PQT_BLOCK");
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // PQT_L1V_QB * D + LP * C1 floats
+  if (blockIdx.x < nTab) pqt_l1virt_block<PQT_L1V_QB>(Q, cb1, cb1L, prm, qL1virt, A.qn, blockIdx.x, smem);
+  else pqt_resolve_block<NW>(A, blockIdx.x - nTab);
 }
 
 // marks every query of a pqt_traverse_bins request as "traverse it yourself" (shapes the fused traversal does not cover)

@@ -71,3 +71,22 @@ def test_default_line_carries_the_hbm_roofline_leg():
         e = leg[knobs]
         assert e["queries_per_sec"] > 0 and 0 < e["roofline"]["frac"] < 1 and e["roofline"]["kernel"].startswith("pqt_k_")
         assert "rerank=mode2" in e["kernel_path"] and e["filter_fallbacks"] == 0
+
+
+def test_eight_gpu_default_code_path_with_two_ranks_and_small_stand_ins():
+    """`--gpus 8` (no --workload): `value` is the big configuration and the sweep's workload rides beside it as config.strong_scaling_leg
+    with its own one-GPU denominator.  The same code path with two gloo ranks on one device and small stand-in workloads."""
+    env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1", MASTER_ADDR="127.0.0.1", PQT_BENCH_HEAD_WL="synth10m", PQT_BENCH_SWEEP_WL="synth1m")
+    port = 30300 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert c["workload_name"] == "synth10m" and d["scaling"] == "strong" and c["ranks_agree"] is True
+    leg = c["strong_scaling_leg"]
+    assert "N=1000000" in leg["workload"] and leg["ranks_agree"] is True
+    assert leg["same_workload_1gpu"]["results_identical_to_sharded"] is True
+    assert d["scaling_vs_1gpu"] == leg["same_workload_1gpu"]["speedup_of_this_run"] > 0
+    assert "strong_scaling_leg" in d["scaling_vs_1gpu_what"]
