@@ -151,6 +151,7 @@ size_t ldsEncode(const PqtDevParams& d) {
 
 // permute the line store into bin order (see pqt_k_reorder_lines); afterwards the id-ordered copy is dropped if owned
 int reorderLines(pqt_index* idx) {
+  if (idx->isView) return fail(PQT_ERR_STATE, "view handle asked to rebuild shared data (line store)");
   int rc = setDevice(idx);
   if (rc) return rc;
   const uint32_t LP = idx->dp.LP;
@@ -177,6 +178,7 @@ int reorderLines(pqt_index* idx) {
 }  // namespace
 int ensureGroupMajor(pqt_index* idx, int G) {
   if (idx->d_codesGrp && idx->grpG == G) return PQT_OK;
+  if (idx->isView) return fail(PQT_ERR_STATE, "view handle asked to rebuild shared data (group-major store)");
   int rc;
   const size_t words = (size_t)idx->nIds * idx->dp.LP;
   if ((rc = devAlloc(&idx->d_codesGrp, words))) return rc;
@@ -192,6 +194,7 @@ namespace {
 // opt-in adc_bias mode: bias[pos] of every row of the bin-ordered store (once per index / line store)
 int ensureBias(pqt_index* idx) {
   if (idx->biasReady) return PQT_OK;
+  if (idx->isView) return fail(PQT_ERR_STATE, "view handle asked to rebuild shared data (row bias)");
   int rc;
   if ((rc = devAlloc(&idx->d_bias, (size_t)idx->nIds))) return rc;
   if (idx->nIds) hipLaunchKernelGGL(pqt_k_adc_bias, dim3((unsigned)((idx->nIds + 255) / 256)), dim3(256), 0, idx->stream, idx->d_codesBin, (uint64_t)idx->nIds,
@@ -544,7 +547,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->ctrPos = (idx->ctrPos + 1) % kCtrRing;
   if (outCount && !countDirect) HIPCHK(hipMemcpyAsync(outCount, idx->d_nCand, (size_t)qn * 4, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipGetLastError());
-  idx->lastQn = qn; idx->lastHe = He;
+  idx->lastQn = qn; idx->lastHe = He; idx->lastPieces = 0;
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
   idx->lastFilter = useFilter || usedSmallFirst;  // (pqt_stats.filter_fallbacks then counts the queries the short-list kernel handed to the block-wide one)
   idx->lastRuns = emitRuns;
@@ -630,6 +633,13 @@ void pqt_index_destroy(pqt_index* idx) {
   if (!idx) return;
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
+  for (auto& v : idx->views) if (v) { pqt_index_destroy(v); v = nullptr; }
+  if (idx->evFork) (void)hipEventDestroy(idx->evFork);
+  for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
+  if (idx->isView) {  // the arrays of the index belong to the owner
+    idx->d_cb1 = idx->d_cb2 = idx->d_coarse = idx->d_cb1L = idx->d_cb2T = nullptr; idx->d_heur = idx->d_heur8 = nullptr; idx->d_heur4 = nullptr;
+    idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_filter = nullptr; idx->d_bias = nullptr;
+  }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
@@ -662,6 +672,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: -1 automatic, 0 never, 1 whenever possible, 2..4 = that many pieces
   if (strcmp(name, "small_lists") == 0) { idx->smallLists = (value != 0); return PQT_OK; }  // 0: every query of a 128 < k <= 4096 call through the block-wide select kernel
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
@@ -997,16 +1008,135 @@ int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, 
   return PQT_OK;
 }
 
+
+// ---- overlapped halves ------------------------------------------------------------------------------------------------
+// Everything a query call READS of an index (arrays, their sizes, flags, options); a view handle carries copies of these
+// words and owns only scratch.  Compared before/after the first half to see whether that call built something lazily
+// (bin-ordered store, group-major copy, row bias): the view's stream must then wait for it.
+namespace {
+struct SharedWords {
+  PqtDevParams dp; pqt_params prm;
+  const void* p[20]; uint64_t u[8]; uint32_t w[8]; float f[2]; int i[10]; bool b[12];
+};
+void captureShared(const pqt_index* x, SharedWords& v) {
+  memset(&v, 0, sizeof(v));
+  v.dp = x->dp; v.prm = x->prm;
+  const void* ps[] = {x->d_cb1, x->d_cb2, x->d_coarse, x->d_cb1L, x->d_cb2T, x->d_heur, x->d_heur8, x->d_heur4, x->d_table, x->d_lower, x->d_ids,
+                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter};
+  for (size_t j = 0; j < sizeof(ps) / sizeof(ps[0]); ++j) v.p[j] = ps[j];
+  v.u[0] = x->heurRows; v.u[1] = x->maxMultiIndex; v.u[2] = x->nIds; v.u[3] = x->nTotal; v.u[4] = x->nCodes; v.u[5] = x->idBase; v.u[6] = x->scratchBudget;
+  v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg;
+  v.f[0] = x->coarseMax;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance;
+  const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
+                     x->forceUnfused, x->useWgRerank, x->noShape};
+  for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
+}
+void applyShared(pqt_index* t, const SharedWords& v) {
+  t->dp = v.dp; t->prm = v.prm;
+  t->d_cb1 = (float*)v.p[0]; t->d_cb2 = (float*)v.p[1]; t->d_coarse = (float*)v.p[2]; t->d_cb1L = (float*)v.p[3]; t->d_cb2T = (float*)v.p[4];
+  t->d_heur = (uint16_t*)v.p[5]; t->d_heur8 = (uint16_t*)v.p[6]; t->d_heur4 = (uint32_t*)v.p[7];
+  t->d_table = (PqtBinEntry*)v.p[8]; t->d_lower = (uint32_t*)v.p[9]; t->d_ids = (uint32_t*)v.p[10];
+  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15];
+  t->codesOwned = false;
+  t->heurRows = v.u[0]; t->maxMultiIndex = v.u[1]; t->nIds = v.u[2]; t->nTotal = v.u[3]; t->nCodes = v.u[4]; t->idBase = v.u[5]; t->scratchBudget = (size_t)v.u[6];
+  t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3];
+  t->coarseMax = v.f[0];
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3];
+  t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
+  t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11];
+  t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
+}
+
+// split when the two launches of a batch leave gaps worth filling: a large batch, the wave-per-query rerank, a line store that stays
+// in the Infinity Cache (with an HBM-resident store the rerank is 95 % of the step and two half-size launches balance worse than one)
+bool overlapWanted(const pqt_index* idx, uint32_t qn, uint32_t k) {
+  if (!idx || idx->isView || idx->overlap == 0 || idx->d_tstamp || (idx->dbg & 0xffffu) || k > PQT_RS_BEST || qn < 2) return false;
+  if (!idx->haveTree || !idx->haveBins || !(idx->d_codes || idx->binOrdered) || !idx->d_heur) return false;  // (queryImpl reports it)
+  if (idx->stageTiming > 0 && (idx->timingPhase % (unsigned long long)idx->stageTiming) == 0) return false;      // the next call is a timed one
+  if (idx->overlap >= 1) return true;
+  return qn >= 4096 && (size_t)idx->nIds * idx->dp.LP * 4 <= ((size_t)256 << 20);
+}
+
+int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx, float* outDist,
+             uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
+  if (!overlapWanted(idx, qn, k)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync);
+  if (!q_dev || !outIdx || !outDist || (idx->sharded && !outPos)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync);
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  // pieces and their shares.  Each piece's persistent rerank launch takes 1/P of the workgroup slots so that all launches are
+  // resident together (full-size grids queue behind each other on the LDS: 4 % slower than one piece instead of 13 % faster at the
+  // SIFT1M shape); the first piece starts first and gets a slightly larger share of the queries
+  static const int envPieces = getenv("PQT_OVERLAP_PIECES") ? atoi(getenv("PQT_OVERLAP_PIECES")) : 0;
+  static const int envFirst = getenv("PQT_OVERLAP_FIRST_PCT") ? atoi(getenv("PQT_OVERLAP_FIRST_PCT")) : 0;
+  uint32_t P = idx->overlap >= 2 ? (uint32_t)idx->overlap : (envPieces >= 2 ? (uint32_t)envPieces : 2u);
+  P = std::min<uint32_t>(std::min<uint32_t>(P, (uint32_t)pqt_index::kMaxViews + 1u), qn);
+  for (uint32_t i = 0; i + 1 < P; ++i) {
+    if (idx->views[i]) continue;
+    pqt_index* t = nullptr;
+    if ((rc = pqt_index_create(&idx->prm, idx->device, &t))) return rc;
+    t->isView = true; t->owner = idx; idx->views[i] = t;
+    HIPCHK(hipEventCreateWithFlags(&idx->evJoin[i], hipEventDisableTiming));
+  }
+  if (!idx->evFork) HIPCHK(hipEventCreateWithFlags(&idx->evFork, hipEventDisableTiming));
+  if (!st) st = idx->stream;
+  if (idx->stageTiming > 0) idx->timingPhase++;  // this call's turn in the every-N-th-call rhythm (the pieces are never timed)
+  const int keepTiming = idx->stageTiming, keepCUs = idx->numCUs;
+  const size_t D = idx->dp.D;
+  uint32_t start[pqt_index::kMaxViews + 2] = {0};
+  {
+    const uint32_t firstPct = envFirst > 0 ? (uint32_t)envFirst : (100u / P + (P == 2 ? 6u : 4u));
+    uint32_t first = (uint32_t)(((uint64_t)qn * firstPct + 99) / 100);
+    first = std::max<uint32_t>(1u, std::min<uint32_t>(first, qn - (P - 1)));
+    start[1] = first;
+    for (uint32_t i = 2; i <= P; ++i) start[i] = first + (uint32_t)(((uint64_t)(qn - first) * (i - 1)) / (P - 1));
+  }
+  const int share = std::max(1, keepCUs / (int)P);
+  SharedWords s0, s1;
+  idx->numCUs = share;
+  captureShared(idx, s0);
+  HIPCHK(hipEventRecord(idx->evFork, st));
+  for (uint32_t i = 0; i + 1 < P; ++i) HIPCHK(hipStreamWaitEvent(idx->views[i]->stream, idx->evFork, 0));
+  idx->stageTiming = 0;
+  rc = queryImpl(idx, q_dev, start[1], Bv, Bb, k, outIdx, outDist, outPos, outCount, st, 0);
+  idx->stageTiming = keepTiming;
+  captureShared(idx, s1);
+  idx->numCUs = keepCUs;
+  if (rc) return rc;
+  if (memcmp(&s0, &s1, sizeof(s0)) != 0) {  // built lazily on `st` by the first piece: visible to the views' streams from here
+    HIPCHK(hipEventRecord(idx->evFork, st));
+    for (uint32_t i = 0; i + 1 < P; ++i) HIPCHK(hipStreamWaitEvent(idx->views[i]->stream, idx->evFork, 0));
+  }
+  int rcPiece = PQT_OK;
+  for (uint32_t i = 1; i < P; ++i) {
+    pqt_index* const v = idx->views[i - 1];
+    applyShared(v, s1);
+    const uint32_t a = start[i], n = start[i + 1] - start[i];
+    const int r2 = queryImpl(v, q_dev + (size_t)a * D, n, Bv, Bb, k, outIdx + (size_t)a * k, outDist + (size_t)a * k,
+                             outPos ? outPos + (size_t)a * k : nullptr, outCount ? outCount + a : nullptr, v->stream, 0);
+    if (r2 && !rcPiece) rcPiece = r2;
+    HIPCHK(hipEventRecord(idx->evJoin[i - 1], v->stream));
+    HIPCHK(hipStreamWaitEvent(st, idx->evJoin[i - 1], 0));
+  }
+  if (rcPiece) return rcPiece;
+  idx->lastPieces = P;
+  for (uint32_t i = 0; i <= P; ++i) idx->pieceStart[i] = start[i];
+  idx->lastPath += " overlap=" + std::to_string(P) + "-pieces";
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+}  // namespace
+
 int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
               float* outDist, uint32_t* outCount, void* stream, int sync) {
   if (idx && idx->sharded) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard + pqt_merge_topk");
-  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, nullptr, outCount, (hipStream_t)stream, sync);
+  return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, nullptr, outCount, (hipStream_t)stream, sync);
 }
 
 int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
                     float* outDist, uint32_t* outPos, uint32_t* outCount, void* stream, int sync) {
   if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard");
-  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync);
+  return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync);
 }
 
 int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t cap,
@@ -1125,6 +1255,20 @@ uint64_t pqt_debug_stride(const pqt_index* idx) { return idx ? idx->stride : 0; 
 int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd, uint32_t* segbin, uint32_t* candIdx,
                    float* candDist, uint32_t* ncand) {
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  if (idx->lastPieces > 1 && qn > idx->pieceStart[1]) {  // overlapped call: the later pieces' scratch lives in the view handles
+    const PqtDevParams& dd = idx->dp;
+    if (qn > idx->pieceStart[idx->lastPieces]) return fail(PQT_ERR_STATE, "no such batch held");
+    for (uint32_t i = 0; i < idx->lastPieces && idx->pieceStart[i] < qn; ++i) {
+      const pqt_index* h = i == 0 ? idx : idx->views[i - 1];
+      const uint32_t a = idx->pieceStart[i], n = std::min<uint32_t>(qn, idx->pieceStart[i + 1]) - a;
+      if (h->stride != idx->stride) return fail(PQT_ERR_STATE, "the pieces of the last call used different candidate strides");
+      const int rc2 = pqt_debug_read(h, n, l1virt ? l1virt + (size_t)a * dd.LP * dd.C1 : nullptr, segd ? segd + (size_t)a * dd.P * dd.WC : nullptr,
+                                     segbin ? segbin + (size_t)a * dd.P * dd.WC : nullptr, candIdx ? candIdx + (size_t)a * idx->stride : nullptr,
+                                     candDist ? candDist + (size_t)a * idx->stride : nullptr, ncand ? ncand + a : nullptr);
+      if (rc2) return rc2;
+    }
+    return PQT_OK;
+  }
   if (qn > idx->lastQn) return fail(PQT_ERR_STATE, "no such batch held");
   if (idx->nChunks > 1 && (candIdx || candDist)) return fail(PQT_ERR_STATE, "last batch ran in several chunks; candidates of earlier chunks are gone");
   if ((segd || segbin) && !idx->lastSegKept)
@@ -1247,6 +1391,21 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
     for (uint32_t v : nl) s.candidates += v;
     for (uint32_t v : ni) s.bins_nonempty += v;
     s.bins_visited = (uint64_t)idx->lastHe * idx->lastQn;
+  }
+  for (uint32_t pi = 1; pi < idx->lastPieces; ++pi) {  // the later pieces of an overlapped call ran on the view handles
+    const pqt_index* tw = idx->views[pi - 1];
+    unsigned long long c2[8] = {0};
+    HIPCHK(hipMemcpy(c2, tw->ctr ? tw->ctr : tw->d_counters, sizeof(c2), hipMemcpyDeviceToHost));
+    s.queries += tw->lastQn; s.ties_l1 += c2[0]; s.ties_l2 += c2[1]; s.ties_bins += c2[2]; s.ties_final += c2[3];
+    if (tw->lastFilter && tw->d_fbCount) { uint32_t fb = 0; HIPCHK(hipMemcpy(&fb, tw->d_fbCount, 4, hipMemcpyDeviceToHost)); s.filter_fallbacks += fb; }
+    std::vector<uint32_t> nl(tw->lastQn), ni(tw->lastQn);
+    if (tw->lastQn) {
+      HIPCHK(hipMemcpy(nl.data(), tw->d_nLocal, (size_t)tw->lastQn * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ni.data(), tw->d_nIncl, (size_t)tw->lastQn * 4, hipMemcpyDeviceToHost));
+    }
+    for (uint32_t v : nl) s.candidates += v;
+    for (uint32_t v : ni) s.bins_nonempty += v;
+    s.bins_visited += (uint64_t)tw->lastHe * tw->lastQn;
   }
   // stage times: those of the last call when it carried events, else of the most recent call that did (stage_timing = N > 1)
   int lastEv = -1;

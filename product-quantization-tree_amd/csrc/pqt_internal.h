@@ -97,6 +97,13 @@ struct pqt_index {
   size_t scratchBudget = (size_t)24 << 30;
   // persistent staging buffers of the host-pointer entry point (pqt_query_host): grown on demand, never freed per call
   float* h2dQ = nullptr; uint32_t* h2dI = nullptr; float* h2dD = nullptr; uint32_t* h2dC = nullptr; size_t h2dQCap = 0, h2dKCap = 0, h2dCCap = 0;
+  // overlapped halves (pqt_index_set_option "overlap"): a view handle shares every read-only array of this index and owns its own
+  // scratch, stream and counters; a large batch is split in pieces that run on their own streams, each rerank launch on its share of the workgroup
+  // slots, so that one piece's (latency-bound) traversal and the tail of its rerank launch fill the gaps of the others'
+  static constexpr int kMaxViews = 3;
+  pqt_index* views[kMaxViews] = {nullptr, nullptr, nullptr}; pqt_index* owner = nullptr; bool isView = false; int overlap = -1 /* -1 auto, 0 off, 1 on, n >= 2: n pieces */;
+  hipEvent_t evFork = nullptr, evJoin[kMaxViews] = {nullptr, nullptr, nullptr};
+  uint32_t lastPieces = 0, pieceStart[kMaxViews + 2] = {0, 0, 0, 0, 0};  // last call: pieces (0: one piece on this handle); piece i = queries [pieceStart[i], pieceStart[i+1]), piece 0 on this handle, piece i >= 1 on views[i-1]
   bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
   std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
   bool smallLists = true;  // 128 < k <= 4096: lists of <= 1024 candidates go through the wave-per-query evaluate + sort kernel

@@ -937,6 +937,66 @@ def test_stage_timing_period_getters_fall_back_to_the_last_timed_call():
         idx.close()
 
 
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "wrap", "odd", "ties", "big_coarse"])
+def test_overlapped_halves_equal_the_single_piece_call(name):
+    """"overlap" = 1 (2 pieces) / n: pqt_query runs the batch as pieces on their own streams, the later ones on view handles that
+    share the index arrays.  Results, candidate counts, statistics and the debug read-back (candidate sets of BOTH halves) equal the
+    one-piece call's; a timed call (stage events) stays in one piece."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        Bv, Bb = BV_BB[name]
+        for k in (10, 100):
+            idx.set_option("overlap", 0)
+            idx.set_option("stage_timing", 0)
+            i0, d0, c0 = idx.query(f.queries, Bv, Bb, k)
+            assert "overlap" not in idx.last_path()
+            st0 = idx.stats()
+            with_cands = "-runs" not in idx.last_path()  # (bin runs: no candidate list is materialised)
+            r0 = idx.debug_read(len(f.queries), cands=with_cands, segs=False, dists=False)
+            idx.set_option("overlap", 1)
+            for rep in range(2):  # (the first overlapped call creates the view handle)
+                i1, d1, c1 = idx.query(f.queries, Bv, Bb, k)
+                assert "overlap=2-pieces" in idx.last_path(), idx.last_path()
+                assert np.array_equal(i0, i1) and np.array_equal(bits(d0), bits(d1)) and np.array_equal(c0, c1)
+            st1 = idx.stats()
+            for key in ("queries", "candidates", "bins_nonempty", "bins_visited", "ties_final", "filter_fallbacks"):
+                assert st0[key] == st1[key], (key, st0[key], st1[key])
+            r1 = idx.debug_read(len(f.queries), cands=with_cands, segs=False, dists=False)
+            assert np.array_equal(r1["ncand"], r0["ncand"]) and np.array_equal(bits(r1["l1virt"]), bits(r0["l1virt"]))
+            if with_cands:
+                for qi in range(len(f.queries)):
+                    assert np.array_equal(r1["cand_idx"][qi, :r1["ncand"][qi]], r0["cand_idx"][qi, :r0["ncand"][qi]]), qi
+            idx.set_option("stage_timing", 1)  # every call carries events: one piece
+            i2, d2, c2 = idx.query(f.queries, Bv, Bb, k)
+            assert "overlap" not in idx.last_path()
+            assert np.array_equal(i0, i2) and np.array_equal(bits(d0), bits(d2))
+        # one query cannot be split; an odd batch splits unevenly
+        idx.set_option("stage_timing", 0)
+        i3, d3, c3 = idx.query(f.queries[:1], Bv, Bb, 10)
+        assert "overlap" not in idx.last_path()
+        i4, d4, c4 = idx.query(f.queries[:3], Bv, Bb, 10)
+        assert "overlap=2-pieces" in idx.last_path()
+        idx.set_option("overlap", 0)
+        i5, d5, c5 = idx.query(f.queries[:3], Bv, Bb, 10)
+        assert np.array_equal(i4, i5) and np.array_equal(bits(d4), bits(d5)) and np.array_equal(c4, c5)
+        # three and four pieces (option value = number of pieces), statistics and read-back over all of them
+        i6, d6, c6 = idx.query(f.queries, Bv, Bb, 10)
+        st6 = idx.stats()
+        for pieces in (3, 4):
+            idx.set_option("overlap", pieces)
+            i7, d7, c7 = idx.query(f.queries, Bv, Bb, 10)
+            want = min(pieces, len(f.queries))
+            assert ("overlap=%d-pieces" % want) in idx.last_path(), idx.last_path()
+            assert np.array_equal(i6, i7) and np.array_equal(bits(d6), bits(d7)) and np.array_equal(c6, c7)
+            st7 = idx.stats()
+            assert st7["queries"] == st6["queries"] and st7["candidates"] == st6["candidates"]
+            r7 = idx.debug_read(len(f.queries), cands=False, segs=False, dists=False)
+            assert np.array_equal(r7["ncand"].astype(np.int64), c6.astype(np.int64))
+    finally:
+        idx.close()
+
+
 def test_query_candidates_entry_point_returns_the_whole_sorted_list():
     """pqt_query_candidates by name (oracle-parity entry): the reference's whole sorted candidate list per query,
     true lengths in out_count, lists longer than cap cut after cap entries; a missing out_count is rejected."""
