@@ -89,8 +89,9 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * of <= 1024 entries are evaluated and sorted by one wavefront each, pqt_k_rerank_sort_small; same results).
  * "overlap": pqt_query / pqt_query_shard run a batch as two halves on two streams (the second on a view handle that shares
  * the index arrays and owns its scratch), so that one half's traversal and the tail of its rerank launch fill the gaps of
- * the other's; -1 (default) = for batches of >= 4096 queries with k <= 128 over a line store that fits the 256 MiB Infinity
- * Cache, 1 = whenever possible, 0 = never.  Calls that carry stage events ("stage_timing") always run as one piece, so the
+ * the other's; -1 (default) = for batches of >= 4096 queries with k <= 128, a coarse table that fits the LDS (LP*C1*C1*4 <=
+ * 64 KB) and a line store that fits the 256 MiB Infinity Cache (the SIFT1M shape: +24 %; measured a loss elsewhere),
+ * 1 = whenever possible (2 pieces; 2..4 = that many), 0 = never.  Calls that carry stage events ("stage_timing") always run as one piece, so the
  * default stage_timing = 1 disables it.  Same results; pqt_get_stats / pqt_debug_read cover both halves.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
  * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache, 1

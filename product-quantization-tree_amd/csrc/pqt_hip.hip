@@ -1048,20 +1048,24 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
 }
 
-// split when the two launches of a batch leave gaps worth filling: a large batch, the wave-per-query rerank, a line store that stays
-// in the Infinity Cache (with an HBM-resident store the rerank is 95 % of the step and two half-size launches balance worse than one)
+// split when the two launches of a batch leave gaps worth filling: a large batch, the wave-per-query rerank with the coarse table in
+// LDS, a line store that stays in the Infinity Cache (with an HBM-resident store the rerank is 95 % of the step and two half-size
+// launches balance worse than one)
 bool overlapWanted(const pqt_index* idx, uint32_t qn, uint32_t k) {
   if (!idx || idx->isView || idx->overlap == 0 || idx->d_tstamp || (idx->dbg & 0xffffu) || k > PQT_RS_BEST || qn < 2) return false;
   if (!idx->haveTree || !idx->haveBins || !(idx->d_codes || idx->binOrdered) || !idx->d_heur) return false;  // (queryImpl reports it)
   if (idx->stageTiming > 0 && (idx->timingPhase % (unsigned long long)idx->stageTiming) == 0) return false;      // the next call is a timed one
   if (idx->overlap >= 1) return true;
-  return qn >= 4096 && (size_t)idx->nIds * idx->dp.LP * 4 <= ((size_t)256 << 20);
+  // measured: +24 % at the SIFT1M shape (rerank with the coarse table in LDS); -7 % with the filtered rerank of the configs[2] shape on a
+  // 160 MB shard, -1.5 % on a 1.3 GB store -> automatic only for the former
+  const bool coarseLds = (size_t)idx->dp.LP * idx->dp.C1 * idx->dp.C1 * 4 <= 64 * 1024;
+  return qn >= 4096 && coarseLds && (size_t)idx->nIds * idx->dp.LP * 4 <= ((size_t)256 << 20);
 }
 
 int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx, float* outDist,
-             uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync) {
-  if (!overlapWanted(idx, qn, k)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync);
-  if (!q_dev || !outIdx || !outDist || (idx->sharded && !outPos)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync);
+             uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync, const unsigned long long* binsIn = nullptr, uint32_t binsCap = 0) {
+  if (!overlapWanted(idx, qn, k)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync, binsIn, binsCap);
+  if (!q_dev || !outIdx || !outDist || (idx->sharded && !outPos)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync, binsIn, binsCap);
   int rc = setDevice(idx);
   if (rc) return rc;
   // pieces and their shares.  Each piece's persistent rerank launch takes 1/P of the workgroup slots so that all launches are
@@ -1098,7 +1102,7 @@ int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint3
   HIPCHK(hipEventRecord(idx->evFork, st));
   for (uint32_t i = 0; i + 1 < P; ++i) HIPCHK(hipStreamWaitEvent(idx->views[i]->stream, idx->evFork, 0));
   idx->stageTiming = 0;
-  rc = queryImpl(idx, q_dev, start[1], Bv, Bb, k, outIdx, outDist, outPos, outCount, st, 0);
+  rc = queryImpl(idx, q_dev, start[1], Bv, Bb, k, outIdx, outDist, outPos, outCount, st, 0, binsIn, binsCap);
   idx->stageTiming = keepTiming;
   captureShared(idx, s1);
   idx->numCUs = keepCUs;
@@ -1113,7 +1117,8 @@ int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint3
     applyShared(v, s1);
     const uint32_t a = start[i], n = start[i + 1] - start[i];
     const int r2 = queryImpl(v, q_dev + (size_t)a * D, n, Bv, Bb, k, outIdx + (size_t)a * k, outDist + (size_t)a * k,
-                             outPos ? outPos + (size_t)a * k : nullptr, outCount ? outCount + a : nullptr, v->stream, 0);
+                             outPos ? outPos + (size_t)a * k : nullptr, outCount ? outCount + a : nullptr, v->stream, 0,
+                             binsIn ? binsIn + (size_t)a * (binsCap + 1u) : nullptr, binsCap);
     if (r2 && !rcPiece) rcPiece = r2;
     HIPCHK(hipEventRecord(idx->evJoin[i - 1], v->stream));
     HIPCHK(hipStreamWaitEvent(st, idx->evJoin[i - 1], 0));
@@ -1179,7 +1184,7 @@ int pqt_query_shard_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32
                          uint32_t* outCount, void* stream, int sync) {
   if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard / _local");
   if (!bins_dev || cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_INVALID, "bin lists missing or capacity outside 1..128");
-  return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync, bins_dev, cap);
+  return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync, bins_dev, cap);
 }
 
 int pqt_query_host(pqt_index* idx, const float* q, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,

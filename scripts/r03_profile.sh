@@ -6,7 +6,9 @@
 # for the group-major / 128-byte-row kernels, 1 for the 64-byte row gathers calibrated in profiles/r01_pmc_calibration.json).
 # Summaries land in gpurun_out/prof/<tag>_*; copy what should be judged into profiles/.
 tag=$1; ff=$2; wl=$3; bv=$4; bb=$5; k=$6; shift 6
-args="--workload $wl --bv $bv --bb $bb --k $k $@"
+# overlap=0: every call in one piece, so that the kernel statistics average full-size launches only (the library's default splits an
+# untimed SIFT1M-shape batch into two half-size launches per kernel; bench.py's own per-kernel numbers come from the one-piece timed calls)
+args="--workload $wl --bv $bv --bb $bb --k $k --option overlap=0 $@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PQT_BENCH_NO_PIPELINE=1   # only the headline launches in the kernel statistics (no half-batch two-stream leg)
 mkdir -p gpurun_out/prof

@@ -67,6 +67,7 @@ for bv, bb in ((20000, 500), (4096, 4096)):
     overflow = int(((bins_all[:qn, cap] & 0xffffffff) == 0xffffffff).sum())
     nb = (bins_all[:qn, cap] & 0xffffffff).float()
     per = []
+    ov = os.environ.get("PQT_SHARD_OVERLAP")  # e.g. "1": also time the calls without stage events and with "overlap" = that value
     for s, sh in enumerate(shards):
         t_rep = timed(lambda: sh.query_shard_dev(queries, bv, bb, k, pack[s, 0], pack[s, 1].view(torch.float32), pack[s, 2], Cc[s], stream=st.cuda_stream))
         hs = sh.stage_ms_history(3).mean(0)
@@ -75,12 +76,23 @@ for bv, bb in ((20000, 500), (4096, 4096)):
         t_trav = timed(lambda: sh.traverse_bins_dev(queries[a:b], bv, bb, cap, scratch, stream=st.cuda_stream))
         t_bins = timed(lambda: sh.query_shard_bins_dev(queries, bv, bb, k, bins_all, cap, pack2[0], pack2[1].view(torch.float32), pack2[2], C2, stream=st.cuda_stream))
         hb = sh.stage_ms_history(3).mean(0)
+        path_bins = sh.last_path()
+        untimed = None
+        if ov is not None:
+            untimed = {}
+            for name, val in (("one_piece", 0), ("overlap_%s" % ov, int(ov))):
+                sh.set_option("stage_timing", 0); sh.set_option("overlap", val)
+                untimed[name] = {"replicated_step_ms": round(timed(lambda: sh.query_shard_dev(queries, bv, bb, k, pack[s, 0], pack[s, 1].view(torch.float32), pack[s, 2], Cc[s], stream=st.cuda_stream)), 4),
+                                 "path_replicated": sh.last_path(),
+                                 "bins_step_ms": round(timed(lambda: sh.query_shard_bins_dev(queries, bv, bb, k, bins_all, cap, pack2[0], pack2[1].view(torch.float32), pack2[2], C2, stream=st.cuda_stream)), 4),
+                                 "path_bins": sh.last_path()}
+            sh.set_option("stage_timing", 1); sh.set_option("overlap", -1)
         same = bool(torch.equal(pack2[0], pack[s, 0]) and torch.equal(pack2[1], pack[s, 1]) and torch.equal(pack2[2], pack[s, 2]) and torch.equal(C2, Cc[s]))
         per.append({"local_candidates_per_query": sh.stats()["candidates"] / qn,
                     "replicated": {"step_ms": round(t_rep, 4), "traverse_ms": round(float(hs[1]), 4), "rerank_select_ms": round(float(hs[3]), 4)},
                     "query_sharded": {"traverse_slice_ms": round(t_trav, 4), "step_ms": round(t_bins, 4), "tables_resolve_ms": round(float(hb[1]), 4),
                                       "rerank_select_ms": round(float(hb[3]), 4), "per_rank_ms": round(t_trav + t_bins, 4), "identical_to_replicated": same,
-                                      "path": sh.last_path()}})
+                                      "path": path_bins}, "without_stage_events": untimed})
     oI = torch.empty((qn, k), dtype=torch.int32, device=dev); oD = torch.empty((qn, k), dtype=torch.float32, device=dev)
     res = {"unsharded": {"step_ms": round(step1, 4), "traverse_ms": round(float(h[1]), 4), "rerank_select_ms": round(float(h[3]), 4)}, "per_shard": per,
            "bin_lists": {"mean_bins_per_query": float(nb[nb < 4e9].mean()), "max": float(nb[nb < 4e9].max()), "overflowed_queries": overflow},
