@@ -799,19 +799,14 @@ def main():
         except Exception as e:
             out["config"]["knobs_4096_4096"] = {"error": repr(e)[:200]}
 
-    # ---- the same batch in ONE piece ("overlap" = 0).  By default the library runs a batch of >= 4096 queries over an Infinity-Cache-
-    # resident line store as two pieces on two streams (each rerank launch on half of the workgroup slots; calls that carry stage events
-    # stay in one piece, so the per-kernel numbers of the roofline block are single-stream).  Reported beside the headline.
+    # ---- the headline batch without stage events on any call (the events cost ~0.01 ms per call), and as two pieces on two streams
+    # ("overlap" = 1: opt-in since the rerank's statistics atomics stopped serialising the launch, DESIGN.md section 4 "Round 3")
     if mode == "single" and not W["chunked"] and not os.environ.get("PQT_BENCH_NO_PIPELINE") and not args.option:
         try:
-            path_default = None
             idx.set_option("stage_timing", 0)
-            idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
-            torch.cuda.synchronize(dev)
-            path_default = idx.last_path()
             oi1, od1, oc1 = torch.empty_like(out_idx), torch.empty_like(out_dist), torch.empty_like(out_cnt)
             leg = {}
-            for name, ov in (("one_piece", 0), ("default", -1)):
+            for name, ov in (("one_piece", 0), ("two_pieces", 1)):
                 idx.set_option("overlap", ov)
                 for _ in range(3):
                     idx.query_dev(queries, args.bv, args.bb, k, oi1, od1, oc1, stream=stream)
@@ -823,16 +818,15 @@ def main():
                 t3 = (time.perf_counter() - t3) / args.steps
                 leg[name] = {"queries_per_sec": qn / t3, "ms_per_step": t3 * 1e3, "kernel_path": idx.last_path(),
                              "results_identical": bool(torch.equal(oi1, out_idx) and torch.equal(od1, out_dist) and torch.equal(oc1, out_cnt))}
-            leg["what"] = ("the headline batch with no stage events on any call: in one piece (overlap = 0) and as the library splits it by default "
-                           "(two pieces on two streams when the kernel_path says overlap=2-pieces); `value` above mixes both, because every "
-                           "timing-period-th step carries events and therefore runs in one piece")
-            out["config"]["overlap"] = leg
+            leg["what"] = ("the headline batch with no stage events on any call: in one piece (the default) and as two pieces on two streams "
+                           "(option overlap = 1); `value` above carries events on every timing-period-th step")
+            out["config"]["no_stage_events"] = leg
             idx.set_option("overlap", -1)
             idx.set_option("stage_timing", 1)
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)
             torch.cuda.synchronize(dev)
         except Exception as e:
-            out["config"]["overlap"] = {"error": repr(e)[:200]}
+            out["config"]["no_stage_events"] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
     if mode == "single" and not args.no_cpu and not W["chunked"]:

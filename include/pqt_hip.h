@@ -87,12 +87,11 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * intermediates readable by pqt_debug_read). Results are identical either way.
  * "small_lists" = 0: a 128 < k <= 4096 call sends every query through the block-wide select kernel (default 1: candidate lists
  * of <= 1024 entries are evaluated and sorted by one wavefront each, pqt_k_rerank_sort_small; same results).
- * "overlap": pqt_query / pqt_query_shard run a batch as two halves on two streams (the second on a view handle that shares
- * the index arrays and owns its scratch), so that one half's traversal and the tail of its rerank launch fill the gaps of
- * the other's; -1 (default) = for batches of >= 4096 queries with k <= 128, a coarse table that fits the LDS (LP*C1*C1*4 <=
- * 64 KB) and a line store that fits the 256 MiB Infinity Cache (the SIFT1M shape: +24 %; measured a loss elsewhere),
- * 1 = whenever possible (2 pieces; 2..4 = that many), 0 = never.  Calls that carry stage events ("stage_timing") always run as one piece, so the
- * default stage_timing = 1 disables it.  Same results; pqt_get_stats / pqt_debug_read cover both halves.
+ * "overlap" = 1 (2..4: that many pieces): pqt_query / pqt_query_shard / pqt_query_shard_bins run a batch as pieces on their own
+ * streams (the later ones on view handles that share the index arrays and own their scratch), each piece's rerank launch on its
+ * share of the workgroup slots.  Off by default (0 / -1): since the statistics atomics of the rerank were reduced to one per
+ * workgroup the one-piece call is faster at every measured shape ("Round 3").  Calls that carry stage events
+ * ("stage_timing") always run in one piece.  Same results; pqt_get_stats / pqt_debug_read cover all pieces.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
  * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache, 1
  * otherwise; 2 = per-XCD query pools in longest-first order (the traversal

@@ -366,7 +366,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     unsigned long long* const tstamp = (nq <= (1u << 16)) ? idx->d_tstamp : nullptr;  // debug buffer holds 65536 query records
     // rerank schedule of this chunk (decided here: for schedule 2 the traversal kernels register the queries by size class)
     const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
-    const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, (uint32_t)idx->numCUs);
+    static const int envGrid = getenv("PQT_RS_GRID") ? atoi(getenv("PQT_RS_GRID")) : 0;  // experiment: workgroups of the persistent rerank launch
+    const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, envGrid > 0 ? (uint32_t)envGrid : (uint32_t)idx->numCUs);
     const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
     // automatic choice: the global pools pay for their registration atomics and chunk draws when a query brings thousands of
     // candidates from an HBM-resident store (configs[2]/[3]: -8..-10 % on the rerank launch); with a cache-resident store and
@@ -672,7 +673,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
-  if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: -1 automatic, 0 never, 1 whenever possible, 2..4 = that many pieces
+  if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "small_lists") == 0) { idx->smallLists = (value != 0); return PQT_OK; }  // 0: every query of a 128 < k <= 4096 call through the block-wide select kernel
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes
@@ -1048,18 +1049,15 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
 }
 
-// split when the two launches of a batch leave gaps worth filling: a large batch, the wave-per-query rerank with the coarse table in
-// LDS, a line store that stays in the Infinity Cache (with an HBM-resident store the rerank is 95 % of the step and two half-size
-// launches balance worse than one)
+// Opt-in ("overlap" >= 1).  History: with one statistics atomic per LANE in the rerank (pqt_count_ties) two half-size launches on two
+// handles ran 1.24x faster than one launch -- two counter words instead of one -- and the split was made the default for the SIFT1M
+// shape; with the atomics reduced to one per workgroup the one-piece call is the faster one (0.167 against 0.173 ms per 10 k queries),
+// so nothing is split automatically any more.
 bool overlapWanted(const pqt_index* idx, uint32_t qn, uint32_t k) {
-  if (!idx || idx->isView || idx->overlap == 0 || idx->d_tstamp || (idx->dbg & 0xffffu) || k > PQT_RS_BEST || qn < 2) return false;
+  if (!idx || idx->isView || idx->overlap < 1 || idx->d_tstamp || (idx->dbg & 0xffffu) || k > PQT_RS_BEST || qn < 2) return false;
   if (!idx->haveTree || !idx->haveBins || !(idx->d_codes || idx->binOrdered) || !idx->d_heur) return false;  // (queryImpl reports it)
   if (idx->stageTiming > 0 && (idx->timingPhase % (unsigned long long)idx->stageTiming) == 0) return false;      // the next call is a timed one
-  if (idx->overlap >= 1) return true;
-  // measured: +24 % at the SIFT1M shape (rerank with the coarse table in LDS); -7 % with the filtered rerank of the configs[2] shape on a
-  // 160 MB shard, -1.5 % on a 1.3 GB store -> automatic only for the former
-  const bool coarseLds = (size_t)idx->dp.LP * idx->dp.C1 * idx->dp.C1 * 4 <= 64 * 1024;
-  return qn >= 4096 && coarseLds && (size_t)idx->nIds * idx->dp.LP * 4 <= ((size_t)256 << 20);
+  return true;
 }
 
 int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx, float* outDist,
@@ -1069,8 +1067,8 @@ int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint3
   int rc = setDevice(idx);
   if (rc) return rc;
   // pieces and their shares.  Each piece's persistent rerank launch takes 1/P of the workgroup slots so that all launches are
-  // resident together (full-size grids queue behind each other on the LDS: 4 % slower than one piece instead of 13 % faster at the
-  // SIFT1M shape); the first piece starts first and gets a slightly larger share of the queries
+  // resident together (full-size grids queue behind each other on the LDS); the first piece starts first and gets a slightly
+  // larger share of the queries
   static const int envPieces = getenv("PQT_OVERLAP_PIECES") ? atoi(getenv("PQT_OVERLAP_PIECES")) : 0;
   static const int envFirst = getenv("PQT_OVERLAP_FIRST_PCT") ? atoi(getenv("PQT_OVERLAP_FIRST_PCT")) : 0;
   uint32_t P = idx->overlap >= 2 ? (uint32_t)idx->overlap : (envPieces >= 2 ? (uint32_t)envPieces : 2u);

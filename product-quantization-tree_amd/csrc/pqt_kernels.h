@@ -34,6 +34,20 @@ __global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ 
 }
 #endif  // PQT_MAIN_TU
 
+// One statistics atomic per WAVEFRONT.  The tie counters (pqt_stats.ties_*) were bumped by every lane that saw a tie, each with its own
+// device-scope atomic on the same word: on the SIFT-shaped data a result list holds ~45 equal-distance neighbours, i.e. ~450 k
+// same-address atomics per 10 k-query launch, and they serialise at the memory side -- 0.058 of the rerank launch's 0.157 ms at the
+// SIFT1M shape (found because two half-size launches on two handles, i.e. two counter words, ran 1.4x faster than one launch).
+// The persistent kernels accumulate in a register across their queries and call this once per wavefront.
+// All lanes of the wavefront must be active.
+__device__ __forceinline__ void pqt_count_ties(unsigned long long* ctr, uint32_t ties) {
+  if (__any(ties != 0)) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) ties += (uint32_t)__shfl_xor((int)ties, d, 64);
+    if ((threadIdx.x & 63u) == 0) atomicAdd(ctr, (unsigned long long)ties);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stage a1 + a2: per-query distance tables and the sorted second-level entry lists.
 //   one workgroup per query.
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
     }
     if (rank < W) sOrd[p * W + rank] = c;
   }
-  if (ties) atomicAdd(&counters[0], (unsigned long long)ties);
+  pqt_count_ties(&counters[0], ties);
   __syncthreads();
   // a2: second-level distances of the W expanded cells
   for (uint32_t t = tid; t < P * WC; t += PQT_BLOCK) {
@@ -119,7 +133,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
     segD[base + rank] = my;
     segBin[base + rank] = sOrd[p * W + h1] * C2 + h2;
   }
-  if (ties) atomicAdd(&counters[1], (unsigned long long)ties);
+  pqt_count_ties(&counters[1], ties);
 }
 #endif  // PQT_MAIN_TU
 
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     loc += sRec[((uint32_t)sKey[i] & 0x1fffu) * RW];
     if (i + 1 < nEnt && (uint32_t)(sKey[i] >> 32) == (uint32_t)(sKey[i + 1] >> 32)) ++ties;
   }
-  if (ties) atomicAdd(&counters[2], (unsigned long long)ties);
+  pqt_count_ties(&counters[2], ties);
   uint32_t total;
   const uint32_t run = pqt_block_excl_scan<PQT_BLOCK>(loc, sPart, &total);
   // included bins = the prefix with exclusive count <= Bv (the count is non-decreasing)
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_select(
       if (SHARDED) outPos[(size_t)q * k + i] = 0xffffffffu;
     }
   }
-  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  pqt_count_ties(&counters[3], ties);
 }
 
 // full sort of every candidate list through a global-memory key buffer (parity / large-k path):
@@ -475,7 +489,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_fullsort(
       if (SHARDED) outPos[(size_t)q * k + i] = 0xffffffffu;
     }
   }
-  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  pqt_count_ties(&counters[3], ties);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -808,7 +822,7 @@ struct PqtRsArgs {
 //   to fbList and redone by the plain exact kernel (pqt_k_rerank_select_list) -- never a wrong answer, rarely a slow one.
 template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
-                                             const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot,
+                                             const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
                                              unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const uint32_t* __restrict__ codes = A.codes; const uint32_t* __restrict__ ids = A.ids; const float* __restrict__ qL1virt = A.qL1virt;
@@ -1285,7 +1299,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       }
     }
   }
-  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  tiesAcc += ties;  // flushed once per wavefront by the kernel (pqt_count_ties)
   __builtin_amdgcn_wave_barrier();
   if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tsOut = __builtin_readcyclecounter() - ts0; }
   if (tstamp && lane == 0) {
@@ -1447,6 +1461,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
       if (e < Ls) { sList[rank[j]] = e; sListN[rank[j]] = ne[j]; }
     }
   }
+  // the workgroup's tie count is summed in the last word of the (by now consumed) ranking scratch: thread 0 belongs to wavefront 0,
+  // which is the only reader/writer of sTmpN above
+  uint32_t* const sTies = sTmpN + (PQT_RS_LIST - 1);
+  if (threadIdx.x == 0) *(volatile uint32_t*)sTies = 0;
   if (COARSE_LDS && !(dbg & 4)) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = coarse[t];
   __syncthreads();
   const float* cz = COARSE_LDS ? sCoarse : coarse;
@@ -1507,17 +1525,25 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   // ahead by a wavefront, which matters at the end of the launch; the other schedules choose it now and fetch a count that
   // is not in the LDS list under the final select + sort
   uint32_t n = 0;
+  uint32_t tiesAcc = 0;  // ties seen by this lane over all queries of the wavefront
   uint32_t q = nextQuery(n);
   if (q != 0xffffffffu && n == 0xffffffffu) n = nLocal[q];
   if (dbg & 2) n = 0;
   while (q != 0xffffffffu) {
     uint32_t nN = 0, qN = 0xffffffffu;
     if (dynamic != 2) qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, sRuns);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
     if (dynamic == 2) { qN = nextQuery(nN); if (dbg & 2) nN = 0; }
     q = qN;
     n = nN;
   }
+  // statistics: ONE device-scope atomic per workgroup (3072 same-address atomics at the end of the launch, one per wavefront, still
+  // cost 0.015 ms of drain: 0.117 against 0.099 ms with the counter switched off)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) tiesAcc += (uint32_t)__shfl_xor((int)tiesAcc, d, 64);
+  if (lane == 0 && tiesAcc) atomicAdd(sTies, tiesAcc);
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t t = *(volatile uint32_t*)sTies; if (t) atomicAdd(&A.counters[3], (unsigned long long)t); }
 }
 
 // the queries MODE 2 handed back (fbList): plain exact rerank+select (MODE 0, coarse through L2), one wavefront per list entry
@@ -1530,14 +1556,16 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select_list(const PqtRsA
   uint64_t* sKeys = (uint64_t*)smem_raw + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
   float* sVirt = (float*)(smem_raw + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
   const uint32_t cnt = *A.qcount;
+  uint32_t tiesAcc = 0;
   for (uint32_t e = blockIdx.x * NW + wave; e < cnt; e += gridDim.x * NW) {
     const uint32_t q = A.qlist[e];
     uint32_t nN = 0;
     unsigned long long* sRuns = (RUNS && A.runs)
         ? reinterpret_cast<unsigned long long*>(smem_raw + (((size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4) + 15) & ~(size_t)15)) + (size_t)wave * (A.runCap + A.runCap / 2)
         : nullptr;
-    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 0, RUNS>(A, q, A.nLocal[q], sKeys, sVirt, A.coarse, 0xffffffffu, nN, 0u, sRuns);
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 0, RUNS>(A, q, A.nLocal[q], sKeys, sVirt, A.coarse, 0xffffffffu, nN, 0u, tiesAcc, sRuns);
   }
+  pqt_count_ties(&A.counters[3], tiesAcc);
 }
 
 // ===================================================================================================
@@ -1767,7 +1795,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     if (rank < W) sOrd[p * W + rank] = c;
   }
   }
-  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[0], (unsigned long long)ties); }
+  pqt_count_ties(&counters[0], ties);
   __builtin_amdgcn_wave_barrier();
   PQT_TS(2);
   // ---- a2 (2 entries per lane in flight)
@@ -1857,7 +1885,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
     }
   }
-  if (__any(ties != 0)) { if (ties) atomicAdd(&counters[1], (unsigned long long)ties); }
+  pqt_count_ties(&counters[1], ties);
   __builtin_amdgcn_wave_barrier();
   PQT_TS(4);
   // ---- a4 + a5: 8 rows per lane and block of 512 rows, row h = hb + lane + 64*r
@@ -2032,7 +2060,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
       }
       sum += g8[r];
     }
-    if (__any(tb != 0)) { if (tb) atomicAdd(&counters[2], (unsigned long long)tb); }
+    pqt_count_ties(&counters[2], tb);
     const uint32_t incl = pqt_wave_incl_scan(sum);
     uint32_t run = incl - sum;  // exclusive prefix of this lane's first element
     uint32_t myCand = 0, myNonEmpty = 0;
@@ -2982,7 +3010,7 @@ __global__ __launch_bounds__(PQT_RS2_NW * 64, PQT_RS2_WPS) void pqt_k_rerank_sel
         if (SHARDED) outPos[o] = 0xffffffffu;
       }
     }
-    if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+    pqt_count_ties(&counters[3], ties);
   }
 }
 
@@ -3158,7 +3186,7 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
       if (SHARDED) outPos[o] = 0xffffffffu;
     }
   }
-  if (ties) atomicAdd(&counters[3], (unsigned long long)ties);
+  pqt_count_ties(&counters[3], ties);
   }
 }
 
@@ -3310,7 +3338,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
       A.outDist[o] = __uint_as_float(0x7f800000u);
       if (SHARDED) A.outPos[o] = 0xffffffffu;
     }
-    if (__any(ties != 0)) { if (ties) atomicAdd(&A.counters[3], (unsigned long long)ties); }
+    pqt_count_ties(&A.counters[3], ties);
     }
     __builtin_amdgcn_wave_barrier();
   }

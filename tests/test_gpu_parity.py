@@ -997,6 +997,33 @@ def test_overlapped_halves_equal_the_single_piece_call(name):
         idx.close()
 
 
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small", "ties", "big_coarse", "wrap"])
+def test_tie_statistics_count_adjacent_equal_distances_of_the_result_lists(name):
+    """pqt_stats.ties_final = adjacent equal-distance pairs inside the returned lists, summed over the batch.  The kernels sum it per
+    wavefront / per workgroup before ONE atomic (pqt_count_ties; one atomic per lane serialised the whole rerank launch): every kernel
+    family must still report the exact count -- fused wave-per-query (k <= 128), short-list + block-wide (128 < k <= 4096), staged."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        Bv, Bb = BV_BB[name]
+        qs = np.concatenate([f.queries] * 8)  # several queries per wavefront slot and equal lists in different workgroups
+        for k, opts in ((100, {}), (7, {}), (300, {}), (300, {"small_lists": 0}), (100, {"fused": 0})):
+            for o, v in opts.items():
+                idx.set_option(o, v)
+            ids, dist, cnt = idx.query(qs, Bv, Bb, k)
+            st = idx.stats()
+            want = 0
+            for qi in range(len(qs)):
+                kk = min(k, int(cnt[qi]))
+                d = bits(dist[qi, :kk])
+                want += int((d[1:] == d[:-1]).sum())
+            assert st["ties_final"] == want, (name, k, opts, idx.last_path(), st["ties_final"], want)
+            for o in opts:
+                idx.set_option(o, 1)
+    finally:
+        idx.close()
+
+
 def test_query_candidates_entry_point_returns_the_whole_sorted_list():
     """pqt_query_candidates by name (oracle-parity entry): the reference's whole sorted candidate list per query,
     true lengths in out_count, lists longer than cap cut after cap entries; a missing out_count is rejected."""
