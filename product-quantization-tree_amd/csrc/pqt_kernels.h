@@ -34,6 +34,8 @@ __global__ void pqt_k_coarse(const float* __restrict__ cb1, float* __restrict__ 
 }
 #endif  // PQT_MAIN_TU
 
+typedef float pqt_f2 __attribute__((ext_vector_type(2)));
+
 // One statistics atomic per WAVEFRONT.  The tie counters (pqt_stats.ties_*) were bumped by every lane that saw a tie, each with its own
 // device-scope atomic on the same word: on the SIFT-shaped data a result list holds ~45 equal-distance neighbours, i.e. ~450 k
 // same-address atomics per 10 k-query launch, and they serialise at the memory side -- 0.058 of the rerank launch's 0.157 ms at the
@@ -1107,32 +1109,47 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 #pragma unroll
         for (int v = 0; v < LPV; ++v) {
           const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+          // two line parts at a time: the per-part arithmetic in packed FP32 (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, nothing
+          // fused, the association of extractDistance unchanged), the running sum still one part after the other -- bit-identical keys
+          // with ~a quarter fewer VALU instructions in the phase that bounds this kernel at the SIFT1M shape (3 wavefronts per SIMD)
 #pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            const uint32_t p = v * 4 + x;
-            const uint32_t A = w[x] & 0xffu, B = (w[x] >> 8) & 0xffu;
-            const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);  // == pqt_lambda_decode: the product is exact
-            float sb, sa, sc;
-            if constexpr (MODE != 0) {
-              const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
-              sb = sVirt[pv + A];
-              sa = sVirt[pv + B];
-              acc = acc + (sb + lam * (sa - sb));
-              continue;
-            } else if constexpr (C1M >= 2 && COARSE_LDS) {
-              // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
-              // the part offsets go into the instructions' immediate fields
-              const uint32_t B4 = B << 2;
-              const uint32_t aV = (A << 2) + vOff, bV = B4 + vOff, aC = (A << (2 + C1M)) + B4;  // v_lshl_add, v_add, v_lshl_add
-              sb = *reinterpret_cast<const float*>(smem_raw + aV + p * (4u << C1M));
-              sa = *reinterpret_cast<const float*>(smem_raw + bV + p * (4u << C1M));
-              sc = *reinterpret_cast<const float*>(smem_raw + aC + p * (4u << (2 * C1M)));
-            } else {
-              sb = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
-              sa = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
-              sc = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
+          for (int x = 0; x < 4; x += 2) {
+            pqt_f2 sb2, sa2, sc2, lam2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint32_t p = v * 4 + x + h;
+              const uint32_t ww = w[x + h];
+              const uint32_t A = ww & 0xffu, B = (ww >> 8) & 0xffu;
+              lam2[h] = (float)(ww >> 16);
+              if constexpr (MODE != 0) {
+                const uint32_t pv = C1P2 ? (p << c1sh) : p * C1;
+                sb2[h] = sVirt[pv + A];
+                sa2[h] = sVirt[pv + B];
+              } else if constexpr (C1M >= 2 && COARSE_LDS) {
+                // byte offsets with compile-time strides: one add per L1virt address, one shift-add for the coarse one,
+                // the part offsets go into the instructions' immediate fields
+                const uint32_t B4 = B << 2;
+                const uint32_t aV = (A << 2) + vOff, bV = B4 + vOff, aC = (A << (2 + C1M)) + B4;  // v_lshl_add, v_add, v_lshl_add
+                sb2[h] = *reinterpret_cast<const float*>(smem_raw + aV + p * (4u << C1M));
+                sa2[h] = *reinterpret_cast<const float*>(smem_raw + bV + p * (4u << C1M));
+                sc2[h] = *reinterpret_cast<const float*>(smem_raw + aC + p * (4u << (2 * C1M)));
+              } else {
+                sb2[h] = sVirt[(C1P2 ? (p << c1sh) : p * C1) + A];
+                sa2[h] = sVirt[(C1P2 ? (p << c1sh) : p * C1) + B];
+                sc2[h] = cz[C1P2 ? ((((p << c1sh) + A) << c1sh) + B) : ((p * C1 + A) * C1 + B)];
+              }
             }
-            acc = acc + pqt_extract_distance(sa, sb, sc, lam);
+            const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
+            lam2 = lam2 * kScale + kOff;  // == pqt_lambda_decode: the product is exact, so mul + add rounds like the scalar fma
+            if constexpr (MODE != 0) {
+              const pqt_f2 d2 = sb2 + lam2 * (sa2 - sb2);
+              acc = acc + d2[0];
+              acc = acc + d2[1];
+            } else {
+              const pqt_f2 d2 = sb2 + lam2 * lam2 * sc2 + lam2 * (sa2 - sb2 - sc2);  // pqt_extract_distance per component
+              acc = acc + d2[0];
+              acc = acc + d2[1];
+            }
           }
         }
         if constexpr (MODE != 0) acc = acc + rbias[u];
@@ -1620,7 +1637,6 @@ struct PqtTravArgs {
 // unrolls the per-dimension loops and issues the centroid reads of a lane's accumulators together; with run-time SS it
 // emitted a remainder loop of one 4-byte load + s_waitcnt per dimension (cfg3 shape: 128 serialized round trips per
 // query in a1 alone, 56 k of the 228 k clocks of a traversal).
-typedef float pqt_f2 __attribute__((ext_vector_type(2)));
 template <int SHAPE> struct PqtShape { static constexpr uint32_t D = 1, P = 1, C1 = 1, C2 = 1, W = 1, LP = 1; };  // run-time shape: unused
 template <> struct PqtShape<1> { static constexpr uint32_t D = 128, P = 4, C1 = 32, C2 = 32, W = 2, LP = 16; };
 template <> struct PqtShape<2> { static constexpr uint32_t D = 128, P = 4, C1 = 64, C2 = 64, W = 1, LP = 32; };
