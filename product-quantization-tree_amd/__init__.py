@@ -56,11 +56,11 @@ EXPORTS = [
 
 def build(force=False):
     """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_rerank_launch.hip", "pqt_traverse_launch.hip", "pqt_internal.h", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h",
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_rerank_launch.hip", "pqt_traverse_launch.hip", "pqt_fused_launch.hip", "pqt_internal.h", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h",
                                            "pqt_multi.cpp", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-j4", "-C", CSRC, "libpqt_hip.so"])
+        subprocess.check_call(["make", "-j5", "-C", CSRC, "libpqt_hip.so"])
     return LIB_PATH
 
 

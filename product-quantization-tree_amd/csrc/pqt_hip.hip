@@ -345,6 +345,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   if (bigK && !bigCL && lBigBase > kMaxLds) bigK = false;
   const size_t lBig = lBigBase + (bigCL ? coarseBytes : 0);
   bool usedSmallFirst = false;
+  bool usedOneLaunch = false;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -386,6 +387,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if ((rc = devAlloc(&idx->d_schedList, (size_t)8 * PQT_SCHED_CLASSES * idx->curSchedCap))) return rc;
       idx->schedCapQ = idx->curSchedCap;
     }
+    // SIFT1M shape, short traversal, plain exact rerank with the LDS table, unsharded: the whole query in ONE launch (pqt_k_query_fused).
+    // Opt-in ("one_launch" = 1): measured 0.191 against 0.167 ms per 10 k queries for the two launches (kernel comment).
+    bool oneLaunch = false;
+    PqtTravArgs oneLaunchT{};
     if (travFused) {
       // a1..a6 in one launch, one wavefront per query
       if (travWide) HIPCHK(hipMemsetAsync(idx->d_ovCount, 0, 4, st));
@@ -413,7 +418,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         targs.qlist = idx->d_tvList; targs.qcount = idx->d_tvCount;
         launchFusedTraversal(idx, targs, tplan, nq, st, nullptr, idx->lev1);
       } else {
-        launchFusedTraversal(idx, targs, tplan, nq, st, idx->lev0, idx->lev1);
+        oneLaunch = idx->oneLaunch > 0 && !travWide && fused && !wgG && !useBias && coarseLds && !emitRuns && !idx->sharded && !useSched && !tstamp &&
+                    travShape(idx, targs) == 1 && queryFusedShape(idx) && !(idx->dbg & 0xffffu) &&
+                    coarseBytes + (size_t)kFusedWaves * queryFusedPerWave(idx, tplan) + 16 <= kMaxLds;
+        if (oneLaunch) oneLaunchT = targs;  // launched below, where the rerank's arguments are known
+        else launchFusedTraversal(idx, targs, tplan, nq, st, idx->lev0, idx->lev1);
       }
       if (travWide) {
         // queries with more than 512 populated rows queued themselves: workgroup-per-query kernel with an He-sized arena
@@ -485,6 +494,16 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       } else {
         idx->curZero8 = nextCtr;  // the kernel also zeroes the statistics block of the next call
         nextZeroed = true;
+        if (oneLaunch) {
+          hipEvent_t e0 = idx->lev0;
+          if (leanEvents && idx->timedCall) {  // one dispatch: its start is the call's BEGIN, the traversal's stop / the rerank's start do not exist
+            e0 = idx->evRing[idx->ringPos][c][EV_BEGIN];
+            idx->evMask[idx->ringPos][c] &= ~((1u << EV_BINS) | (1u << EV_ORDER));
+          }
+          if ((rc = launchQueryFused(idx, oneLaunchT, tplan, grid, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0, stride, k, nq, oI, oD,
+                                     e0, idx->lev1))) return rc;
+          usedOneLaunch = true;
+        } else
         if ((rc = launchRerankSelect(idx, coarseLds, grid, emitRuns ? lRuns : lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                      stride, k, nq, oI, oD, oP))) return rc;
         idx->poolDirty = false;
@@ -568,7 +587,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "");
     } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + ((idx->smallLists && (d.LP == 16 || d.LP == 32)) ? "+small-lists" : "");
     else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
-    idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks);
+    idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks) + (usedOneLaunch ? " one-launch" : "");
   }
   idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
   if (sync) HIPCHK(hipStreamSynchronize(st));
@@ -674,6 +693,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
+  if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
   if (strcmp(name, "small_lists") == 0) { idx->smallLists = (value != 0); return PQT_OK; }  // 0: every query of a 128 < k <= 4096 call through the block-wide select kernel
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes

@@ -106,6 +106,7 @@ struct pqt_index {
   uint32_t lastPieces = 0, pieceStart[kMaxViews + 2] = {0, 0, 0, 0, 0};  // last call: pieces (0: one piece on this handle); piece i = queries [pieceStart[i], pieceStart[i+1]), piece 0 on this handle, piece i >= 1 on views[i-1]
   bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
   std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
+  int oneLaunch = -1;  // SIFT1M shape: traversal + rerank of a query by the same wavefront in ONE launch (pqt_k_query_fused): 1 on, 0 / -1 (default) off -- measured slower than the two launches
   bool smallLists = true;  // 128 < k <= 4096: lists of <= 1024 candidates go through the wave-per-query evaluate + sort kernel
   int numCUs = 256; bool forceUnfused = false; bool useWgRerank = true; int balance = -1 /* auto */; int stageTiming = 1; bool timedCall = true; unsigned long long timingPhase = 0; bool noShape = false; uint32_t dbg = 0;
 };
@@ -155,3 +156,7 @@ struct TravPlan { bool fused = false, wide = false, p2 = false; size_t lTrav = 0
 int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp);
 int travShape(const pqt_index* idx, const PqtTravArgs& targs);
 void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& tp, uint32_t waves, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+size_t queryFusedPerWave(const pqt_index* idx, const TravPlan& tp);
+bool queryFusedShape(const pqt_index* idx);
+int launchQueryFused(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& tp, uint32_t grid, hipStream_t st, const float* qL1virt,
+                     const uint32_t* nLocal, uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, hipEvent_t ev0, hipEvent_t ev1);

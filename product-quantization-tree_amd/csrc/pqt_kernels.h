@@ -2444,6 +2444,61 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtT
 }
 
 // ---------------------------------------------------------------------------------------------------
+// One launch for the whole query (SIFT1M shape: compile-time traversal shape 1, rerank with the coarse table in LDS): a wavefront
+// draws a query, traverses it (pqt_traverse_query) and reranks it (pqt_rs_query) before it draws the next.  Two launches kept the
+// latency-bound traversal (VALU mostly idle) and the VALU-bound rerank apart; here the wavefronts of a SIMD are in different phases
+// at any time.  The traversal arena and the rerank's key/table slots of a wavefront share one LDS region (used one after the
+// other).  The traversal's outputs (candidate list, counts, L1virt) go through global memory exactly as between the two launches:
+// the wavefront that wrote them reads them back after s_waitcnt vmcnt(0) (same CU, write-through L1).
+// Schedule: workgroup b owns the queries b, b + G, ...; its wavefronts draw them in index order through an LDS ticket (the candidate
+// counts that the two-launch rerank orders by are not known before the traversal).
+// MEASURED AND NOT THE DEFAULT: 0.191 ms per 10 k queries against 0.065 + 0.005 + 0.101 = 0.167 ms for the two launches (same box, same
+// results).  The coarse table (64 KB) + 6.7 KB per wavefront cap a workgroup at 12 wavefronts = 3 per SIMD, where the stand-alone traversal
+// runs 5 per SIMD to hide its dependent round trips; the merged body needs 168 VGPRs (39 spilled at the 12-wavefront budget; 8 wavefronts
+// with 218 VGPRs and no spills: 0.222 ms), is 110 KB of code for a 64 KB instruction cache, and loses the longest-first order.  Kept as
+// the opt-in "one_launch" option with its parity test; the L1virt round trip it was meant to save is 2 KB per query out of L2.
+// ---------------------------------------------------------------------------------------------------
+template <int NW, int LPV, int UREQ, int C1M, int SHAPE>
+__global__ __launch_bounds__(NW * 64) void pqt_k_query_fused(const PqtTravArgs TA, const PqtRsArgs RA, uint32_t perWaveBytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M, nCoarse = LP * C1 * C1;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* sCoarse = (float*)smem_raw;  // offset 0: pqt_rs_query's compile-time-stride addressing assumes it
+  unsigned char* const wbase = smem_raw + (size_t)nCoarse * 4 + (size_t)wave * perWaveBytes;
+  uint64_t* const sKeys = (uint64_t*)wbase;
+  float* const sVirt = (float*)(wbase + (size_t)(PQT_RS_BEST + PQT_RS_PEND) * 8);
+  uint32_t* const sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * perWaveBytes);  // [0] ticket, [1] ties
+  if (threadIdx.x < 2) sTicket[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 8 && RA.zero8) RA.zero8[threadIdx.x] = 0;
+  for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = RA.coarse[t];
+  __syncthreads();
+  const uint32_t G = gridDim.x, qn = RA.qn;
+  const uint32_t L = blockIdx.x < qn ? (qn - blockIdx.x + G - 1) / G : 0u;
+  const uint32_t slot = blockIdx.x * NW + wave;
+  uint32_t tiesAcc = 0;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(sTicket, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= L) break;
+    const uint32_t q = blockIdx.x + t * G;
+    pqt_traverse_query<1, false, true, SHAPE>(TA, q, wbase, perWaveBytes);
+    // the wavefront's own stores (candidate list, nLocal, L1virt) before its own loads of them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n = RA.nLocal[q];
+    uint32_t nN = 0;
+    pqt_rs_query<LPV, UREQ, true, false, C1M, 0, false>(RA, q, n, sKeys, sVirt, sCoarse, 0xffffffffu, nN, slot, tiesAcc, nullptr);
+    __builtin_amdgcn_wave_barrier();
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) tiesAcc += (uint32_t)__shfl_xor((int)tiesAcc, d, 64);
+  if (lane == 0 && tiesAcc) atomicAdd(&sTicket[1], tiesAcc);
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t tt = *(volatile uint32_t*)&sTicket[1]; if (tt) atomicAdd(&RA.counters[3], (unsigned long long)tt); }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Query-sharded traversal, receiving side (pqt_query_shard_bins).  The traversal of a query ran on ANOTHER shard
 // (pqt_traverse_bins) and arrives as its list of included populated bins (bin id | global start << 32, visiting order).
 //   pqt_l1virt_block   a1 only: L1virt[lp][c] of every query (the rerank's distance table), same sums as the traversal.

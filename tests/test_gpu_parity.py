@@ -1024,6 +1024,43 @@ def test_tie_statistics_count_adjacent_equal_distances_of_the_result_lists(name)
         idx.close()
 
 
+def test_one_launch_query_kernel_equals_the_two_launches():
+    """"one_launch" = 1 (SIFT1M shape): traversal + rerank/select of a query by one wavefront in one launch (pqt_k_query_fused) --
+    identical lists, counts and statistics, stage events around the single dispatch; shapes it does not cover keep the two launches."""
+    f = fixture("cfg2_small")
+    idx = f.hip_index()
+    try:
+        Bv, Bb = BV_BB["cfg2_small"]
+        qs = np.concatenate([f.queries] * 40)  # several queries per wavefront
+        for k in (1, 10, 100):
+            idx.set_option("one_launch", 0)
+            i0, d0, c0 = idx.query(qs, Bv, Bb, k)
+            assert "one-launch" not in idx.last_path()
+            st0 = idx.stats()
+            idx.set_option("one_launch", 1)
+            i1, d1, c1 = idx.query(qs, Bv, Bb, k)
+            assert "one-launch" in idx.last_path(), idx.last_path()
+            st1 = idx.stats()
+            assert np.array_equal(i0, i1) and np.array_equal(bits(d0), bits(d1)) and np.array_equal(c0, c1)
+            for key in ("queries", "candidates", "bins_nonempty", "ties_final"):
+                assert st0[key] == st1[key], key
+            assert st1["ms_total"] > 0 and st1["ms_rerank"] > 0
+        i2, d2, c2 = idx.query(qs, Bv, 1024, 10)  # wide traversal: not covered
+        assert "one-launch" not in idx.last_path()
+        i3, d3, c3 = idx.query(qs, Bv, Bb, 300)   # k > 128: not covered
+        assert "one-launch" not in idx.last_path()
+    finally:
+        idx.close()
+    g = fixture("cfg3_small")
+    jdx = g.hip_index()
+    try:
+        jdx.set_option("one_launch", 1)
+        jdx.query(g.queries, *BV_BB["cfg3_small"], 10)
+        assert "one-launch" not in jdx.last_path()
+    finally:
+        jdx.close()
+
+
 def test_query_candidates_entry_point_returns_the_whole_sorted_list():
     """pqt_query_candidates by name (oracle-parity entry): the reference's whole sorted candidate list per query,
     true lengths in out_count, lists longer than cap cut after cap entries; a missing out_count is rejected."""
