@@ -40,7 +40,7 @@ int ensureQueryScratch(pqt_index* idx, uint32_t qn) {
   if ((rc = devAlloc(&idx->d_nIncl, (size_t)qn))) return rc;
   if ((rc = devAlloc(&idx->d_ovList, (size_t)qn))) return rc;
   if (!idx->d_ovCount && (rc = devAlloc(&idx->d_ovCount, (size_t)2))) return rc;
-  if ((rc = devAlloc(&idx->d_fbList, (size_t)qn))) return rc;
+  if ((rc = devAlloc(&idx->d_fbList, (size_t)2 * qn))) return rc;  // second half: the list the mid-size pass of the k > 128 path leaves for the block-wide kernel
   if (!idx->d_fbCount && (rc = devAlloc(&idx->d_fbCount, (size_t)2))) return rc;
   if ((rc = devAlloc(&idx->d_tvList, (size_t)qn))) return rc;
   if (!idx->d_tvCount && (rc = devAlloc(&idx->d_tvCount, (size_t)2))) return rc;
@@ -346,6 +346,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const size_t lBig = lBigBase + (bigCL ? coarseBytes : 0);
   bool usedSmallFirst = false;
   bool usedOneLaunch = false;
+  bool usedMid = false;
   idx->nChunks = nChunks;
   idx->ringPos = (int)(idx->calls % kRing);
   idx->ringChunks[idx->ringPos] = nChunks;
@@ -521,7 +522,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (smallFirst) {
         constexpr int SNW = 8;
         const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16;
-        HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
+        HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 8, st));
         PqtRsArgs sa{};
         sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;
         sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr; sa.dbg = idx->dbg & 15u; sa.nIds = idx->nIds;
@@ -529,6 +530,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         if (!(idx->dbg & 32768u)) { if ((rc = launchSmallLists(idx, smallCL, lSmall, sgrid, st, sa, idx->lev0))) return rc; }  // (debug bit: bisecting)
         bigQl = idx->d_fbList; bigQc = idx->d_fbCount;
         bigEv0 = nullptr;
+        // lists of 1025..2048 candidates: second wave-per-query pass (4 wavefronts around 16 KB of keys each), SIFT1M shape
+        const size_t lMid = coarseBytes + (size_t)4 * (d.LP * d.C1 * 4 + 2048 * 8) + 16;
+        if (smallCL && d.LP == 16 && lMid <= kMaxLds && idx->smallLists && !(idx->dbg & (32768u | 131072u))) {
+          sa.qlist = idx->d_fbList; sa.qcount = idx->d_fbCount;
+          if ((rc = launchMidLists(idx, lMid, (uint32_t)idx->numCUs, st, sa, idx->d_fbList + idx->qCap, idx->d_fbCount + 1))) return rc;
+          bigQl = idx->d_fbList + idx->qCap; bigQc = idx->d_fbCount + 1;
+          usedMid = true;
+        }
       }
       if (!(smallFirst && (idx->dbg & 16384u))) {
       if ((rc = launchBigK(idx, bigCL, lBig, nq, st, v, idx->d_nLocal + q0, stride, k, kP2, kcap, oI, oD, oP, bigQl, bigQc, bigEv0, idx->lev1))) return rc;
@@ -585,7 +594,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "");
       else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
       else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "");
-    } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + ((idx->smallLists && (d.LP == 16 || d.LP == 32)) ? "+small-lists" : "");
+    } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + ((idx->smallLists && (d.LP == 16 || d.LP == 32)) ? (usedMid ? "+small-lists+mid-lists" : "+small-lists") : "");
     else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
     idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks) + (usedOneLaunch ? " one-launch" : "");
   }

@@ -148,6 +148,7 @@ int launchRSWGAny(pqt_index* idx, int G, uint32_t nq, hipStream_t st, const floa
                   uint32_t* oI, float* oD, uint32_t* oP);
 // 128 < k <= 4096: wave-per-query evaluate + sort of the short lists, block-wide select of the (listed) rest
 int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, hipEvent_t ev0);
+int launchMidLists(pqt_index* idx, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, uint32_t* outList, uint32_t* outCount);
 int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
                uint32_t kP2, uint32_t kcap, uint32_t* oI, float* oD, uint32_t* oP, const uint32_t* qlist, const uint32_t* qcount, hipEvent_t ev0, hipEvent_t ev1);
 

@@ -3288,8 +3288,12 @@ __device__ __forceinline__ void pqt_wave_sort_lds(uint64_t* sKey) {
 // Three phases per query so that nothing big is live across the network: keys -> LDS (rows of 4 candidates per lane in flight),
 // sort (R keys per lane in registers, nothing else), results read back from LDS in coalesced order.  The first version kept
 // keys, positions and rows in registers across all phases: 256 VGPRs + 2 KB of scratch per lane.)
-template <int NW, int LPV, bool COARSE_LDS>
+// MAXN = 2048, LIST = true is the second pass: the lists of 1025..2048 candidates the first pass set aside (A.qlist / A.qcount), four
+// wavefronts per workgroup around 16 KB of keys each; each half is sorted by the 16-keys-per-lane network and the halves are joined by one
+// bitonic merge level with 32 keys per lane (the second half read back in reverse).  What is longer still goes to bigList.
+template <int NW, int LPV, bool COARSE_LDS, int MAXN = PQT_RSS_MAXN, bool LIST = false>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsArgs A, uint32_t* __restrict__ bigList, uint32_t* __restrict__ bigCount) {
+  static_assert(MAXN == 1024 || MAXN == 2048, "key slots per wavefront");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t LP = LPV * 4;
   const uint32_t C1 = A.prm.C1;
@@ -3299,25 +3303,26 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint64_t* sKey = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * PQT_RSS_MAXN;
-  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * PQT_RSS_MAXN * 8) + (size_t)wave * LP * C1;
-  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * PQT_RSS_MAXN * 8 + (size_t)NW * LP * C1 * 4);
+  uint64_t* sKey = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * MAXN;
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 8) + (size_t)wave * LP * C1;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 8 + (size_t)NW * LP * C1 * 4);
   if (threadIdx.x == 0) sTicket[0] = 0;
   if (COARSE_LDS) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = A.coarse[t];
   __syncthreads();
   const float* cz = COARSE_LDS ? sCoarse : A.coarse;
   const uint32_t G = gridDim.x, k = A.k;
-  const uint32_t L = blockIdx.x < A.qn ? (A.qn - blockIdx.x + G - 1) / G : 0u;  // this workgroup's queries: b, b + G, ...
+  const uint32_t nWork = LIST ? *A.qcount : A.qn;
+  const uint32_t L = blockIdx.x < nWork ? (nWork - blockIdx.x + G - 1) / G : 0u;  // this workgroup's queries (list entries): b, b + G, ...
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(sTicket, 1u);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t >= L) break;
-    const uint32_t q = blockIdx.x + t * G;
+    const uint32_t q = LIST ? A.qlist[blockIdx.x + t * G] : blockIdx.x + t * G;
     const uint32_t n = A.nLocal[q];
     // (no `continue` in this loop: with one, hipcc 7.2 emitted a self-branch spinning on the loop-invariant `n <= 1024` mask for
     // the long-list path -- a hang on the first query with more than 1024 candidates)
-    if (n > PQT_RSS_MAXN) {  // long list: the block-wide kernel takes it
+    if (n > (uint32_t)MAXN) {  // long list: the next pass / the block-wide kernel takes it
       if (lane == 0) bigList[atomicAdd(bigCount, 1u)] = q;
     } else {
     if ((LP * C1) % 4 == 0) {
@@ -3366,14 +3371,25 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
       }
     }
     // ---- phase 2: pad to the network size, sort
-    const uint32_t nSort = n <= 128 ? 128u : n <= 256 ? 256u : n <= 512 ? 512u : 1024u;
+    const uint32_t nSort = n <= 128 ? 128u : n <= 256 ? 256u : n <= 512 ? 512u : n <= 1024 ? 1024u : 2048u;
     for (uint32_t e = n + lane; e < nSort; e += 64) sKey[e] = ~0ull;
     __builtin_amdgcn_wave_barrier();
     if (A.dbg & 2u) {}
     else if (nSort == 128) pqt_wave_sort_lds<2>(sKey);
     else if (nSort == 256) pqt_wave_sort_lds<4>(sKey);
     else if (nSort == 512) pqt_wave_sort_lds<8>(sKey);
-    else pqt_wave_sort_lds<16>(sKey);
+    else if (nSort == 1024) pqt_wave_sort_lds<16>(sKey);
+    else if constexpr (MAXN > 1024) {
+#pragma nounroll
+      for (int h = 0; h < 2; ++h) { pqt_wave_sort_lds<16>(sKey + h * 1024); __builtin_amdgcn_wave_barrier(); }
+      uint64_t key[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) { const uint32_t e = lane * 32 + r; key[r] = sKey[e < 1024u ? e : 3071u - e]; }  // ascending | descending = bitonic
+      __builtin_amdgcn_wave_barrier();
+      pqt_sort_merge<32, 2048, 1024>(key, (int)lane);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sKey[lane * 32 + r] = key[r];
+    }
     __builtin_amdgcn_wave_barrier();
     // ---- phase 3: results in coalesced order, 4 slots per lane in flight; padding behind them
     const uint32_t kk = n < k ? n : k;

@@ -156,6 +156,15 @@ int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStre
   return PQT_OK;
 }
 
+// second pass of the short-list path: lists of 1025..2048 candidates (SIFT1M shape with the coarse table in LDS only)
+int launchMidLists(pqt_index* idx, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, uint32_t* outList, uint32_t* outCount) {
+  auto kern = pqt_k_rerank_sort_small<4, 4, true, 2048, true>;
+  int rc = allowLds(kern, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(4 * 64), (uint32_t)lds, st, sa, outList, outCount);
+  return PQT_OK;
+}
+
 int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
                uint32_t kP2, uint32_t kcap, uint32_t* oI, float* oD, uint32_t* oP, const uint32_t* qlist, const uint32_t* qcount, hipEvent_t ev0, hipEvent_t ev1) {
   const PqtDevParams& d = idx->dp;

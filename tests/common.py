@@ -111,6 +111,8 @@ CONFIGS = {
     "tools_default": dict(D=128, P=2, C1=16, C2=8, W=4, LP=32, n_base=20000, n_query=48, seed=11, heur_rows=1024),
     # BASELINE cfg1/cfg2 shape (SIFT1M d=128 p=4 c1=32 c2=32 lineparts=16), W=2
     "cfg2_small": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=20000, n_query=32, seed=22, heur_rows=4096),
+    # the same shape with three times the vectors: candidate lists of 1025..2048 and beyond at 4096 bins (the k > 128 passes)
+    "cfg2_dense": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=60000, n_query=24, seed=23, heur_rows=4096),
     # uint32 wrap-around of the bin id ((C1*C2)^P = 2^40) and aliased bins, small D for speed
     "wrap": dict(D=32, P=4, C1=32, C2=32, W=1, LP=8, n_base=30000, n_query=32, seed=33, heur_rows=2048),
     # odd sizes: LP not a multiple of 4 (scalar code reads), non-power-of-two everything

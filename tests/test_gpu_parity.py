@@ -1215,21 +1215,30 @@ def test_multi_handle_equals_single_index(name, nsh):
         ref.close()
 
 
-@pytest.mark.parametrize("name,bv", [("tools_default", 300), ("tools_default", 10 ** 6), ("cfg2_small", 10 ** 6), ("cfg3_small", 10 ** 6), ("odd", 400)])
+@pytest.mark.parametrize("name,bv", [("tools_default", 300), ("tools_default", 10 ** 6), ("cfg2_small", 10 ** 6), ("cfg2_dense", 1500), ("cfg2_dense", 10 ** 6), ("cfg3_small", 10 ** 6), ("odd", 400)])
 @pytest.mark.parametrize("k", [129, 600, 4096])
 def test_short_lists_sorted_by_one_wavefront_long_ones_by_the_block_kernel(name, bv, k):
     """128 < k <= 4096: candidate lists of <= 1024 entries are evaluated and sorted by one wavefront (pqt_k_rerank_sort_small), longer
-    ones are handed to the block-wide select kernel -- both against the oracle, and identical to the block-wide kernel alone."""
+    ones are handed on -- 1025..2048 to a second wave-per-query pass at the SIFT1M shape, the rest to the block-wide select kernel --
+    all against the oracle, and identical to the block-wide kernel alone."""
     f = fixture(name)
     idx = f.hip_index()
     try:
         bb = min(CONFIGS[name]["heur_rows"], 1024)
+        if name == "cfg2_dense":
+            bb = 4096  # enough bins for lists of 1025..2048 candidates (bv = 1500: cut after the bin that crosses 1500) and beyond
         ids, dist, cnt = idx.query(f.queries, bv, bb, k)
         path = idx.last_path()
         handed = idx.stats()["filter_fallbacks"]
         if CONFIGS[name]["LP"] in (16, 32):
             assert "+small-lists" in path, path
-            assert handed == int((cnt > 1024).sum()), (handed, cnt)  # exactly the long lists went to the block-wide kernel
+            assert handed == int((cnt > 1024).sum()), (handed, cnt)  # exactly the long lists were set aside by the first pass
+            # SIFT1M shape: a second wave-per-query pass takes the lists of 1025..2048 candidates, the block-wide kernel the rest
+            assert ("+mid-lists" in path) == (name in ("cfg2_small", "cfg2_dense")), path
+            if name == "cfg2_dense":
+                assert int(((cnt > 1024) & (cnt <= 2048)).sum()) > 0, cnt  # the second pass is exercised
+                if bv > 1500:
+                    assert int((cnt > 2048).sum()) > 0, cnt            # and so is the hand-over to the block-wide kernel
         f.oracle.set_sort_mode(1)
         try:
             for qi, q in enumerate(f.queries):
