@@ -12,7 +12,7 @@ from common import CONFIGS, fixture, pqt_pkg
 
 pytestmark = pytest.mark.gpu
 
-BV_BB = {"tools_default": (2000, 500), "cfg2_small": (300, 500), "wrap": (100, 1000), "odd": (400, 144), "ties": (500, 400), "big_coarse": (600, 64), "cfg3_small": (400, 500)}
+BV_BB = {"tools_default": (2000, 500), "cfg2_small": (300, 500), "cfg2_dense": (1500, 800), "wrap": (100, 1000), "odd": (400, 144), "ties": (500, 400), "big_coarse": (600, 64), "cfg3_small": (400, 500)}
 
 
 def bits(a):
