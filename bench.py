@@ -752,7 +752,7 @@ def main():
         try:
             gbs_ = ctx.pkg.stream_read_GBps(4 << 30, 5, dev.index or 0)
             out["roofline"]["measured_stream_GBps"] = gbs_
-            out["roofline"]["measured_stream_what"] = "read-only kernel, 16-byte loads, every byte of a 4 GiB buffer once (pqt_debug_stream_read)"
+            out["roofline"]["measured_stream_what"] = "read-only kernel, 16-byte loads, every byte of a 4 GiB buffer once; best of 15 launch shapes (4/8/16 loads in flight, grid-stride or contiguous share per workgroup, 8/16/32 workgroups per CU: pqt_debug_stream_read)"
             out["roofline"]["frac_of_measured_stream"] = out["roofline"]["achieved"] / gbs_
         except Exception as e:
             out["roofline"]["measured_stream_GBps"] = None
@@ -906,7 +906,15 @@ def main():
                 idx.close()
                 del W, R, idx, queries, out_idx, out_dist, out_cnt, raw_u8
                 torch.cuda.empty_cache()
-                out["config"]["hbm_roofline_leg"] = hbm_roofline_leg(ctx, args)
+                leg_ = hbm_roofline_leg(ctx, args)
+                gbs_ = out["roofline"].get("measured_stream_GBps")
+                if gbs_:
+                    for kk_ in ("knobs_20000_500", "knobs_4096_4096"):
+                        r_ = (leg_.get(kk_) or {}).get("roofline")
+                        if r_:
+                            r_["measured_stream_GBps"] = gbs_
+                            r_["frac_of_measured_stream"] = r_["achieved"] / gbs_
+                out["config"]["hbm_roofline_leg"] = leg_
             except Exception as e:
                 out["config"]["hbm_roofline_leg"] = {"error": repr(e)[:300]}
     if rank == 0:

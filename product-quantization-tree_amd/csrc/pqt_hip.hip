@@ -1385,14 +1385,27 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms) {
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   if (e == hipSuccess) {
-    const unsigned grid = (unsigned)std::max(1, prop.multiProcessorCount) * 16u;
-    hipLaunchKernelGGL(pqt_k_stream_read, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);  // warm-up
-    e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipEventRecord(e0, 0);
-    for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(pqt_k_stream_read, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);
-    if (e == hipSuccess) e = hipEventRecord(e1, 0);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    // the best of a few launch shapes (loads in flight per lane x grid-stride / contiguous share per workgroup x workgroups per CU):
+    // which one wins differs between boxes by a few per cent, and the probe is meant to say what the memory system gives a plain reader
+    using Kern = void (*)(const uint4*, uint64_t, unsigned long long*);
+    const Kern kerns[] = {pqt_k_stream_read<4, false>, pqt_k_stream_read<8, false>, pqt_k_stream_read<16, false>, pqt_k_stream_read<8, true>, pqt_k_stream_read<16, true>};
+    const unsigned perCu[] = {8u, 16u, 32u};
+    float best = 0.f;
+    for (const Kern kern : kerns) {
+      for (const unsigned wpc : perCu) {
+        const unsigned grid = (unsigned)std::max(1, prop.multiProcessorCount) * wpc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);  // warm-up
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipEventRecord(e0, 0);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const uint4*)buf, bytes / 16, sink);
+        if (e == hipSuccess) e = hipEventRecord(e1, 0);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (e == hipSuccess && (best == 0.f || t < best)) best = t;
+      }
+    }
+    ms = best;
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

@@ -2757,15 +2757,35 @@ __global__ __launch_bounds__(256) void pqt_k_calib_gather(const uint4* __restric
 // read-only streaming probe: every 16-byte piece of a buffer exactly once, four independent loads per lane in flight (the
 // access shape of the group-major rerank: 64 lanes = one contiguous KB).  bench.py reports its GB/s beside the nominal peak.
 #ifdef PQT_MAIN_TU
+// U 16-byte loads in flight per lane.  CHUNK = false: grid-stride (consecutive workgroups read consecutive 4 KB pieces, a workgroup's next
+// piece is gridDim * 4 KB further); CHUNK = true: a workgroup walks its own contiguous share.
+template <int U, bool CHUNK>
 __global__ __launch_bounds__(256) void pqt_k_stream_read(const uint4* __restrict__ p, uint64_t n16, unsigned long long* __restrict__ sink) {
-  const uint64_t stride = (uint64_t)gridDim.x * 256;
-  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   uint32_t acc = 0;
-  for (; i + 3 * stride < n16; i += 4 * stride) {
-    const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-    acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+  if constexpr (CHUNK) {
+    const uint64_t per = (n16 + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    uint64_t i = lo + threadIdx.x;
+    for (; i + (uint64_t)(U - 1) * 256 < hi; i += (uint64_t)U * 256) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = p[i + (uint64_t)u * 256];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < hi; i += 256) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+  } else {
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + (uint64_t)(U - 1) * stride < n16; i += (uint64_t)U * stride) {
+      uint4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = p[i + (uint64_t)u * stride];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   }
-  for (; i < n16; i += stride) { const uint4 a = p[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
   if (acc == 0x12345678u) atomicAdd(sink, 1ull);  // keeps the loads alive
 }
 #endif  // PQT_MAIN_TU
