@@ -405,7 +405,7 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period):
     out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
     sbuf = engine = None
     if mode == "shard_db":
-        sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev)
+        sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
         engine = ctx.sharding.PqtShardEngine(idx)
 
     def step():

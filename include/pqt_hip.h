@@ -242,7 +242,7 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bo
  * treequantizer::query (treequantizer.hpp:323-350): id + segmentInfo + orderBins + the cut of rerankVectors (:450-477).
  *   out_bins_dev[qn][cap + 1] u64, shard independent: entry i of a row = bin id | (global visiting position of the bin's first
  *   member << 32) of the i-th included populated bin in visiting order; the trailer word [cap] = number of entries | (global
- *   candidate count << 32).  A count of 0xffffffff marks a query whose list does not fit `cap` entries (1 <= cap <= 128), or
+ *   candidate count << 32).  A count of 0xffffffff marks a query whose list does not fit `cap` entries (1 <= cap <= 256), or
  *   that the fused traversal could not finish: pqt_query_shard_bins traverses such queries itself.  Sharded indices only. */
 int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t cap,
                       unsigned long long* out_bins_dev, void* hip_stream, int sync);

@@ -412,9 +412,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                                    emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
                                    countDirect ? outCount + q0 : nullptr, idx->d_tvList, idx->d_tvCount, schedCntArg, idx->d_schedList, idx->curSchedCap};
         const size_t lTR = (size_t)(PQT_L1V_QB * d.D + d.LP * d.C1) * 4;
-        if ((rc = allowLds(pqt_k_tables_resolve<4>, lTR))) return rc;
+        auto trKern = binsCap > 128u ? pqt_k_tables_resolve<4, 4> : pqt_k_tables_resolve<4, 2>;  // list entries per lane of the resolving wavefront
+        if ((rc = allowLds(trKern, lTR))) return rc;
         const uint32_t nResolve = (nq + 3) / 4, nTab = (nq + PQT_L1V_QB - 1) / PQT_L1V_QB;
-        hipExtLaunchKernelGGL(pqt_k_tables_resolve<4>, dim3(nResolve + nTab), dim3(PQT_BLOCK), (uint32_t)lTR, st, idx->lev0, nullptr, 0u, rargs, nTab,
+        hipExtLaunchKernelGGL(trKern, dim3(nResolve + nTab), dim3(PQT_BLOCK), (uint32_t)lTR, st, idx->lev0, nullptr, 0u, rargs, nTab,
                               q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb1L, d, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1);
         targs.qlist = idx->d_tvList; targs.qcount = idx->d_tvCount;
         launchFusedTraversal(idx, targs, tplan, nq, st, nullptr, idx->lev1);
@@ -1175,7 +1176,7 @@ int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t 
                       unsigned long long* out_bins_dev, void* stream, int sync) {
   if (!idx || !out_bins_dev || (qn && !q_dev)) return fail(PQT_ERR_INVALID, "null argument");
   if (!idx->sharded) return fail(PQT_ERR_INVALID, "pqt_traverse_bins needs a range-sharded index (pqt_index_set_bins_shard / _local)");
-  if (cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_LIMIT, "bin-list capacity must be 1..128");
+  if (cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_LIMIT, "bin-list capacity must be 1..256");
   if (!idx->haveTree || !idx->haveBins || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic and bins before traversing");
   if (qn == 0) return PQT_OK;
   int rc = setDevice(idx);
@@ -1210,7 +1211,7 @@ int pqt_query_shard_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32
                          const unsigned long long* bins_dev, uint32_t cap, uint32_t* outIdx, float* outDist, uint32_t* outPos,
                          uint32_t* outCount, void* stream, int sync) {
   if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard / _local");
-  if (!bins_dev || cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_INVALID, "bin lists missing or capacity outside 1..128");
+  if (!bins_dev || cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_INVALID, "bin lists missing or capacity outside 1..256");
   return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync, bins_dev, cap);
 }
 

@@ -2601,11 +2601,11 @@ struct PqtResolveArgs {
   uint32_t* tvList; uint32_t* tvCount;
   uint32_t* schedCnt; unsigned long long* schedList; uint32_t schedCap;
 };
-#define PQT_GBIN_MAX 128  // largest per-query list pqt_resolve_block accepts (2 entries per lane)
-template <int NW>
+#define PQT_GBIN_MAX 256  // largest per-query list pqt_resolve_block accepts (EPL = 4 entries per lane; 2 for lists of <= 128)
+template <int NW, int EPL>
 __device__ __forceinline__ void pqt_resolve_block(const PqtResolveArgs& A, uint32_t blk) {
-  __shared__ unsigned long long sBinAll[NW][PQT_GBIN_MAX];
-  __shared__ uint32_t sGposAll[NW][PQT_GBIN_MAX];
+  __shared__ unsigned long long sBinAll[NW][64 * EPL];
+  __shared__ uint32_t sGposAll[NW][64 * EPL];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint32_t q = blk * NW + wave;
   if (q >= A.qn) return;
@@ -2619,11 +2619,11 @@ __device__ __forceinline__ void pqt_resolve_block(const PqtResolveArgs& A, uint3
     return;
   }
   const uint4* table4 = reinterpret_cast<const uint4*>(A.table);
-  uint32_t ls[2], lc[2], gp[2];
+  uint32_t ls[EPL], lc[EPL], gp[EPL];
   uint32_t myLocal = 0, myBins = 0;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const uint32_t e = lane * 2 + r;  // blocked: the wave scans below run in entry (= visiting) order
+  for (int r = 0; r < EPL; ++r) {
+    const uint32_t e = lane * EPL + r;  // blocked: the wave scans below run in entry (= visiting) order
     ls[r] = 0; lc[r] = 0; gp[r] = 0;
     if (e < m) {
       const unsigned long long ent = row[e];
@@ -2641,7 +2641,7 @@ __device__ __forceinline__ void pqt_resolve_block(const PqtResolveArgs& A, uint3
   const uint32_t mL = __shfl(nbIncl, 63, 64);  // listed bins with members on this shard
   uint32_t wpos = nbIncl - myBins;
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < EPL; ++r) {
     if (lc[r]) { sBin[wpos] = (unsigned long long)lrun | ((unsigned long long)ls[r] << 32); sGpos[wpos] = gp[r]; ++wpos; lrun += lc[r]; }
   }
   __builtin_amdgcn_wave_barrier();
@@ -2689,14 +2689,14 @@ __device__ __forceinline__ void pqt_resolve_block(const PqtResolveArgs& A, uint3
 // one launch for both halves of the receiving side: the first nTab workgroups compute the distance tables (store-bound, fewer than the
 // chip holds at once), the rest resolve the bin lists (latency chains: table look-up, scans, run write-out) and start beside them --
 // two independent jobs that used to queue behind each other
-template <int NW>
+template <int NW, int EPL>
 __global__ __launch_bounds__(NW * 64) void pqt_k_tables_resolve(const PqtResolveArgs A, uint32_t nTab, const float* __restrict__ Q,
                                                                  const float* __restrict__ cb1, const float* __restrict__ cb1L,
                                                                  const PqtDevParams prm, float* __restrict__ qL1virt) {
   static_assert(NW * 64 == PQT_BLOCK, "the table half strides by PQT_BLOCK");
   extern __shared__ __attribute__((aligned(16))) float smem[];  // PQT_L1V_QB * D + LP * C1 floats
   if (blockIdx.x < nTab) pqt_l1virt_block<PQT_L1V_QB>(Q, cb1, cb1L, prm, qL1virt, A.qn, blockIdx.x, smem);
-  else pqt_resolve_block<NW>(A, blockIdx.x - nTab);
+  else pqt_resolve_block<NW, EPL>(A, blockIdx.x - nTab);
 }
 
 // marks every query of a pqt_traverse_bins request as "traverse it yourself" (shapes the fused traversal does not cover)

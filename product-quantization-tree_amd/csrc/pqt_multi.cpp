@@ -17,7 +17,9 @@
 #include "../../include/pqt_hip.h"
 
 namespace {
-constexpr uint32_t kBinCap = 128;  // per-query capacity of the exchanged bin lists (pqt_traverse_bins: 1..128)
+// per-query capacity of the exchanged bin lists (pqt_traverse_bins: 1..256): 128 for the short traversal, 256 for the wide one (bound_bins > 512),
+// whose lists are longer -- a list beyond the capacity makes every shard traverse that query itself
+inline uint32_t binCapFor(uint32_t Bb) { return Bb > 512u ? 256u : 128u; }
 
 // error text of this translation unit; pqt_multi_last_error() falls back to pqt_last_error() for failures of the shard calls
 thread_local std::string g_merr;
@@ -205,6 +207,7 @@ int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv,
   if (qn == 0) return PQT_OK;
   const int n = m->n;
   const uint32_t D = m->prm.dim;
+  const uint32_t kBinCap = binCapFor(Bb);
   const size_t wordsPack = (size_t)3 * qn * k, wordsBins = (size_t)qn * (kBinCap + 1);
   for (int s = 0; s < n; ++s) {
     int rc;

@@ -25,7 +25,12 @@ so the same code drives the HIP library (PqtShardEngine below) and, in the CPU t
 import torch
 
 
-BIN_CAP = 128  # per-query capacity of the exchanged bin lists (pqt_traverse_bins accepts 1..128); a longer list falls back
+BIN_CAP = 128  # default per-query capacity of the exchanged bin lists (pqt_traverse_bins accepts 1..256; bin_cap_for()); a longer list falls back
+
+
+def bin_cap_for(bb):
+    """Capacity to exchange for a call with bound_bins = bb: the wide traversal (bb > 512) lists more bins per query."""
+    return 256 if bb > 512 else BIN_CAP
 
 
 def shard_range(rank, world, n):
@@ -87,7 +92,7 @@ class ShardBuffers:
     32-bit words (idx | dist bits | global visiting position; qs = ceil(qn / W) queries per slice, the rows beyond qn are
     permanent padding: idx 0xffffffff, dist +inf), written in place by the shard kernels."""
 
-    def __init__(self, world, qn, k, device):
+    def __init__(self, world, qn, k, device, bin_cap=None):
         i32 = torch.int32
         self.world, self.qn, self.k = world, qn, k
         self.qs = qs = (qn + world - 1) // world
@@ -111,8 +116,9 @@ class ShardBuffers:
         self.out_idx, self.out_dist = self.out_idx_pad[:qn], self.out_dist_pad[:qn]
         # traversal = "sharded": this rank's bin lists of its query slice, and everybody's after the all-gather.  Rows of the
         # padding queries beyond qn stay zero (an empty list: trailer count 0).
-        self.bins_local = torch.zeros((qs, BIN_CAP + 1), dtype=torch.int64, device=device)
-        self.bins_all = torch.zeros((world * qs, BIN_CAP + 1), dtype=torch.int64, device=device)
+        self.bin_cap = int(BIN_CAP if bin_cap is None else bin_cap)
+        self.bins_local = torch.zeros((qs, self.bin_cap + 1), dtype=torch.int64, device=device)
+        self.bins_all = torch.zeros((world * qs, self.bin_cap + 1), dtype=torch.int64, device=device)
 
 
 def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False, traversal="replicated", rank=None):
@@ -137,13 +143,13 @@ def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", f
             rank = dist.get_rank() if (world > 1 or force_collectives) else 0
         lo, hi = min(rank * qs, qn), min((rank + 1) * qs, qn)
         if hi > lo:
-            engine.traverse_bins(q[lo:hi], bv, bb, BIN_CAP, buf.bins_local)
+            engine.traverse_bins(q[lo:hi], bv, bb, buf.bin_cap, buf.bins_local)
         if world == 1 and not force_collectives:
             bins = buf.bins_local
         else:
             dist.all_gather_into_tensor(buf.bins_all, buf.bins_local)
             bins = buf.bins_all
-        engine.query_shard_bins(q, bv, bb, k, bins, BIN_CAP, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
+        engine.query_shard_bins(q, bv, bb, k, bins, buf.bin_cap, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
     else:
         engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
     if world == 1 and not force_collectives:

@@ -40,7 +40,7 @@ for r, (lo, hi) in enumerate(ranges[:n_sh]):
 torch.cuda.synchronize()
 out = {"workload": "N=%d (configs[2] shape), 8 range shards (%d measured) on one device, %d queries per batch, k=%d" % (n, n_sh, qn, k), "knobs": {}}
 oi = torch.empty((qn, k), dtype=torch.int32, device=dev); od = torch.empty((qn, k), dtype=torch.float32, device=dev); oc = torch.empty(qn, dtype=torch.int32, device=dev)
-cap, qs = sharding.BIN_CAP, (qn + world - 1) // world
+cap_env, qs = os.environ.get("PQT_SHARD_BINCAP"), (qn + world - 1) // world  # bin-list capacity: default = what sharding.bin_cap_for picks per knob set
 
 
 def timed(fn, reps=8):
@@ -53,6 +53,7 @@ def timed(fn, reps=8):
 
 
 for bv, bb in ((20000, 500), (4096, 4096)):
+    cap = int(cap_env) if cap_env else sharding.bin_cap_for(bb)
     step1 = timed(lambda: idx.query_dev(queries, bv, bb, k, oi, od, oc, stream=st.cuda_stream))
     h = idx.stage_ms_history(3).mean(0)
     pack = torch.empty((world, 3, qn, k), dtype=torch.int32, device=dev); Cc = torch.empty((world, qn), dtype=torch.int32, device=dev)

@@ -120,18 +120,17 @@ def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", b
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sh = __import__("importlib").import_module("product-quantization-tree_amd.sharding")
-        if bin_cap:
-            sh.BIN_CAP = bin_cap  # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
         fx = fixture("odd")
         n = fx.oracle.num_vectors
         lo, hi = sh.shard_range(rank, world, n)
         eng = OracleShardEngine(fx, lo, hi)
         queries = torch.from_numpy(fx.queries[:7])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded
         k, bv, bb = 20, 300, 100
-        buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu")
+        # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
+        buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
         oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange, traversal=traversal)
         if traversal == "sharded":
-            trailer = buf.bins_all[:queries.shape[0], sh.BIN_CAP].numpy().view(np.uint64) & np.uint64(0xffffffff)
+            trailer = buf.bins_all[:queries.shape[0], buf.bin_cap].numpy().view(np.uint64) & np.uint64(0xffffffff)
             over = int((trailer == 0xffffffff).sum())
             assert (over > 0) == bool(bin_cap), (over, bin_cap)  # the fallback is exercised exactly when the capacity is small
         ok = True

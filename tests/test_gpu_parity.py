@@ -1096,7 +1096,7 @@ def test_query_candidates_entry_point_returns_the_whole_sorted_list():
 
 
 @pytest.mark.parametrize("name", ["tools_default", "cfg2_small", "cfg3_small", "wrap", "odd", "ties", "big_coarse"])
-@pytest.mark.parametrize("cap", [128, 3])
+@pytest.mark.parametrize("cap", [128, 3, 256])
 def test_query_sharded_traversal_equals_replicated_traversal(name, cap):
     """pqt_traverse_bins on ONE shard + pqt_query_shard_bins on EVERY shard == pqt_query_shard (each shard traversing itself):
     ids, distance bits, global visiting positions, counts.  The bin lists are shard independent (every shard writes the same
