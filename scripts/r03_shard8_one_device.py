@@ -4,7 +4,7 @@ index built from the shard's side like the multi-GPU bench does.  Per shard and 
   query-sharded        : pqt_traverse_bins over the shard's query slice (QN/8 queries) + pqt_query_shard_bins over the full batch
                          (distance tables + bin-list resolution stage, rerank/select stage), results identical to the above
 plus the merge of one query slice / of all queries, and the unsharded index on the same device as the denominator.  No
-collective is timed here (the all-gather of the bin lists moves (128 + 1) x 8 B per query: 10 MB per batch in total).
+collective is timed here (the all-gather of the bin lists moves (128 + 1) x 8 B per query: 10 MB per batch in total; (256 + 1) x 8 B at bound_bins > 512).
     PQT_SHARD_WORKLOAD=synth10m|synth100m python scripts/r03_shard8_one_device.py
     PQT_TSTAMP=1 ... additionally prints the per-query phase clocks of shard 0's rerank (instrumented kernel: slower)"""
 import importlib, json, os, sys, time
