@@ -95,8 +95,8 @@ int pqt_index_params(const pqt_index* idx, pqt_params* out);
  * "one_launch" = 1 (SIFT1M shape, bound_bins <= 512, k <= 128, unsharded): traversal and rerank/select of a query by the same
  * wavefront in one launch (pqt_k_query_fused).  Off by default: measured 0.191 against 0.167 ms per 10 k queries.  Same results.
  * "wg_rerank" = 0 disables the workgroup-per-query rerank kernel for large first-level codebooks (tuning).
- * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache, 1
- * otherwise; 2 = per-XCD query pools in longest-first order (the traversal
+ * "balance" = schedule of the wave-per-query rerank: -1 (default) = 2 for line stores beyond the 256 MiB Infinity Cache and
+ * for the filtered rerank (coarse table too large for the LDS), 1 otherwise; 2 = per-XCD query pools in longest-first order (the traversal
  * registers every query under its size class), a share dealt out statically and the rest drawn in shrinking chunks, other
  * pools' leftovers when the own is empty; 1 = a fixed share per workgroup whose wavefronts draw it longest-first through an
  * LDS ticket; 0 = static round-robin.  It only changes the schedule, never a result.

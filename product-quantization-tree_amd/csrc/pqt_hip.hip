@@ -374,7 +374,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     // automatic choice: the global pools pay for their registration atomics and chunk draws when a query brings thousands of
     // candidates from an HBM-resident store (configs[2]/[3]: -8..-10 % on the rerank launch); with a cache-resident store and
     // a few hundred candidates per query the fixed share per workgroup is 1-2 % ahead (SIFT1M shape)
-    const int balance = idx->balance >= 0 ? idx->balance : ((size_t)idx->nIds * d.LP * 4 > ((size_t)256 << 20) ? 2 : 1);
+    // (round 3: the filtered rerank also prefers the pools on a cache-resident store -- 160 MB shard of the 8-way 10 M layout: 0.334 -> 0.318 ms)
+    const int balance = idx->balance >= 0 ? idx->balance : ((useBias || (size_t)idx->nIds * d.LP * 4 > ((size_t)256 << 20)) ? 2 : 1);
     const bool useSched = severalPerWave && balance == 2;
     uint32_t* const schedCntArg = useSched ? poolBlock(idx, idx->poolPos) + 16 : nullptr;
     if (useSched) {
