@@ -830,7 +830,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   const uint32_t* __restrict__ codes = A.codes; const uint32_t* __restrict__ ids = A.ids; const float* __restrict__ qL1virt = A.qL1virt;
   const uint32_t* __restrict__ cand = A.cand; const uint32_t* __restrict__ candPos = A.candPos; const uint32_t* __restrict__ nLocal = A.nLocal;
   const uint64_t stride = A.stride; const uint32_t k = A.k; uint32_t* __restrict__ outIdx = A.outIdx; float* __restrict__ outDist = A.outDist;
-  uint32_t* __restrict__ outPos = A.outPos; unsigned long long* __restrict__ counters = A.counters; const uint32_t dbg = A.dbg;
+  uint32_t* __restrict__ outPos = A.outPos; const uint32_t dbg = A.dbg;
   unsigned long long* __restrict__ tstamp = A.tstamp;
   (void)candPos; (void)outPos; (void)cz;
   // U candidates per lane are in flight together (16 code vectors = 64 VGPRs): the id -> row -> table chain of
