@@ -306,13 +306,35 @@ class Ctx:
     pass
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: re-execute the very same command line under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port).  Rank 0 prints the one JSON line; the
+    launcher passes the ranks' stdout/stderr through.  The torchrun form of the docstring keeps working (WORLD_SIZE is set then)."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("PQT_BENCH_SAME_DEVICE"):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (PQT_BENCH_SAME_DEVICE=1 + PQT_BENCH_BACKEND=gloo runs all ranks on device 0: a functional check)"
+                         % (args.gpus, have))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PQT_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] --gpus %d without a rank environment: re-executing under torch.distributed.run (port %d)" % (args.gpus, port))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def init_ctx(args):
     c = Ctx()
     c.world = int(os.environ.get("WORLD_SIZE", "1"))
     c.rank = int(os.environ.get("RANK", "0"))
     c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != c.world and c.world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("internal: --gpus %d reached init_ctx without ranks (self_launch() should have re-executed the command)" % args.gpus)
     c.dist = None
     c.backend = None
     # PQT_BENCH_FORCE_SHARD=1: run the range-sharded layout with whatever world size there is -- with one rank this drives
@@ -396,24 +418,43 @@ def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
                 chunked=w.get("chunk", n) < n, mode=mode, qn=qn)
 
 
-def time_path(ctx, args, W, bv, bb, k, steps, warmup, period):
+def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
     """W warm-up steps, then exactly `steps` timed steps of the hot path between barriers (+ device synchronisation); the
-    per-kernel HIP events ride on every period-th call.  Returns the timing, the stage means and the outputs."""
+    per-kernel HIP events ride on every period-th call.  Returns the timing, the stage means and the outputs.
+    Range-sharded mode: pipeline = 2 (default, --pipeline) runs every step as two half batches in flight (sharding.py:
+    sharded_query_pipelined -- half B's kernels under half A's collectives), 1 as one batch; the collectives of the event-carrying
+    steps are bracketed by HIP events (exchange_ms)."""
     idx, queries, qn, dev, mode = W["idx"], W["queries"], W["qn"], ctx.dev, W["mode"]
     out_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
     out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
-    sbuf = engine = None
+    sbuf = engine = timer = view = None
+    pipeline = (args.pipeline if pipeline is None else pipeline) if (mode == "shard_db" and qn >= 2) else 1
     if mode == "shard_db":
-        sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
+        timer = ctx.sharding.ExchangeTimer(cuda=True)
         engine = ctx.sharding.PqtShardEngine(idx)
+        if pipeline >= 2:
+            if "view" not in W:
+                W["view"] = idx.view()
+            view = W["view"]
+            sbuf = ctx.sharding.PipelineBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
+            engines = (engine, ctx.sharding.PqtShardEngine(view))
+        else:
+            sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
+    calls = [0]
 
     def step():
         if mode != "shard_db":
             idx.query_dev(queries, bv, bb, k, out_idx, out_dist, out_cnt, stream=ctx.stream)
+            return
+        timer.on = calls[0] % period == 0  # the calls that carry the library's per-kernel events also carry the exchange events
+        calls[0] += 1
+        if pipeline >= 2:
+            ctx.sharding.sharded_query_pipelined(engines, ctx.dist, ctx.world, queries, bv, bb, k, sbuf, exchange=args.exchange, force_collectives=ctx.force_shard,
+                                                 traversal=args.traversal, timer=timer)
         else:
             ctx.sharding.sharded_query(engine, ctx.dist, ctx.world, queries, bv, bb, k, sbuf, exchange=args.exchange, force_collectives=ctx.force_shard,
-                                       traversal=args.traversal)
+                                       traversal=args.traversal, timer=timer)
 
     # per-kernel HIP events on every P-th call (the first call after the option is set is a timed one): the timed region holds
     # the calls warmup .. warmup + steps - 1
@@ -422,6 +463,8 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period):
     if not timed_in_region:
         period, timed_in_region = 1, list(range(steps))
     idx.set_option("stage_timing", period)
+    if view is not None:
+        view.set_option("stage_timing", period)
     elapsed = time_steps(step, lambda: barrier(ctx), warmup, steps)
     idx.set_option("stage_timing", 1)  # later legs time every call
     if mode == "shard_db":
@@ -433,14 +476,34 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period):
     hist = idx.stage_ms_history(min(len(timed_in_region), 32))
     st = idx.stats()
     stage = dict(zip(STAGES, hist.mean(0).tolist())) if hist.shape[0] else dict.fromkeys(STAGES, 0.0)
+    path = idx.last_path()
+    if view is not None:
+        # two half batches: a kernel's time per step is the sum over the halves (they overlap in time); statistics likewise
+        h2 = view.stage_ms_history(min(len(timed_in_region), 32))
+        if h2.shape[0]:
+            for n_, v_ in zip(STAGES, h2.mean(0).tolist()):
+                stage[n_] += v_
+        st2 = view.stats()
+        for n_ in ("queries", "candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_bins", "ties_final", "filter_fallbacks"):
+            st[n_] = st[n_] + st2[n_]
+        view.set_option("stage_timing", 0)
+        path += " | two half batches in flight"
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if ctx.collectives:
         ctx.dist.all_reduce(tmax, op=ctx.dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     units = qn * (ctx.world if mode == "replica" else 1)  # queries answered by the whole job per step
+    exchange_ms = per_rank = None
+    if mode == "shard_db":
+        exchange_ms = timer.means_ms()
+        mine = {"rank": ctx.rank, "stage_ms": stage, "exchange_ms": exchange_ms, "candidates": int(st["candidates"])}
+        per_rank = [mine]
+        if ctx.collectives:
+            per_rank = [None] * ctx.world
+            ctx.dist.all_gather_object(per_rank, mine)
     return dict(elapsed=elapsed, steps=steps, warmup=warmup, qps=units * steps / elapsed, ms_per_step=elapsed / steps * 1e3, units=units, stage=stage, st=st,
                 out_idx=out_idx, out_dist=out_dist, out_cnt=out_cnt, sbuf=sbuf, step=step, period=period, n_timed=len(timed_in_region), bv=bv, bb=bb, k=k,
-                path=idx.last_path())
+                path=path, exchange_ms=exchange_ms, per_rank=per_rank, pipeline=pipeline)
 
 
 def roofline_block(ctx, args, W, R):
@@ -547,6 +610,11 @@ def make_line(ctx, args, W, R):
                                    "shard_db": shard_par}[mode],
                    "exchange": args.exchange if mode == "shard_db" else None,
                    "traversal": args.traversal if mode == "shard_db" else None,
+                   # range-sharded run: mean device time of each collective of a step (HIP events on the issuing stream around the call, on the
+                   # steps that also carry the per-kernel events; with two half batches in flight: per half-batch call), this rank and all ranks
+                   "pipeline": ("two half batches in flight (half B's kernels run under half A's collectives)" if R["pipeline"] >= 2 else "one batch per step") if mode == "shard_db" else None,
+                   "exchange_ms": R["exchange_ms"],
+                   "per_rank_stage_ms": R["per_rank"],
                    "collective_backend": ({"nccl": "rccl"}.get(ctx.backend, ctx.backend) if ctx.collectives else None), "collective_world_size": world,
                    "options": args.option,
                    "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call; the events cost ~10 us per call)"
@@ -662,6 +730,9 @@ def main():
                     help="range-sharded run: per-shard top-k exchanged by query slice (all-to-all, merged slices all-gathered) or by one all-gather of the whole lists")
     ap.add_argument("--traversal", default=None, choices=["sharded", "replicated"],
                     help="range-sharded run: traversal sharded by queries with one all-gather of the per-query bin lists (default) or replicated on every rank")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
+                    help="range-sharded run: 2 = every step as two half batches in flight on two streams (the collectives of one half hide behind the kernels of "
+                         "the other), 1 = one batch per step; the line carries the other variant's step time as config.pipeline_ab")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
     ap.add_argument("--no-scaling-leg", action="store_true", help="--gpus 8 default (synth1b): skip the synth100m strong-scaling leg of the sweep")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")
@@ -676,6 +747,8 @@ def main():
     ap.add_argument("--center-scale", type=float, default=GEN["center_scale"])
     ap.add_argument("--query-mode", default="fresh", choices=["fresh", "perturbed"])
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     ctx = init_ctx(args)
     world, rank, dev, dist = ctx.world, ctx.rank, ctx.dev, ctx.dist
     if args.traversal is None:
@@ -875,6 +948,15 @@ def main():
     if mode == "shard_db":
         out["config"]["same_workload_1gpu"] = ref1 = same_workload_1gpu(ctx, args, W, R)
         out["config"]["ranks_agree"] = ranks_agree(ctx, R)  # every rank must hold the same merged result
+        try:  # the other schedule on the same index and batch, a few steps: what the half batches in flight buy (or cost)
+            other = 1 if R["pipeline"] >= 2 else 2
+            Ro = time_path(ctx, args, W, args.bv, args.bb, k, max(3, min(args.steps, 10)), 2, args.timing_period, pipeline=other)
+            out["config"]["pipeline_ab"] = {"this_line": "pipeline=%d" % R["pipeline"], "other": "pipeline=%d" % other, "other_ms_per_step": Ro["ms_per_step"],
+                                            "other_queries_per_sec": Ro["qps"], "other_exchange_ms": Ro["exchange_ms"],
+                                            "results_identical": bool(torch.equal(Ro["out_idx"], R["out_idx"]) and torch.equal(Ro["out_dist"], R["out_dist"]) and torch.equal(Ro["out_cnt"], R["out_cnt"]))}
+            del Ro
+        except Exception as e:
+            out["config"]["pipeline_ab"] = {"error": repr(e)[:300]}
         if ref1 and "speedup_of_this_run" in ref1:
             out["scaling_vs_1gpu"] = ref1["speedup_of_this_run"]
             out["scaling_vs_1gpu_what"] = "this line's queries/sec / the same database and batch on ONE GPU (config.same_workload_1gpu, timed on rank 0 in this run)"

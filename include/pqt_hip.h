@@ -82,6 +82,15 @@ int pqt_device_count(void);
 int pqt_index_create(const pqt_params* prm, int device, pqt_index** out);
 void pqt_index_destroy(pqt_index* idx);
 int pqt_index_params(const pqt_index* idx, pqt_params* out);
+/* A second handle on the SAME loaded index for a second batch in flight (a handle serves one batch at a time): the view shares
+ * every array of `owner` (tree, heuristic, bins, line store and what the owner derives from them) and owns only scratch, a
+ * stream and statistics, so two batches -- or the two halves of one (sharding.py: half B's kernels run under half A's
+ * collectives) -- can be enqueued on two streams.  A view re-reads the owner's state at every call; it never builds shared data
+ * itself: the owner must have served one call of the same kind before (PQT_ERR_STATE otherwise).  Query entry points only
+ * (pqt_query*, pqt_traverse_bins, pqt_query_shard_bins, statistics, "stage_timing"); loading into a view is an error.
+ * Destroyed by pqt_index_destroy(view) or with the owner.  The reference has no counterpart (one batch at a time on the
+ * default stream, PerturbationProTree.cu:8179-8321). */
+int pqt_index_create_view(pqt_index* owner, pqt_index** out);
 /* tuning/debug options: "fused" = 1 (default) use the wave-per-query fused kernels (traversal; rerank+select) when
  * the request fits them, 0 = always use the workgroup-per-query staged kernels (which also keep the stage
  * intermediates readable by pqt_debug_read). Results are identical either way.

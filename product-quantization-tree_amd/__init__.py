@@ -41,7 +41,7 @@ class pqt_stats(C.Structure):
 
 # every symbol include/pqt_hip.h declares (checked by the CPU test-suite against the built library)
 EXPORTS = [
-    "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params",
+    "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params", "pqt_index_create_view",
     "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather", "pqt_rerank_exact",
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_build_heuristic_cuda", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
@@ -78,6 +78,7 @@ def lib():
     L.pqt_index_destroy.argtypes = [C.c_void_p]
     L.pqt_index_destroy.restype = None
     L.pqt_index_params.argtypes = [C.c_void_p, C.POINTER(pqt_params)]
+    L.pqt_index_create_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.pqt_index_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.pqt_debug_tstamps.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.pqt_index_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
@@ -164,6 +165,9 @@ class PqtIndex:
         self._keep = []
 
     def close(self):
+        for v in getattr(self, "_views", []):  # the library destroys the views with their owner: only drop the handles
+            v.h = C.c_void_p()
+        self._views = []
         if getattr(self, "h", None) and self.h.value:
             self.L.pqt_index_destroy(self.h)
             self.h = C.c_void_p()
@@ -173,6 +177,19 @@ class PqtIndex:
             self.close()
         except Exception:
             pass
+
+    def view(self):
+        """A second handle on the same loaded index (pqt_index_create_view): own scratch / stream / statistics, for a second batch
+        in flight.  Query entry points only; dies with this object."""
+        v = object.__new__(PqtIndex)
+        v.L, v.device, v._keep, v._views = self.L, self.device, [], []
+        v.D, v.P, v.C1, v.C2, v.W, v.LP = self.D, self.P, self.C1, self.C2, self.W, self.LP
+        v.h = C.c_void_p()
+        _chk(self.L.pqt_index_create_view(self.h, C.byref(v.h)))
+        if not hasattr(self, "_views"):
+            self._views = []
+        self._views.append(v)
+        return v
 
     def set_option(self, name, value):
         _chk(self.L.pqt_index_set_option(self.h, name.encode(), int(value)))

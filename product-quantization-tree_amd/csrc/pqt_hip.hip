@@ -665,6 +665,15 @@ void pqt_index_destroy(pqt_index* idx) {
   (void)hipSetDevice(idx->device);
   (void)hipDeviceSynchronize();
   for (auto& v : idx->views) if (v) { pqt_index_destroy(v); v = nullptr; }
+  {  // user views die with their owner; a view destroyed by the caller leaves the owner's list
+    std::vector<pqt_index*> uv;
+    uv.swap(idx->userViews);
+    for (pqt_index* v : uv) { v->owner = nullptr; pqt_index_destroy(v); }
+    if (idx->userView && idx->owner) {
+      auto& l = idx->owner->userViews;
+      l.erase(std::remove(l.begin(), l.end(), idx), l.end());
+    }
+  }
   if (idx->evFork) (void)hipEventDestroy(idx->evFork);
   for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
   if (idx->isView) {  // the arrays of the index belong to the owner
@@ -683,6 +692,19 @@ void pqt_index_destroy(pqt_index* idx) {
 int pqt_index_params(const pqt_index* idx, pqt_params* out) {
   if (!idx || !out) return fail(PQT_ERR_INVALID, "null argument");
   *out = idx->prm;
+  return PQT_OK;
+}
+
+int pqt_index_create_view(pqt_index* owner, pqt_index** out) {
+  if (!owner || !out) return fail(PQT_ERR_INVALID, "null argument");
+  if (owner->isView) return fail(PQT_ERR_INVALID, "a view cannot be the owner of another view");
+  pqt_index* v = nullptr;
+  int rc = pqt_index_create(&owner->prm, owner->device, &v);
+  if (rc) return rc;
+  v->isView = true; v->userView = true; v->owner = owner;
+  v->stageTiming = 0;  // per-kernel events only on request (pqt_index_set_option on the view)
+  owner->userViews.push_back(v);
+  *out = v;
   return PQT_OK;
 }
 
@@ -719,6 +741,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
 }
 
 int pqt_index_set_codebooks(pqt_index* idx, const float* cb1, const float* cb2) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_codebooks: a view handle shares the owner's index; load into the owner");
   if (!idx || !cb1 || !cb2) return fail(PQT_ERR_INVALID, "null argument");
   int rc = setDevice(idx);
   if (rc) return rc;
@@ -803,6 +826,7 @@ static int uploadHeuristic(pqt_index* idx) {
 // ordered by squared norm with std::sort and the reference's comparator, so the order of equal norms is the
 // one the reference's own build (same libstdc++ introsort) produces.  Only `rows` rows are kept.
 int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_build_heuristic: a view handle shares the owner's index; load into the owner");
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
   const uint64_t M = idx->maxMultiIndex;
   if (M == 0) {
@@ -845,6 +869,7 @@ int pqt_index_build_heuristic(pqt_index* idx, uint64_t rows) {
 // cpu_version semantics, so results under this table are not the reference CPU path's (nor bit-comparable with the CUDA
 // path, whose bin-id digit order differs: SURVEY 8a "divergences").
 int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_t rows) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_build_heuristic_cuda: a view handle shares the owner's index; load into the owner");
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
   const uint32_t P = idx->dp.P;
   uint32_t b = std::min<uint32_t>(std::min<uint32_t>(max_cluster, 16u), idx->dp.WC);
@@ -869,6 +894,7 @@ int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_
 }
 
 int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples, uint64_t rows) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_heuristic: a view handle shares the owner's index; load into the owner");
   if (!idx || (!tuples && rows)) return fail(PQT_ERR_INVALID, "null argument");
   idx->heurHost.assign(tuples, tuples + rows * idx->dp.P);
   idx->heurRows = rows;
@@ -883,6 +909,7 @@ int pqt_index_get_heuristic(const pqt_index* idx, uint32_t* out, uint64_t rows) 
 }
 
 int pqt_index_set_bins(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* sizes, const uint32_t* members) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_bins: a view handle shares the owner's index; load into the owner");
   if (!idx || (nbins && (!ids || !sizes || !members))) return fail(PQT_ERR_INVALID, "null argument");
   std::vector<BinDesc> bins(nbins);
   uint64_t off = 0;
@@ -899,6 +926,7 @@ int pqt_index_set_bins(pqt_index* idx, uint64_t nbins, const uint32_t* ids, cons
 
 int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* sizes, const uint32_t* members,
                              uint32_t id_lo, uint32_t id_hi) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_bins_shard: a view handle shares the owner's index; load into the owner");
   if (!idx || (nbins && (!ids || !sizes || !members))) return fail(PQT_ERR_INVALID, "null argument");
   std::vector<BinDesc> bins(nbins);
   std::vector<uint32_t> local;
@@ -927,6 +955,7 @@ int pqt_index_set_bins_shard(pqt_index* idx, uint64_t nbins, const uint32_t* ids
 
 int pqt_index_set_bins_local(pqt_index* idx, uint64_t nbins, const uint32_t* ids, const uint32_t* gsizes, const uint32_t* lower,
                              const uint32_t* lsizes, const uint32_t* members, uint64_t n_total) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_bins_local: a view handle shares the owner's index; load into the owner");
   if (!idx || (nbins && (!ids || !gsizes || !lower || !lsizes)) ) return fail(PQT_ERR_INVALID, "null argument");
   std::vector<BinDesc> bins(nbins);
   uint64_t off = 0;
@@ -945,6 +974,7 @@ int pqt_index_set_bins_local(pqt_index* idx, uint64_t nbins, const uint32_t* ids
 
 int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix, const uint32_t* counts, const uint32_t* dbidx,
                             uint32_t hash_size) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_db_hashed: a view handle shares the owner's index; load into the owner");
   if (!idx || !prefix || !counts || !dbidx || !hash_size) return fail(PQT_ERR_INVALID, "null argument");
   std::vector<BinDesc> bins;
   for (uint32_t s = 0; s < hash_size; ++s)
@@ -959,6 +989,7 @@ int pqt_index_set_db_hashed(pqt_index* idx, uint32_t n, const uint32_t* prefix, 
 }
 
 int pqt_index_set_lines_host(pqt_index* idx, const uint32_t* codes, uint64_t nvec, uint64_t id_base) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_lines_host: a view handle shares the owner's index; load into the owner");
   if (!idx || (!codes && nvec)) return fail(PQT_ERR_INVALID, "null argument");
   int rc = setDevice(idx);
   if (rc) return rc;
@@ -972,6 +1003,7 @@ int pqt_index_set_lines_host(pqt_index* idx, const uint32_t* codes, uint64_t nve
 }
 
 int pqt_index_set_lines_dev(pqt_index* idx, const uint32_t* codes_dev, uint64_t nvec, uint64_t id_base) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_set_lines_dev: a view handle shares the owner's index; load into the owner");
   if (!idx || !codes_dev) return fail(PQT_ERR_INVALID, "null argument");
   if (((uintptr_t)codes_dev & 15) != 0) return fail(PQT_ERR_INVALID, "line-code buffer must be 16-byte aligned");
   if (idx->codesOwned && idx->d_codes) { (void)hipSetDevice(idx->device); (void)hipFree(idx->d_codes); }
@@ -1091,8 +1123,21 @@ bool overlapWanted(const pqt_index* idx, uint32_t qn, uint32_t k) {
   return true;
 }
 
+// A user view (pqt_index_create_view) re-reads the owner's shared words at every call: whatever the owner loaded or built since
+// (heuristic prefix, bin-ordered store, group-major copy, row bias, options) is what the view works with.  It keeps its own
+// scratch, stream, statistics and "stage_timing".
+void refreshUserView(pqt_index* v) {
+  if (!v || !v->userView || !v->owner) return;
+  SharedWords s;
+  captureShared(v->owner, s);
+  const int keepTiming = v->stageTiming;
+  applyShared(v, s);
+  v->stageTiming = keepTiming;
+}
+
 int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx, float* outDist,
              uint32_t* outPos, uint32_t* outCount, hipStream_t st, int sync, const unsigned long long* binsIn = nullptr, uint32_t binsCap = 0) {
+  refreshUserView(idx);
   if (!overlapWanted(idx, qn, k)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync, binsIn, binsCap);
   if (!q_dev || !outIdx || !outDist || (idx->sharded && !outPos)) return queryImpl(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, st, sync, binsIn, binsCap);
   int rc = setDevice(idx);
@@ -1176,6 +1221,7 @@ int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv
 int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t cap,
                       unsigned long long* out_bins_dev, void* stream, int sync) {
   if (!idx || !out_bins_dev || (qn && !q_dev)) return fail(PQT_ERR_INVALID, "null argument");
+  refreshUserView(idx);
   if (!idx->sharded) return fail(PQT_ERR_INVALID, "pqt_traverse_bins needs a range-sharded index (pqt_index_set_bins_shard / _local)");
   if (cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_LIMIT, "bin-list capacity must be 1..256");
   if (!idx->haveTree || !idx->haveBins || !idx->d_heur) return fail(PQT_ERR_STATE, "index needs codebooks, heuristic and bins before traversing");

@@ -102,6 +102,8 @@ struct pqt_index {
   // slots, so that one piece's (latency-bound) traversal and the tail of its rerank launch fill the gaps of the others'
   static constexpr int kMaxViews = 3;
   pqt_index* views[kMaxViews] = {nullptr, nullptr, nullptr}; pqt_index* owner = nullptr; bool isView = false; int overlap = -1 /* -1 auto, 0 off, 1 on, n >= 2: n pieces */;
+  bool userView = false;                 // created by pqt_index_create_view: refreshed from the owner at every call
+  std::vector<pqt_index*> userViews;     // views handed to the caller (destroyed with the owner at the latest)
   hipEvent_t evFork = nullptr, evJoin[kMaxViews] = {nullptr, nullptr, nullptr};
   uint32_t lastPieces = 0, pieceStart[kMaxViews + 2] = {0, 0, 0, 0, 0};  // last call: pieces (0: one piece on this handle); piece i = queries [pieceStart[i], pieceStart[i+1]), piece 0 on this handle, piece i >= 1 on views[i-1]
   bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet

@@ -121,7 +121,120 @@ class ShardBuffers:
         self.bins_all = torch.zeros((world * qs, self.bin_cap + 1), dtype=torch.int64, device=device)
 
 
-def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False, traversal="replicated", rank=None):
+class ExchangeTimer:
+    """Device time of each collective of a sharded step: event pairs on the stream the step is enqueued on (the collective's
+    own stream is joined to it on both sides by torch.distributed), or host clocks when the tensors live on the CPU (gloo tests).
+    Armed per step by the caller (`on`); read after the closing barrier with means_ms()."""
+    NAMES = ("bins_allgather", "topk_alltoall", "merged_allgather", "topk_allgather")
+
+    def __init__(self, cuda):
+        self.cuda, self.on = bool(cuda), False
+        self.spans = {n: [] for n in self.NAMES}
+
+    def begin(self, name):
+        if not self.on:
+            return None
+        if self.cuda:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return (name, e0)
+        import time
+        return (name, time.perf_counter())
+
+    def end(self, tok):
+        if tok is None:
+            return
+        name, t0 = tok
+        if self.cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.spans[name].append((t0, e1))
+        else:
+            import time
+            self.spans[name].append(time.perf_counter() - t0)
+
+    def means_ms(self):
+        """{collective: mean ms per call} over the armed steps (call after a device synchronisation)."""
+        out = {}
+        for n, v in self.spans.items():
+            if not v:
+                continue
+            ms = [a.elapsed_time(b) for a, b in v] if self.cuda else [x * 1e3 for x in v]
+            out[n] = sum(ms) / len(ms)
+        out["calls_timed"] = max([len(v) for v in self.spans.values()] + [0])
+        return out
+
+
+def _stages(engine, dist, world, q, bv, bb, k, buf, exchange, force_collectives, traversal, rank, timer, delay=None):
+    """The stages of one sharded step as closures, in issue order; every collective is a stage of its own so that two half batches
+    can be interleaved stage by stage (sharded_query_pipelined).  `delay` (seconds, test/measurement aid): called after every
+    collective with the stream's tensors -- the one-device harness injects a synthetic collective latency through it."""
+    qn = q.shape[0]
+    qs = buf.qs
+    coll = world > 1 or force_collectives
+    st = {}
+
+    def timed(name, fn):
+        tok = timer.begin(name) if timer is not None else None
+        fn()
+        if delay is not None:
+            delay()
+        if timer is not None:
+            timer.end(tok)
+
+    stages = []
+    if traversal == "sharded":
+        r = rank if rank is not None else (dist.get_rank() if coll else 0)
+        lo, hi = min(r * qs, qn), min((r + 1) * qs, qn)
+
+        def s_traverse():
+            if hi > lo:
+                engine.traverse_bins(q[lo:hi], bv, bb, buf.bin_cap, buf.bins_local)
+        stages.append(s_traverse)
+        if coll:
+            stages.append(lambda: timed("bins_allgather", lambda: dist.all_gather_into_tensor(buf.bins_all, buf.bins_local)))
+        else:
+            stages.append(lambda: None)
+
+        def s_rerank():
+            engine.query_shard_bins(q, bv, bb, k, buf.bins_all if coll else buf.bins_local, buf.bin_cap, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
+        stages.append(s_rerank)
+    else:
+        stages.append(lambda: None)
+        stages.append(lambda: None)
+        stages.append(lambda: engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count))
+    if not coll:
+        stages.append(lambda: engine.merge_topk(1, qn, k, buf.pack[0], buf.pack[1].view(torch.float32), buf.pack[2], buf.out_idx, buf.out_dist, 3 * world * qs * k))
+        return stages
+    if exchange == "allgather":
+        stages.append(lambda: timed("topk_allgather", lambda: dist.all_gather_into_tensor(buf.gathered.view(world * 3, world * qs, k), buf.pack)))
+
+        def s_merge_all():
+            g = buf.gathered
+            engine.merge_topk(world, qn, k, g[0, 0], g[0, 1].view(torch.float32), g[0, 2], buf.out_idx, buf.out_dist, 3 * world * qs * k)
+        stages.append(s_merge_all)
+        return stages
+
+    def s_a2a():
+        # block r of the send buffer = the three planes of the rows of slice r
+        buf.send.copy_(buf.pack.view(3, world, qs, k).permute(1, 0, 2, 3))
+        timed("topk_alltoall", lambda: dist.all_to_all_single(buf.recv.view(world * 3, qs, k), buf.send.view(world * 3, qs, k)))
+    stages.append(s_a2a)
+
+    def s_merge():
+        r_ = buf.recv  # [source shard][3][qs][k]: the layout pqt_merge_topk reads with shard_stride = 3*qs*k
+        engine.merge_topk(world, qs, k, r_[0, 0], r_[0, 1].view(torch.float32), r_[0, 2], buf.slice_out[0], buf.slice_out[1].view(torch.float32), 3 * qs * k)
+    stages.append(s_merge)
+    stages.append(lambda: timed("merged_allgather", lambda: dist.all_gather_into_tensor(buf.all_out.view(world * 2, qs, k), buf.slice_out)))
+
+    def s_out():
+        buf.out_idx_pad.view(world, qs, k).copy_(buf.all_out[:, 0])
+        buf.out_dist_pad.view(torch.int32).view(world, qs, k).copy_(buf.all_out[:, 1])
+    stages.append(s_out)
+    return stages
+
+
+def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", force_collectives=False, traversal="replicated", rank=None, timer=None, delay=None):
     """One step of the sharded hot path.  Returns (out_idx, out_dist, count) views into `buf`.
 
     traversal = "replicated": every rank traverses the whole batch (pqt_query_shard).
@@ -135,40 +248,76 @@ def sharded_query(engine, dist, world, q, bv, bb, k, buf, exchange="alltoall", f
         slices (idx | dist, 8 bytes per result) gives every rank the whole answer.  Per rank and batch of 10 k queries,
         k = 100, W = 8: 10.5 MB + 7 MB received instead of 84 MB, 1250 merged queries instead of 10 000.
     exchange = "allgather": the single all-gather of the whole [3][qn][k] messages + a merge of all queries on every rank
-        (the protocol of round 1; same result bit for bit)."""
-    qn = q.shape[0]
-    qs = buf.qs
-    if traversal == "sharded":
-        if rank is None:
-            rank = dist.get_rank() if (world > 1 or force_collectives) else 0
-        lo, hi = min(rank * qs, qn), min((rank + 1) * qs, qn)
-        if hi > lo:
-            engine.traverse_bins(q[lo:hi], bv, bb, buf.bin_cap, buf.bins_local)
-        if world == 1 and not force_collectives:
-            bins = buf.bins_local
-        else:
-            dist.all_gather_into_tensor(buf.bins_all, buf.bins_local)
-            bins = buf.bins_all
-        engine.query_shard_bins(q, bv, bb, k, bins, buf.bin_cap, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
-    else:
-        engine.query_shard(q, bv, bb, k, buf.sh_idx, buf.sh_dist, buf.sh_pos, buf.count)
-    if world == 1 and not force_collectives:
-        engine.merge_topk(1, qn, k, buf.pack[0], buf.pack[1].view(torch.float32), buf.pack[2], buf.out_idx, buf.out_dist, 3 * world * qs * k)
-        return buf.out_idx, buf.out_dist, buf.count
-    if exchange == "allgather":
-        dist.all_gather_into_tensor(buf.gathered.view(world * 3, world * qs, k), buf.pack)
-        g = buf.gathered
-        engine.merge_topk(world, qn, k, g[0, 0], g[0, 1].view(torch.float32), g[0, 2], buf.out_idx, buf.out_dist, 3 * world * qs * k)
-        return buf.out_idx, buf.out_dist, buf.count
-    # block r of the send buffer = the three planes of the rows of slice r
-    buf.send.copy_(buf.pack.view(3, world, qs, k).permute(1, 0, 2, 3))
-    dist.all_to_all_single(buf.recv.view(world * 3, qs, k), buf.send.view(world * 3, qs, k))
-    r = buf.recv  # [source shard][3][qs][k]: the layout pqt_merge_topk reads with shard_stride = 3*qs*k
-    engine.merge_topk(world, qs, k, r[0, 0], r[0, 1].view(torch.float32), r[0, 2], buf.slice_out[0], buf.slice_out[1].view(torch.float32), 3 * qs * k)
-    dist.all_gather_into_tensor(buf.all_out.view(world * 2, qs, k), buf.slice_out)
-    buf.out_idx_pad.view(world, qs, k).copy_(buf.all_out[:, 0])
-    buf.out_dist_pad.view(torch.int32).view(world, qs, k).copy_(buf.all_out[:, 1])
+        (the protocol of round 1; same result bit for bit).
+    timer: an ExchangeTimer (armed by the caller) brackets every collective."""
+    for stage in _stages(engine, dist, world, q, bv, bb, k, buf, exchange, force_collectives, traversal, rank, timer, delay):
+        stage()
     return buf.out_idx, buf.out_dist, buf.count
+
+
+class PipelineBuffers:
+    """Two half batches in flight (SURVEY.md 8e "one collective launch latency per batch, hidden by double-buffering batches"):
+    the batch is split into halves [0, h) and [h, qn), each with its own ShardBuffers, engine (the index and a view of it: a
+    handle serves one batch at a time) and stream; the whole answer is assembled in out_idx / out_dist / count."""
+
+    def __init__(self, world, qn, k, device, bin_cap=None, cuda=None):
+        self.qn, self.k = qn, k
+        self.h = (qn + 1) // 2
+        self.halves = [ShardBuffers(world, self.h, k, device, bin_cap), ShardBuffers(world, max(qn - self.h, 1), k, device, bin_cap)]
+        self.out_idx = torch.empty((qn, k), dtype=torch.int32, device=device)
+        self.out_dist = torch.empty((qn, k), dtype=torch.float32, device=device)
+        self.count = torch.empty(qn, dtype=torch.int32, device=device)
+        self.cuda = (torch.device(device).type == "cuda") if cuda is None else cuda
+        self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if self.cuda else [None, None]
+        self.bin_cap = self.halves[0].bin_cap
+
+
+def sharded_query_pipelined(engines, dist, world, q, bv, bb, k, pbuf, exchange="alltoall", force_collectives=False, traversal="sharded", rank=None,
+                            timer=None, delay=None):
+    """sharded_query for the two halves of the batch, interleaved stage by stage on two streams: while half A's collective is in
+    flight (a launch latency, not bandwidth: 10 MB per batch) half B's kernels run, and the other way round.  The collectives of
+    both halves are issued in the same order on every rank.  engines = (engine of the index, engine of a view of it).  The result
+    is sharded_query's, bit for bit (each query's answer does not depend on which other queries share its launch).
+    Returns (out_idx, out_dist, count) of the whole batch."""
+    qn = q.shape[0]
+    h = pbuf.h
+    if qn - h < 1:
+        oi, od, oc = sharded_query(engines[0], dist, world, q, bv, bb, k, pbuf.halves[0], exchange, force_collectives, traversal, rank, timer, delay)
+        pbuf.out_idx.copy_(oi), pbuf.out_dist.copy_(od), pbuf.count.copy_(oc)
+        return pbuf.out_idx, pbuf.out_dist, pbuf.count
+    parts = [(0, h), (h, qn)]
+    plans = [_stages(engines[i], dist, world, q[a:b], bv, bb, k, pbuf.halves[i], exchange, force_collectives, traversal, rank, timer, delay)
+             for i, (a, b) in enumerate(parts)]
+
+    def out_copy(i):
+        a, b = parts[i]
+        hb = pbuf.halves[i]
+        pbuf.out_idx[a:b].copy_(hb.out_idx)
+        pbuf.out_dist[a:b].copy_(hb.out_dist)
+        pbuf.count[a:b].copy_(hb.count)
+
+    if not pbuf.cuda:
+        for sidx in range(len(plans[0])):
+            for i in range(2):
+                plans[i][sidx]()
+        out_copy(0), out_copy(1)
+        return pbuf.out_idx, pbuf.out_dist, pbuf.count
+    cur = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    for s_ in pbuf.streams:
+        s_.wait_event(fork)
+    for sidx in range(len(plans[0])):
+        for i in range(2):
+            with torch.cuda.stream(pbuf.streams[i]):
+                plans[i][sidx]()
+    for i in range(2):
+        with torch.cuda.stream(pbuf.streams[i]):
+            out_copy(i)
+        done = torch.cuda.Event()
+        done.record(pbuf.streams[i])
+        cur.wait_event(done)
+    return pbuf.out_idx, pbuf.out_dist, pbuf.count
 
 
 class PqtShardEngine:

@@ -113,7 +113,7 @@ class OracleShardEngine:
             out_dist[qi] = torch.from_numpy(d[order])
 
 
-def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", bin_cap=None):
+def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", bin_cap=None, pipelined=False):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -127,9 +127,20 @@ def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", b
         queries = torch.from_numpy(fx.queries[:7])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded
         k, bv, bb = 20, 300, 100
         # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
-        buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
-        oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange, traversal=traversal)
-        if traversal == "sharded":
+        timer = sh.ExchangeTimer(cuda=False)
+        timer.on = True
+        if pipelined:
+            # two half batches in flight (4 + 3 queries: both halves have padded slices), interleaved stage by stage
+            pbuf = sh.PipelineBuffers(world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
+            oi, od, cnt = sh.sharded_query_pipelined((eng, eng), dist, world, queries, bv, bb, k, pbuf, exchange=exchange, traversal=traversal, timer=timer)
+            buf = None
+        else:
+            buf = sh.ShardBuffers(world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
+            oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange, traversal=traversal, timer=timer)
+        tm = timer.means_ms()
+        want = (["bins_allgather"] if traversal == "sharded" else []) + (["topk_allgather"] if exchange == "allgather" else ["topk_alltoall", "merged_allgather"])
+        assert sorted(n_ for n_ in tm if n_ != "calls_timed") == sorted(want) and tm["calls_timed"] == (2 if pipelined else 1), tm
+        if traversal == "sharded" and buf is not None:
             trailer = buf.bins_all[:queries.shape[0], buf.bin_cap].numpy().view(np.uint64) & np.uint64(0xffffffff)
             over = int((trailer == 0xffffffff).sum())
             assert (over > 0) == bool(bin_cap and bin_cap < 16), (over, bin_cap)  # the fallback is exercised exactly when the capacity is small
@@ -227,6 +238,24 @@ def test_gloo_query_sharded_traversal_equals_unsharded(world, exchange, bin_cap)
     q = ctx.Queue()
     port = 33500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (17 if bin_cap == 256 else 0)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, "sharded", bin_cap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,exchange,traversal,bin_cap", [(2, "alltoall", "sharded", None), (3, "alltoall", "sharded", 3), (3, "allgather", "sharded", None),
+                                                              (2, "alltoall", "replicated", None)])
+def test_gloo_two_half_batches_in_flight_equal_unsharded(world, exchange, traversal, bin_cap):
+    """sharded_query_pipelined: the batch as two halves whose stages (and collectives) are interleaved -- every rank issues the
+    collectives of both halves in the same order, and the assembled answer is the unsharded engine's bit for bit."""
+    fixture("odd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (19 if traversal == "replicated" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, bin_cap, True)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

@@ -90,3 +90,30 @@ def test_eight_gpu_default_code_path_with_two_ranks_and_small_stand_ins():
     assert leg["same_workload_1gpu"]["results_identical_to_sharded"] is True
     assert d["scaling_vs_1gpu"] == leg["same_workload_1gpu"]["speedup_of_this_run"] > 0
     assert "strong_scaling_leg" in d["scaling_vs_1gpu_what"]
+
+
+@pytest.mark.parametrize("pipeline", [2, 1])
+def test_bare_command_launches_its_own_ranks_and_reports_the_exchange(pipeline):
+    """`python bench.py --gpus 2` with NO rank environment (the driver's own command form): bench.py re-executes itself under
+    torch.distributed.run, rank 0 prints the one line, and the line carries the per-collective device times (exchange_ms), every
+    rank's stage times, and the step time of the other schedule (two half batches in flight vs one batch) with identical results."""
+    env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1")
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k_, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "synth1m", "--steps", "4", "--warmup", "1", "--timing-period", "2",
+                          "--pipeline", str(pipeline)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["collective_world_size"] == 2 and d["scaling"] == "strong"
+    assert c["ranks_agree"] is True and c["same_workload_1gpu"]["results_identical_to_sharded"] is True
+    ex = c["exchange_ms"]
+    assert set(ex) == {"bins_allgather", "topk_alltoall", "merged_allgather", "calls_timed"}, ex
+    assert all(ex[n_] > 0 for n_ in ("bins_allgather", "topk_alltoall", "merged_allgather"))
+    assert ex["calls_timed"] == (4 if pipeline == 2 else 2)  # 2 of the 4 timed steps carry events; two half-batch calls each when pipelined
+    pr = c["per_rank_stage_ms"]
+    assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["stage_ms"]["rerank_select"] > 0 and r_["candidates"] > 0 for r_ in pr)
+    assert ("two half batches" in c["pipeline"]) == (pipeline == 2) and ("two half batches in flight" in c["kernel_path"]) == (pipeline == 2)
+    ab = c["pipeline_ab"]
+    assert "error" not in ab, ab
+    assert ab["results_identical"] is True and ab["other"] == "pipeline=%d" % (3 - pipeline) and ab["other_ms_per_step"] > 0
