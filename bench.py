@@ -55,6 +55,13 @@ WORKLOADS = {
     "synth1b": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=1_000_000_000, n_train=200_000, qn=10_000, chunk=4_000_000),
     # cfg3 shape at 1 M vectors: functional checks of the chunk-built / sharded path (not a bench line)
     "synth1m": dict(D=128, P=4, C1=64, C2=64, W=1, LP=32, n_base=1_000_000, n_train=100_000, qn=2_000, chunk=300_000),
+    # BASELINE.json configs[4] shape (d=256 p=8 c1=128 c2=64, lineparts=32) at a single-GPU size.  THROUGHPUT ONLY, NO REFERENCE COUNTERPART:
+    # the reference counts its heuristic rows in uint32, (W*C2)^P = 64^8 wraps to 0 and its query enumerates nothing at this shape (the
+    # engine's default does the same: tests/test_gpu_parity.py::test_config5_shape...).  This workload lifts that limit (option
+    # "enumerate_beyond_wrap") and supplies the first rows of the sum-of-squares order produced best-first (heuristic.py); bin ids keep
+    # the reference's uint32 wrap-around ((C1*C2)^p = 2^13p: only parts 0..2 reach the bin id).
+    "synth_cfg5": dict(D=256, P=8, C1=128, C2=64, W=1, LP=32, n_base=4_000_000, n_train=150_000, qn=10_000, chunk=1_000_000, beyond_wrap=True),
+    "tiny_cfg5": dict(D=256, P=8, C1=128, C2=64, W=1, LP=32, n_base=200_000, n_train=40_000, qn=1_000, chunk=100_000, beyond_wrap=True),
     # small variant for quick checks (not a bench line)
     "tiny": dict(D=128, P=4, C1=32, C2=32, W=2, LP=16, n_base=50_000, n_train=20_000, qn=1_000),
 }
@@ -376,6 +383,17 @@ def barrier(ctx):
     torch.cuda.synchronize(ctx.dev)
 
 
+def set_heuristic_rows(ctx, idx, w, rows):
+    """The traversal heuristic of a bench index: the reference's table (built by the library) -- or, for the configs[4]-shape workloads
+    whose table cannot exist (2^48 rows; the reference enumerates none), the best-first prefix with the wrap limit lifted."""
+    if w.get("beyond_wrap"):
+        hp = importlib.import_module("product-quantization-tree_amd.heuristic")
+        idx.set_option("enumerate_beyond_wrap", 1)
+        idx.set_heuristic(hp.heuristic_prefix_best_first(w["W"] * w["C2"], w["P"], rows))
+    else:
+        idx.build_heuristic(rows)
+
+
 def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
     """Index + query batch (+ exact ground truth) of one workload.  mode: single | replica | shard_db."""
     w = WORKLOADS[wl_name]
@@ -387,7 +405,7 @@ def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
         name_, val_ = ov.split("=")
         idx.set_option(name_, int(val_))
     t0 = time.time()
-    idx.build_heuristic(max(args.bb, 1))
+    set_heuristic_rows(ctx, idx, w, max(args.bb, 1))
     log("[bench] %s index: N=%d%s bins=%d max_bin=%d  data %.1fs encode %.1fs csr %.1fs heuristic %.1fs" %
         (wl_name, n, (" (this rank: ids [%d, %d))" % shard) if shard else "", meta["n_bins"], meta["max_bin"], meta["t_data"], meta["t_encode"],
          meta["t_csr"], time.time() - t0))
@@ -602,7 +620,10 @@ def make_line(ctx, args, W, R):
         # is fixed; --replicas is the weak-scaling variant
         "scaling": "weak" if mode == "replica" else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("SIFT1M-shape synthetic" if W["name"] in ("sift1m", "tiny") else "synthetic SIFT-shaped (chunk-built)") + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
+        "config": {"workload": ("SIFT1M-shape synthetic" if W["name"] in ("sift1m", "tiny") else
+                                ("configs[4]-shape synthetic (chunk-built), THROUGHPUT ONLY -- no reference counterpart: the reference enumerates 0 heuristic rows at this shape "
+                                 "((W*C2)^P wraps to 0 in uint32); limit lifted, best-first sum-of-squares prefix supplied" if w.get("beyond_wrap") else
+                                 "synthetic SIFT-shaped (chunk-built)")) + ": N=%d d=%d p=%d c1=%d c2=%d w=%d lineparts=%d, batch=%d queries, "
                                "query(boundVectors=%d, boundBins=%d), k=%d" %
                                (n, w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], qn, R["bv"], R["bb"], k),
                    "workload_name": W["name"],
@@ -642,7 +663,7 @@ def same_workload_1gpu(ctx, args, W, R):
         if not args.no_ref1 and n <= 200_000_000:
             if ctx.rank == 0:
                 ridx, _, rmeta = build_index(ctx.pkg, w, ctx.local_rank, codebooks=(W["meta"]["cb1"], W["meta"]["cb2"]))
-                ridx.build_heuristic(max(R["bb"], 1))
+                set_heuristic_rows(ctx, ridx, w, max(R["bb"], 1))
                 for ov in args.option:
                     ridx.set_option(ov.split("=")[0], int(ov.split("=")[1]))
                 ro = (torch.empty((qn, k), dtype=torch.int32, device=dev), torch.empty((qn, k), dtype=torch.float32, device=dev), torch.empty(qn, dtype=torch.int32, device=dev))
@@ -673,7 +694,7 @@ def ranks_agree(ctx, R):
 
 def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
     """One knob set on an index that is already built: q/s, stage ms, roofline of its dominant kernel."""
-    W["idx"].build_heuristic(max(bb, 1))
+    set_heuristic_rows(ctx, W["idx"], W["w"], max(bb, 1))
     R = time_path(ctx, args, W, bv, bb, k, steps, warmup, period=2)
     roof, ex = roofline_block(ctx, args, W, R)
     r1, r10, r100 = recalls(W, R["out_idx"])
@@ -871,6 +892,39 @@ def main():
             torch.cuda.synchronize(dev)
         except Exception as e:
             out["config"]["knobs_4096_4096"] = {"error": repr(e)[:200]}
+
+    # ---- the kept C++ front-end: pqt::PerturbationProTree::queryKNN as the reference's tool_query calls it
+    # (tool_query.cpp:153-161: batches of <= 4096 queries, device query pointer, two std::vectors resized + filled), wall clock per
+    # call split into kernels / D2H / host; "legacy_copy" = round 3's hand-over (two synchronous pageable copies of the padded arrays)
+    if args.extras and mode == "single" and not W["chunked"]:
+        try:
+            fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
+            codes_h = idx._keep[0].cpu().numpy().view(np.uint32)
+            fe = fe_mod.FrontEnd(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], meta["cb1"], meta["cb2"], meta["bin_ids"], meta["sizes"], meta["members"], codes_h,
+                                 devices=(dev.index or 0,))
+            del codes_h
+            leg = {"what": "wall clock of PerturbationProTree::queryKNN per call (mean of 5 after 1 warm-up), this workload's index handed over as host arrays; "
+                           "compact = only the first max(list length) columns of both arrays cross PCIe into pinned staging, padding written on the host; "
+                           "legacy_copy = the whole padded [QN][nVec] arrays copied into the caller's pageable vectors (round 3)"}
+            for name_, qn_, nvec_, bv_, bb_ in (("qn4096_nvec4096_knobs_4096_4096", min(4096, qn), 4096, 4096, 4096), ("qn4096_nvec100", min(4096, qn), 100, args.bv, args.bb),
+                                                ("qn%d_nvec100" % qn, qn, 100, args.bv, args.bb)):
+                e_ = {}
+                for variant in ("compact", "legacy_copy"):
+                    if variant == "legacy_copy":
+                        os.environ["PQT_FRONTEND_LEGACY_COPY"] = "1"
+                    else:
+                        os.environ.pop("PQT_FRONTEND_LEGACY_COPY", None)
+                    fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=1, want_results=False)
+                    tm_, _, _ = fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=5, want_results=False)
+                    tm_["queries_per_sec"] = qn_ / (tm_["total_ms"] * 1e-3)
+                    tm_["copy_share_of_call"] = tm_["d2h_ms"] / max(tm_["total_ms"], 1e-9)
+                    e_[variant] = tm_
+                os.environ.pop("PQT_FRONTEND_LEGACY_COPY", None)
+                leg[name_] = e_
+            fe.close()
+            out["config"]["frontend_queryKNN"] = leg
+        except Exception as e:
+            out["config"]["frontend_queryKNN"] = {"error": repr(e)[:300]}
 
     # ---- the headline batch without stage events on any call (the events cost ~0.01 ms per call), and as two pieces on two streams
     # ("overlap" = 1: opt-in since the rerank's statistics atomics stopped serialising the launch, DESIGN.md section 4 "Round 3")
@@ -1133,6 +1187,9 @@ def cpu_baseline_chunked(pkg, idx, w, meta, queries, args, out_idx, out_dist, k)
     (insert() is bit-identical to the build kernel, tests/test_gpu_parity.py) and timed on a bounded sample."""
     from oracle import Oracle
     o = Oracle(w["D"], w["P"], w["C1"], w["C2"], w["W"], w["LP"], heur_keep=max(args.bb, 1))
+    if w.get("beyond_wrap"):  # the checker follows the engine's throughput-only mode (NOT reference behaviour: the reference enumerates 0 rows here)
+        o.lift_tuple_wrap(max(args.bb, 1))
+        o.set_heuristic(idx.heuristic(max(args.bb, 1)))
     heur_same = bool(np.array_equal(o.heuristic(max(args.bb, 1)), idx.heuristic(max(args.bb, 1))))
     o.set_codebooks(meta["cb1"], meta["cb2"])
     o.import_bins(meta["bin_ids"], meta["sizes"], meta["members"])

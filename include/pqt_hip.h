@@ -115,6 +115,9 @@ int pqt_index_create_view(pqt_index* owner, pqt_index** out);
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
  * "debug_bits" = ablation switches of the fused kernels (measurement only: results are WRONG for non-zero values;
  * scripts/ablate*.sh, PQT_DBG).
+ * "enumerate_beyond_wrap" = 1: enumerable heuristic rows = the true (W*C2)^P, not the reference's uint32 product (which wraps to 0 at
+ * BASELINE configs[4], where the reference therefore enumerates nothing): throughput-only mode WITHOUT a reference counterpart, used with
+ * a supplied prefix (pqt_index_set_heuristic); bin ids keep the uint32 wrap-around.  Default 0.
  * "scratch_mb" = budget of the candidate arena in MiB (default 1/8 of device memory, at most 24 GiB): batches whose
  * candidate lists exceed it are processed in several chunks of queries. */
 int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value);
@@ -283,6 +286,7 @@ int pqt_multi_shard_range(const pqt_multi* m, int s, uint64_t* id_lo, uint64_t* 
 int pqt_multi_set_option(pqt_multi* m, const char* name, int64_t value);
 int pqt_multi_set_codebooks(pqt_multi* m, const float* cb1_host, const float* cb2_host);   /* = pqt_index_set_codebooks */
 int pqt_multi_build_heuristic(pqt_multi* m, uint64_t rows);                                /* = pqt_index_build_heuristic */
+int pqt_multi_build_heuristic_cuda(pqt_multi* m, uint32_t max_cluster, uint64_t rows);     /* = pqt_index_build_heuristic_cuda, every shard gets the table */
 int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows);
 /* the WHOLE database as for pqt_index_set_bins (members of a bin in ascending id order = the reference's insertion order);
  * every shard keeps its id range.  n_total = number of vectors (0: the sum of the bin sizes). */
@@ -320,6 +324,13 @@ int pqt_debug_calibrate_gather(int device, uint32_t log2_rows, uint32_t row_byte
  * (coalesced, four loads per lane in flight); *out_ms = mean launch time.  bench.py reports bytes / time beside the nominal
  * HBM peak (choose bytes far above the 256 MiB Infinity Cache). */
 int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms);
+/* The reference's own self-checks of its sort / scan primitives (pqt/bitonicSort.cuh:213-252: sortTestLarge sorts the values N - tid
+ * carrying tid and expects payload[tid] == N - tid - 1; scanTestLarge expects the exclusive scan of ones == tid; N = 1024, 2048,
+ * 4096), run through THIS library's primitives by a one-workgroup kernel: mode 0 = in-register wave sorting network
+ * (pqt_wave_sort_u64, n <= 2048), 1 = block-wide bitonic network in LDS, 2 = wave radix select (out[j] = payload of the (j+1)-th
+ * smallest key for every j; n = 512 | 1024), 3 = block radix select (64 ranks n/64 apart, the other entries stay 0xffffffff),
+ * 4 = wave scan, 5 = block scan (out[n] = the total).  out_host[n + 1].  n a power of two, 64..8192. */
+int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host);
 int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* Which kernels the last pqt_query* call launched, as text (tests assert the path taken, not only the result):
  * "traverse=<fused|fused-wide|staged>[-shape1|-shape2|-p2|-generic] rerank=<lds-table|l2-table|mode1-nwN|mode2-nwN|wg-gG|

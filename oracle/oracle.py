@@ -44,6 +44,7 @@ def _lib():
     L.pqo_set_sum_mode.argtypes = [C.c_void_p, C.c_int]
     L.pqo_max_multi_index.restype = C.c_ulonglong
     L.pqo_max_multi_index.argtypes = [C.c_void_p]
+    L.pqo_set_max_multi_index.argtypes = [C.c_void_p, C.c_ulonglong]
     L.pqo_heuristic_rows.restype = C.c_ulonglong
     L.pqo_heuristic_rows.argtypes = [C.c_void_p]
     L.pqo_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_ulonglong]
@@ -168,6 +169,11 @@ class Oracle:
     @property
     def max_multi_index(self):
         return self.L.pqo_max_multi_index(self.h)
+
+    def lift_tuple_wrap(self, rows):
+        """NOT reference behaviour (the checker following the engine's throughput-only "enumerate_beyond_wrap" mode): allow `rows`
+        heuristic rows to be enumerated although (W*C2)^P wraps in the reference's uint arithmetic."""
+        self.L.pqo_set_max_multi_index(self.h, int(rows))
 
     def heuristic(self, rows=None):
         n = self.L.pqo_heuristic_rows(self.h)

@@ -543,6 +543,9 @@ void pqo_set_sort_mode(void* h, int m) { ((Oracle*)h)->sortMode = m; }
 // sensitivity probe: order of the squared-norm sums (see sqdist); the coarse table is recomputed in the new order
 void pqo_set_sum_mode(void* h, int m) { Oracle* o = (Oracle*)h; o->sumMode = m; if (!o->cb1.empty()) o->computeLookupTable(); }
 unsigned long long pqo_max_multi_index(void* h) { return ((Oracle*)h)->maxMultiIndex; }
+// NOT reference behaviour: lifts the uint wrap of (W*C2)^P (treequantizer.hpp:40-41) so that the checker can follow the engine's
+// throughput-only "enumerate_beyond_wrap" mode at BASELINE configs[4] (the reference itself enumerates 0 rows there)
+void pqo_set_max_multi_index(void* h, unsigned long long v) { ((Oracle*)h)->maxMultiIndex = (size_t)v; }
 unsigned long long pqo_heuristic_rows(void* h) { return ((Oracle*)h)->heurRows; }
 void pqo_get_heuristic(void* h, uint* out, unsigned long long rows) {
   Oracle* o = (Oracle*)h; memcpy(out, o->heur.data(), std::min((size_t)rows, o->heurRows) * o->P * sizeof(uint));

@@ -47,9 +47,9 @@ EXPORTS = [
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
-    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_traverse_bins", "pqt_query_shard_bins",
+    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
     "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
-    "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
+    "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
     "pqt_multi_query_host",
 ]
 
@@ -117,6 +117,7 @@ def lib():
     L.pqt_get_stage_ms_history.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_get_last_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.pqt_debug_stream_read.argtypes = [C.c_int, C.c_uint64, C.c_int, f32p]
+    L.pqt_debug_sort_scan.argtypes = [C.c_int, C.c_uint32, C.c_uint32, u32p]
     L.pqt_multi_last_error.restype = C.c_char_p
     L.pqt_multi_create.argtypes = [C.POINTER(pqt_params), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
     L.pqt_multi_destroy.argtypes = [C.c_void_p]
@@ -128,6 +129,7 @@ def lib():
     L.pqt_multi_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.pqt_multi_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqt_multi_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
+    L.pqt_multi_build_heuristic_cuda.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     L.pqt_multi_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_multi_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint64]
     L.pqt_multi_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64]
@@ -376,6 +378,9 @@ class PqtMulti:
     def build_heuristic(self, rows):
         self._chk(self.L.pqt_multi_build_heuristic(self.h, rows))
 
+    def build_heuristic_cuda(self, max_cluster, rows):
+        self._chk(self.L.pqt_multi_build_heuristic_cuda(self.h, max_cluster, rows))
+
     def set_heuristic(self, tuples):
         t = _np(tuples, np.uint32).reshape(-1, self.P)
         self._chk(self.L.pqt_multi_set_heuristic(self.h, _p(t, u32p), t.shape[0]))
@@ -417,6 +422,13 @@ def stream_read_GBps(nbytes=4 << 30, reps=5, device=0):
     ms = C.c_float(0)
     _chk(lib().pqt_debug_stream_read(device, nbytes, reps, C.byref(ms)))
     return nbytes / (ms.value * 1e-3) / 1e9
+
+
+def debug_sort_scan(mode, n, device=0):
+    """The reference's sort / scan self-check patterns through the library's primitives (include/pqt_hip.h: pqt_debug_sort_scan)."""
+    out = np.zeros(n + 1, np.uint32)
+    _chk(lib().pqt_debug_sort_scan(device, mode, n, _p(out, u32p)))
+    return out
 
 
 def dev_triangle(a, b, c, l, device=0):

@@ -736,6 +736,17 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "balance") == 0) { idx->balance = value < 0 ? -1 : (value >= 2 ? 2 : (int)value); return PQT_OK; }  // rerank schedule: -1 automatic, 0 static, 1 workgroup-local, 2 global pools
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
+  // "enumerate_beyond_wrap" = 1: the number of enumerable heuristic rows is the true (W*C2)^P instead of the reference's uint32 product
+  // (treequantizer.hpp:40-41), which wraps to 0 at BASELINE configs[4] (64^8 = 2^48) and makes its orderBins enumerate nothing.  NO
+  // reference counterpart: a throughput-only mode for that shape, used with a supplied prefix (pqt_index_set_heuristic).  Bin ids keep
+  // the reference's uint32 wrap-around.  Default 0 = the reference's behaviour.
+  if (strcmp(name, "enumerate_beyond_wrap") == 0) {
+    if (idx->isView) return fail(PQT_ERR_INVALID, "set enumerate_beyond_wrap on the owner");
+    uint64_t full = 1;
+    for (uint32_t i = 0; i < idx->dp.P; ++i) { full *= idx->dp.WC; if (full > ((uint64_t)1 << 62) / std::max<uint32_t>(idx->dp.WC, 1)) { full = (uint64_t)1 << 62; break; } }
+    idx->maxMultiIndex = value ? full : (uint64_t)upow(idx->dp.WC, idx->dp.P);
+    return PQT_OK;
+  }
   if (strcmp(name, "scratch_mb") == 0) { if (value < 1) return fail(PQT_ERR_INVALID, "scratch_mb must be >= 1"); idx->scratchBudget = (size_t)value << 20; return PQT_OK; }
   return fail(PQT_ERR_INVALID, std::string("unknown option ") + name);
 }
@@ -1460,6 +1471,28 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms) {
   (void)hipFree(buf); (void)hipFree(sink);
   if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
   *out_ms = ms / (float)reps;
+  return PQT_OK;
+}
+
+int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host) {
+  if (!out_host || mode > 5) return fail(PQT_ERR_INVALID, "mode 0..5, out_host[n + 1]");
+  const bool p2 = n >= 64 && (n & (n - 1)) == 0;
+  if (!p2 || n > 8192 || (mode == 0 && n > 2048) || (mode == 2 && n != 512 && n != 1024) || (mode == 5 && n < 256))
+    return fail(PQT_ERR_INVALID, "n: a power of two, 64..8192 (wave sort <= 2048, wave select 512 | 1024, block scan >= 256)");
+  HIPCHK(hipSetDevice(device));
+  uint32_t* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, ((size_t)n + 1) * 4));
+  hipError_t e = hipMemset(d, 0xff, ((size_t)n + 1) * 4);
+  const size_t lds = (size_t)n * 8 + 256 * 4 + 4 * 8 + 64;
+  if (e == hipSuccess) {
+    int rc = allowLds(pqt_k_debug_sortscan, lds);
+    if (rc) { (void)hipFree(d); return rc; }
+    hipLaunchKernelGGL(pqt_k_debug_sortscan, dim3(1), dim3(256), lds, 0, mode, n, d);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out_host, d, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(PQT_ERR_DEVICE, hipGetErrorString(e));
   return PQT_OK;
 }
 

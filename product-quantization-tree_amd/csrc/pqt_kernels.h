@@ -3481,3 +3481,78 @@ __global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restr
   out[t] = in[pos * LP + g * G + x];
 }
 #endif  // PQT_MAIN_TU
+
+// ===================================================================================================
+// Self-checks of the sort / select / scan primitives on the patterns the reference's own self-tests use
+// (pqt/bitonicSort.cuh:213-252: sortTestLarge sorts the values N - tid with payload tid and expects payload[tid] == N - tid - 1;
+// scanTestLarge scans a vector of ones and expects the exclusive prefix tid), N = 1024 / 2048 / 4096.  One launch per (primitive, N);
+// out[N] receives what the reference checks.  mode: 0 = in-register wave network pqt_wave_sort_u64<R> (N = 64 R <= 2048, one wavefront),
+// 1 = block-wide bitonic network in LDS (pqt_bitonic_sort_u64), 2 = wave radix select pqt_wave_kth_u64 (out[j] = payload of the
+// (j+1)-th smallest key, every rank j asked for in turn), 3 = block radix select pqt_block_kth_u64, 4 = wave scan pqt_wave_incl_scan of
+// ones (exclusive = inclusive - 1, per wavefront of the block, offset by the wave's base), 5 = block scan pqt_block_excl_scan of N ones
+// held N / 256 per thread.  Keys are built like the product's: pqt_f2key(value) << 32 | payload.
+// ===================================================================================================
+#ifdef PQT_MAIN_TU
+template <int R>
+__device__ __forceinline__ void pqt_dbg_wave_sort(uint32_t n, uint32_t* out) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t key[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; key[r] = ((uint64_t)pqt_f2key((float)(n - e)) << 32) | e; }
+  pqt_wave_sort_u64<R>(key);
+#pragma unroll
+  for (int r = 0; r < R; ++r) out[lane * R + r] = (uint32_t)key[r];
+}
+template <int R>
+__device__ __forceinline__ void pqt_dbg_wave_kth(uint32_t n, uint32_t* out, uint32_t* hist) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint64_t key[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { const uint32_t e = r * 64 + lane; key[r] = ((uint64_t)pqt_f2key((float)(n - e)) << 32) | e; }
+  for (uint32_t j = 0; j < n; ++j) {
+    const uint64_t tau = pqt_wave_kth_u64<R>(key, j + 1, hist);
+    if (lane == 0) out[j] = (uint32_t)tau;
+  }
+}
+__global__ __launch_bounds__(256) void pqt_k_debug_sortscan(uint32_t mode, uint32_t n, uint32_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* sKey = reinterpret_cast<uint64_t*>(smem_raw);
+  const uint32_t tid = threadIdx.x;
+  if (mode == 0) {
+    if (tid >= 64) return;
+    if (n == 64) pqt_dbg_wave_sort<1>(n, out); else if (n == 128) pqt_dbg_wave_sort<2>(n, out); else if (n == 256) pqt_dbg_wave_sort<4>(n, out);
+    else if (n == 512) pqt_dbg_wave_sort<8>(n, out); else if (n == 1024) pqt_dbg_wave_sort<16>(n, out); else if (n == 2048) pqt_dbg_wave_sort<32>(n, out);
+  } else if (mode == 1) {
+    for (uint32_t e = tid; e < n; e += 256) sKey[e] = ((uint64_t)pqt_f2key((float)(n - e)) << 32) | e;
+    __syncthreads();
+    pqt_bitonic_sort_u64<256>(sKey, n);
+    for (uint32_t e = tid; e < n; e += 256) out[e] = (uint32_t)sKey[e];
+  } else if (mode == 2) {
+    if (tid >= 64) return;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);  // 256 u32 + 4 u64
+    if (n == 512) pqt_dbg_wave_kth<8>(n, out, hist); else if (n == 1024) pqt_dbg_wave_kth<16>(n, out, hist);
+  } else if (mode == 3) {
+    uint32_t* hist = reinterpret_cast<uint32_t*>(sKey + n);
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(hist + 256);
+    for (uint32_t e = tid; e < n; e += 256) sKey[e] = ((uint64_t)pqt_f2key((float)(n - e)) << 32) | e;
+    __syncthreads();
+    for (uint32_t j = 0; j < n; j += (n >> 6)) {  // 64 ranks spread over the range (each costs a few block-wide passes)
+      const uint64_t tau = pqt_block_kth_u64<256>(sKey, n, j + 1, hist, slot);
+      if (tid == 0) out[j] = (uint32_t)tau;
+      __syncthreads();
+    }
+  } else if (mode == 4) {
+    for (uint32_t e = tid; e < n; e += 256) {  // every wavefront scans its 64 ones; element e sits in lane e % 64 of round e / 64
+      const uint32_t incl = pqt_wave_incl_scan(1u);
+      out[e] = (e & ~63u) + incl - 1u;
+    }
+  } else if (mode == 5) {
+    uint32_t* sPart = reinterpret_cast<uint32_t*>(smem_raw);
+    const uint32_t per = n / 256;  // ones held per thread (contiguous elements tid*per ..)
+    uint32_t total = 0;
+    const uint32_t base = pqt_block_excl_scan<256>(per, sPart, &total);
+    for (uint32_t i = 0; i < per; ++i) out[tid * per + i] = base + i;
+    if (tid == 0) out[n] = total;
+  }
+}
+#endif  // PQT_MAIN_TU

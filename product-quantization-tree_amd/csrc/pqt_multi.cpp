@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -53,12 +54,22 @@ struct pqt_multi {
   float* hQ = nullptr; uint32_t* hI = nullptr; float* hD = nullptr; uint32_t* hC = nullptr;  // staging of pqt_multi_query_host (device 0)
   size_t capHQ = 0, capHK = 0, capHC = 0;
   bool replicatedTraversal = false;
+  bool drained = false;                 // growDev: all streams already synchronised in this call
+  hipEvent_t evDone = nullptr;          // end of the previous pqt_multi_query on the stream it was enqueued on
 };
 
 namespace {
+// A buffer that grows is freed first.  hipFree only waits for the owning device, but with sync = 0 a peer copy of the PREVIOUS batch that
+// reads it may still be queued on another device's stream (st0 gathering dPack[s], st[d] pulling dBins[s]): every stream of the handle
+// is drained before the first free of a call.
 template <class T>
-int growDev(int device, T** p, size_t* cap, size_t want) {
+int growDev(pqt_multi* m, int device, T** p, size_t* cap, size_t want) {
   if (want <= *cap) return PQT_OK;
+  if (*p && m && !m->drained) {
+    for (int s = 0; s < m->n; ++s) { MHIP(hipSetDevice(m->dev[s])); MHIP(hipStreamSynchronize(m->st[s])); }
+    if (m->evDone) MHIP(hipEventSynchronize(m->evDone));  // the previous batch's merge on the caller's stream (reads dGather)
+    m->drained = true;
+  }
   MHIP(hipSetDevice(device));
   if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
   MHIP(hipMalloc((void**)p, std::max<size_t>(want, 1) * sizeof(T)));
@@ -70,6 +81,29 @@ int peerCopy(void* dst, int dd, const void* src, int sd, size_t bytes, hipStream
   if (!bytes) return PQT_OK;
   if (dd == sd) MHIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
   else MHIP(hipMemcpyPeerAsync(dst, dd, src, sd, bytes, st));
+  return PQT_OK;
+}
+}  // namespace
+
+namespace {
+// the table of shard 0 (built once: the reference's sort of all (W*C2)^P tuples, or the CUDA library's order) handed to the other
+// shards as a prefix.  The shard keeps min(rows, number of tuples) rows: the vector is sized from what it holds, not from the
+// caller's `rows` (which may be "all rows" = 2^32), and nothing throws across the C-ABI.
+int broadcastHeuristic(pqt_multi* m, uint64_t rows) {
+  if (m->n <= 1) return PQT_OK;
+  uint64_t total = 1;  // tuples that exist: (W*C2)^P, saturating
+  for (uint32_t i = 0; i < m->prm.p; ++i) { total *= (uint64_t)m->prm.w * m->prm.c2; if (total > ((uint64_t)1 << 40)) { total = (uint64_t)1 << 40; break; } }
+  uint64_t ask = std::min<uint64_t>(rows, total);
+  if (ask > ((uint64_t)1 << 28)) return mfail(PQT_ERR_LIMIT, "heuristic prefix of more than 2^28 rows");
+  try {
+    std::vector<uint32_t> t((size_t)ask * m->prm.p, 0xffffffffu);
+    uint64_t have = ask;
+    MPQT(pqt_index_get_heuristic(m->sh[0], t.data(), ask));
+    while (have > 0 && t[(have - 1) * m->prm.p] == 0xffffffffu) --have;  // rows beyond the table were not written
+    for (int s = 1; s < m->n; ++s) MPQT(pqt_index_set_heuristic(m->sh[s], t.data(), have));
+  } catch (const std::exception& e) {
+    return mfail(PQT_ERR_LIMIT, std::string("heuristic hand-over failed: ") + e.what());
+  }
   return PQT_OK;
 }
 }  // namespace
@@ -108,7 +142,8 @@ int pqt_multi_create(const pqt_params* prm, int nshards, const int* devices, pqt
           (void)hipGetLastError();
         }
       }
-  if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventCreateWithFlags(&m->evIn, hipEventDisableTiming) != hipSuccess) {
+  if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventCreateWithFlags(&m->evIn, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&m->evDone, hipEventDisableTiming) != hipSuccess) {
     pqt_multi_destroy(m);
     return mfail(PQT_ERR_DEVICE, "event creation failed");
   }
@@ -130,6 +165,7 @@ void pqt_multi_destroy(pqt_multi* m) {
   if (m->n) (void)hipSetDevice(m->dev[0]);
   for (void* p : {(void*)m->dGather, (void*)m->hQ, (void*)m->hI, (void*)m->hD, (void*)m->hC}) if (p) (void)hipFree(p);
   if (m->evIn) (void)hipEventDestroy(m->evIn);
+  if (m->evDone) (void)hipEventDestroy(m->evDone);
   delete m;
 }
 
@@ -161,16 +197,13 @@ int pqt_multi_build_heuristic(pqt_multi* m, uint64_t rows) {
   if (!m) return mfail(PQT_ERR_INVALID, "null argument");
   // the table is built once (the reference's sort of all (W*C2)^P tuples) and handed to the other shards as a prefix
   MPQT(pqt_index_build_heuristic(m->sh[0], rows));
-  if (m->n > 1) {
-    std::vector<uint32_t> t((size_t)rows * m->prm.p);
-    uint64_t have = rows;
-    // the shard keeps min(rows, (W*C2)^P) rows: ask for what it holds
-    std::fill(t.begin(), t.end(), 0xffffffffu);
-    MPQT(pqt_index_get_heuristic(m->sh[0], t.data(), rows));
-    while (have > 0 && t[(have - 1) * m->prm.p] == 0xffffffffu) --have;  // rows beyond the table were not written
-    for (int s = 1; s < m->n; ++s) MPQT(pqt_index_set_heuristic(m->sh[s], t.data(), have));
-  }
-  return PQT_OK;
+  return broadcastHeuristic(m, rows);
+}
+
+int pqt_multi_build_heuristic_cuda(pqt_multi* m, uint32_t max_cluster, uint64_t rows) {
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  MPQT(pqt_index_build_heuristic_cuda(m->sh[0], max_cluster, rows));
+  return broadcastHeuristic(m, rows);
 }
 
 int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows) {
@@ -209,14 +242,15 @@ int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv,
   const uint32_t D = m->prm.dim;
   const uint32_t kBinCap = binCapFor(Bb);
   const size_t wordsPack = (size_t)3 * qn * k, wordsBins = (size_t)qn * (kBinCap + 1);
+  m->drained = false;
   for (int s = 0; s < n; ++s) {
     int rc;
-    if (s > 0 && (rc = growDev(m->dev[s], &m->dQ[s], &m->capQ[s], (size_t)qn * D))) return rc;
-    if ((rc = growDev(m->dev[s], &m->dBins[s], &m->capBins[s], wordsBins))) return rc;
-    if ((rc = growDev(m->dev[s], &m->dPack[s], &m->capPack[s], wordsPack))) return rc;
-    if ((rc = growDev(m->dev[s], &m->dCount[s], &m->capCount[s], (size_t)qn))) return rc;
+    if (s > 0 && (rc = growDev(m, m->dev[s], &m->dQ[s], &m->capQ[s], (size_t)qn * D))) return rc;
+    if ((rc = growDev(m, m->dev[s], &m->dBins[s], &m->capBins[s], wordsBins))) return rc;
+    if ((rc = growDev(m, m->dev[s], &m->dPack[s], &m->capPack[s], wordsPack))) return rc;
+    if ((rc = growDev(m, m->dev[s], &m->dCount[s], &m->capCount[s], (size_t)qn))) return rc;
   }
-  { int rc; if ((rc = growDev(m->dev[0], &m->dGather, &m->capGather, (size_t)n * wordsPack))) return rc; }
+  { int rc; if ((rc = growDev(m, m->dev[0], &m->dGather, &m->capGather, (size_t)n * wordsPack))) return rc; }
   MHIP(hipSetDevice(m->dev[0]));
   hipStream_t st0 = hip_stream ? (hipStream_t)hip_stream : m->st[0];
   // the batch is ready (and the previous batch of this handle fully merged) once everything enqueued on st0 so far has run
@@ -272,22 +306,26 @@ int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv,
   MPQT(pqt_merge_topk(m->sh[0], (uint32_t)n, qn, k, m->dGather, reinterpret_cast<const float*>(m->dGather + (size_t)qn * k), m->dGather + (size_t)2 * qn * k,
                       (uint64_t)wordsPack, out_idx_dev0, out_dist_dev0, st0, 0));
   if (out_count_dev0) MHIP(hipMemcpyAsync(out_count_dev0, m->dCount[0], (size_t)qn * 4, hipMemcpyDeviceToDevice, st0));
+  MHIP(hipEventRecord(m->evDone, st0));
   if (sync) MHIP(hipStreamSynchronize(st0));
   return PQT_OK;
 }
 
 int pqt_multi_query_host(pqt_multi* m, const float* q_host, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* out_idx_host,
                          float* out_dist_host, uint32_t* out_count_host) {
-  if (!m || !q_host || !out_idx_host || !out_dist_host) return mfail(PQT_ERR_INVALID, "null argument");
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  if (qn == 0) return PQT_OK;  // like pqt_query
+  if (!q_host || !out_idx_host || !out_dist_host) return mfail(PQT_ERR_INVALID, "null argument");
   const size_t nq = (size_t)qn * m->prm.dim, nk = (size_t)qn * k;
   int rc;
-  if ((rc = growDev(m->dev[0], &m->hQ, &m->capHQ, nq))) return rc;
+  m->drained = false;
+  if ((rc = growDev(m, m->dev[0], &m->hQ, &m->capHQ, nq))) return rc;
   if (nk > m->capHK) {
     size_t c1 = m->capHK, c2 = m->capHK;
-    if ((rc = growDev(m->dev[0], &m->hI, &c1, nk)) || (rc = growDev(m->dev[0], &m->hD, &c2, nk))) { m->capHK = 0; return rc; }
+    if ((rc = growDev(m, m->dev[0], &m->hI, &c1, nk)) || (rc = growDev(m, m->dev[0], &m->hD, &c2, nk))) { m->capHK = 0; return rc; }
     m->capHK = nk;
   }
-  if ((rc = growDev(m->dev[0], &m->hC, &m->capHC, (size_t)qn))) return rc;
+  if ((rc = growDev(m, m->dev[0], &m->hC, &m->capHC, (size_t)qn))) return rc;
   MHIP(hipSetDevice(m->dev[0]));
   MHIP(hipMemcpyAsync(m->hQ, q_host, nq * 4, hipMemcpyHostToDevice, m->st[0]));
   if ((rc = pqt_multi_query(m, m->hQ, qn, Bv, Bb, k, m->hI, m->hD, m->hC, m->st[0], 0))) return rc;

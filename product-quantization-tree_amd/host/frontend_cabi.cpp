@@ -1,0 +1,67 @@
+// frontend_cabi.cpp -- libpqt_frontend.so: a C wrapper around pqt::PerturbationProTree so that bench.py / the tests can time and check
+// the KEPT C++ front-end (the call the reference's tool_query makes per batch, tool_query.cpp:153-161: queryKNN with a device query
+// pointer and two std::vectors that are resized and filled) from Python without going through files.  Test/bench glue: the product
+// surface is the class (host/pqt/PerturbationProTree.hh) and the C-ABI under it (include/pqt_hip.h).
+#include <hip/hip_runtime_api.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "pqt/PerturbationProTree.hh"
+
+using namespace pqt;
+
+namespace {
+thread_local std::string g_err;
+struct Fe {
+  PerturbationProTree t;
+  std::vector<uint> idx;
+  std::vector<float> dist;
+  Fe(uint dim, uint p) : t(dim, p, p) {}
+};
+}  // namespace
+
+extern "C" {
+
+const char* pqtfe_last_error(void) { return g_err.c_str(); }
+
+// tree + database handed over as host arrays (the class copies them, like setTree / setBins / setLines); ndev > 1: range-sharded
+void* pqtfe_create(uint32_t dim, uint32_t p, uint32_t c1, uint32_t c2, uint32_t w, uint32_t lp, const float* cb1, const float* cb2,
+                   uint64_t nbins, const uint32_t* binIds, const uint32_t* binSizes, const uint32_t* members, const uint32_t* codes, uint64_t nvec,
+                   const int* devices, int ndev) {
+  try {
+    Fe* f = new Fe(dim, p);
+    if (ndev > 1) f->t.setDevices(std::vector<int>(devices, devices + ndev));
+    else f->t.setDevice(ndev == 1 ? devices[0] : 0);
+    f->t.setW(w);
+    f->t.prepareEmptyLambda(0, lp);
+    f->t.setTree(c1, c2, cb1, cb2);
+    f->t.setBins((size_t)nbins, binIds, binSizes, members);
+    f->t.setLines(reinterpret_cast<const lineDescr*>(codes), (size_t)nvec);
+    return f;
+  } catch (const std::exception& e) { g_err = e.what(); return nullptr; }
+}
+
+void pqtfe_destroy(void* h) { delete static_cast<Fe*>(h); }
+
+// `reps` calls of queryKNN(resIdx, resDist, q_dev, qn, nvec) on the SAME two vectors (tool_query's loop reuses them); timing[6] =
+// means over the calls of {total, kernels, d2h, host} ms, bytes over PCIe and columns copied per row; the vectors of the last call are
+// copied to out_idx / out_dist when those are not null
+int pqtfe_queryKNN(void* h, const float* q_dev, uint32_t qn, uint32_t nvec, uint32_t bv, uint32_t bb, int reps, double* timing, uint32_t* out_idx,
+                   float* out_dist) {
+  try {
+    Fe* f = static_cast<Fe*>(h);
+    f->t.setBounds(bv, bb);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r) {
+      f->t.queryKNN(f->idx, f->dist, q_dev, qn, nvec);
+      const PerturbationProTree::CallTiming& c = f->t.lastCallTiming();
+      acc[0] += c.total_ms; acc[1] += c.kernels_ms; acc[2] += c.d2h_ms; acc[3] += c.host_ms; acc[4] += (double)c.d2h_bytes; acc[5] += c.columns;
+    }
+    if (timing) for (int i = 0; i < 6; ++i) timing[i] = acc[i] / (reps > 0 ? reps : 1);
+    if (out_idx) memcpy(out_idx, f->idx.data(), f->idx.size() * 4);
+    if (out_dist) memcpy(out_dist, f->dist.data(), f->dist.size() * 4);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

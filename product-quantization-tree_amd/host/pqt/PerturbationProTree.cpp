@@ -2,12 +2,16 @@
 #include "PerturbationProTree.hh"
 
 #include <hip/hip_runtime_api.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <stdexcept>
+#include <thread>
 
 namespace pqt {
 
@@ -26,13 +30,24 @@ void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_hashPrefix(nullptr),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_resCnt(nullptr), d_resCntCap(0),
+      h_stageIdx(nullptr), h_stageDist(nullptr), h_stageCap(0), h_stageCnt(nullptr), h_stageCntCap(0), d_copyStream(nullptr), d_evIdx(nullptr), d_evDist(nullptr),
+      d_lastTiming(), d_hashPrefix(nullptr),
       d_hashCounts(nullptr), d_hashSizeHeld(0), d_lineById(nullptr), d_lineByIdValid(false), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
 
 void PerturbationProTree::releaseDeviceScratch() {
   if (d_resIdx) (void)hipFree(d_resIdx);
   if (d_resDist) (void)hipFree(d_resDist);
+  if (d_resCnt) (void)hipFree(d_resCnt);
+  if (h_stageIdx) (void)hipHostFree(h_stageIdx);
+  if (h_stageDist) (void)hipHostFree(h_stageDist);
+  if (h_stageCnt) (void)hipHostFree(h_stageCnt);
+  if (d_evIdx) (void)hipEventDestroy(d_evIdx);
+  if (d_evDist) (void)hipEventDestroy(d_evDist);
+  if (d_copyStream) (void)hipStreamDestroy(d_copyStream);
+  d_resCnt = nullptr; d_resCntCap = 0; h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0; h_stageCnt = nullptr; h_stageCntCap = 0;
+  d_copyStream = nullptr; d_evIdx = d_evDist = nullptr;
   if (d_hashPrefix) (void)hipFree(d_hashPrefix);
   if (d_hashCounts) (void)hipFree(d_hashCounts);
   if (d_lineById) (void)hipFree(d_lineById);
@@ -59,6 +74,35 @@ void PerturbationProTree::ensureResultBuffers(size_t _n) {
   d_resCap = _n;
 }
 
+// pinned staging of queryKNN's results (grown on demand, lives as long as the object) + the copy stream and its two events
+void PerturbationProTree::ensureStaging(size_t _n, size_t _qn) {
+  if (!d_copyStream) {
+    if (hipStreamCreateWithFlags(&d_copyStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d_evIdx, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d_evDist, hipEventDisableTiming) != hipSuccess)
+      throw std::runtime_error("stream / event creation failed");
+  }
+  if (_n > h_stageCap) {
+    if (h_stageIdx) (void)hipHostFree(h_stageIdx);
+    if (h_stageDist) (void)hipHostFree(h_stageDist);
+    h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0;
+    if (hipHostMalloc((void**)&h_stageIdx, _n * 4, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&h_stageDist, _n * 4, hipHostMallocDefault) != hipSuccess)
+      throw std::runtime_error("pinned host allocation failed");
+    h_stageCap = _n;
+  }
+  if (_qn > h_stageCntCap) {
+    if (h_stageCnt) (void)hipHostFree(h_stageCnt);
+    h_stageCnt = nullptr; h_stageCntCap = 0;
+    if (hipHostMalloc((void**)&h_stageCnt, _qn * 4, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("pinned host allocation failed");
+    h_stageCntCap = _qn;
+  }
+  if (_qn > d_resCntCap) {
+    if (d_resCnt) (void)hipFree(d_resCnt);
+    d_resCnt = nullptr; d_resCntCap = 0;
+    if (hipMalloc((void**)&d_resCnt, _qn * 4) != hipSuccess) throw std::runtime_error("device allocation failed");
+    d_resCntCap = _qn;
+  }
+}
+
 void PerturbationProTree::check(int rc, const char* what) {
   if (rc != PQT_OK) throw std::runtime_error(std::string(what) + ": " + pqt_last_error());
 }
@@ -74,8 +118,19 @@ void PerturbationProTree::singleDeviceOnly(const char* what) const {
 }
 
 void PerturbationProTree::prepareDistSequence(uint _rows) {
-  if (d_multi) { if (pqt_multi_build_heuristic(d_multi, _rows) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); return; }
-  ProTree::prepareDistSequence(_rows);
+  if (d_multi) { if (pqt_multi_build_heuristic(d_multi, _rows) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
+  else ProTree::prepareDistSequence(_rows);
+  d_heurRows = _rows;
+}
+
+// the CUDA library's order (ProTree.cu:128-207) as the table: with several devices EVERY shard gets it (the traversal is sharded by
+// query slice, so a table on shard 0 only would order one slice's bins differently from the others').  The table holds at most 65536
+// rows; d_heurRows records it so that a later queryKNN does not silently replace it by the cpu_version table.
+void PerturbationProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
+  if (_groupParts != (int)d_p) throw std::runtime_error("prepareDistSequence: groupParts must equal p");
+  if (d_multi) { if (pqt_multi_build_heuristic_cuda(d_multi, (uint32_t)_maxCluster, 65536) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
+  else ProTree::prepareDistSequence(_maxCluster, _groupParts);
+  d_heurRows = 65536;
 }
 
 void PerturbationProTree::uploadLines(size_t _N) {
@@ -518,21 +573,102 @@ const uint* PerturbationProTree::getBinCounts(uint _hashSize) {
 }
 
 void PerturbationProTree::ensureHeuristic(uint rows) {
-  if (rows > d_heurRows) { prepareDistSequence(rows); d_heurRows = rows; }
+  if (rows > d_heurRows) prepareDistSequence(rows);
 }
 
+namespace {
+// rows [r0, r1) of a padded result array: the first cnt[r] entries from the compact staging rows (pitch `cols`), the reference's
+// padding behind them
+template <class T>
+void scatterRows(T* dst, const T* stage, const uint* cnt, size_t r0, size_t r1, size_t nVec, size_t cols, T pad) {
+  for (size_t r = r0; r < r1; ++r) {
+    const size_t c = std::min<size_t>(cnt[r], nVec);
+    T* d = dst + r * nVec;
+    if (c) memcpy(d, stage + r * cols, c * sizeof(T));
+    std::fill(d + c, d + nVec, pad);
+  }
+}
+template <class T>
+void scatterParallel(T* dst, const T* stage, const uint* cnt, size_t rows, size_t nVec, size_t cols, T pad) {
+  const size_t words = rows * nVec;
+  size_t nt = words < ((size_t)1 << 18) ? 1 : std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), rows);
+  if (nt <= 1) { scatterRows(dst, stage, cnt, 0, rows, nVec, cols, pad); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < nt; ++t) th.emplace_back(scatterRows<T>, dst, stage, cnt, rows * t / nt, rows * (t + 1) / nt, nVec, cols, pad);
+  scatterRows(dst, stage, cnt, 0, rows / nt, nVec, cols, pad);
+  for (auto& x : th) x.join();
+}
+double msSince(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+}  // namespace
+
+// Same contract as the reference (PerturbationProTree.cu:8179-8183, 8278-8281): the two vectors are resized to _QN * _nVec and every
+// row is padded.  What changed against round 3 (two synchronous pageable copies of the whole padded [QN][nVec] arrays -- 134 MB per
+// 4096-query batch at _nVec = 4096, ~82 % of it padding): the engine reports each query's list length, only the first
+// max(length) columns cross PCIe (one strided copy per array into pinned staging owned by the object), and the padding is written
+// on the host by a few threads while the second array is still in flight.
 void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec) {
+  const auto tAll = std::chrono::steady_clock::now();
   pqt_index* h = handle();
   ensureHeuristic(d_boundBins);
-  _resIdx.resize((size_t)_QN * _nVec);
-  _resDist.resize((size_t)_QN * _nVec);
-  if (!_QN) return;
+  const size_t n = (size_t)_QN * _nVec;
+  double hostMs = 0;
+  {
+    const auto t = std::chrono::steady_clock::now();
+    if (_resIdx.size() != n) _resIdx.resize(n);    // (value-initialises only what is new: a caller that reuses its vectors pays once)
+    if (_resDist.size() != n) _resDist.resize(n);
+    hostMs += msSince(t);
+  }
+  d_lastTiming = CallTiming();
+  if (!_QN || !_nVec) return;
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-  ensureResultBuffers(_resIdx.size());
-  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
-  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, nullptr, nullptr, 1), "queryKNN");
-  d2h(_resIdx.data(), d_resIdx, _resIdx.size() * 4);
-  d2h(_resDist.data(), d_resDist, _resDist.size() * 4);
+  ensureResultBuffers(n);
+  ensureStaging(n, _QN);
+  auto t = std::chrono::steady_clock::now();
+  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, d_resCnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
+  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, d_resCnt, nullptr, 1), "queryKNN");
+  d_lastTiming.kernels_ms = msSince(t);
+  const bool legacyCopy = getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr;  // read per call: bench.py toggles it between its two legs
+  if (legacyCopy) {
+    // measurement only (profiles/r04_frontend_queryKNN.json "before"): round 3's hand-over -- two synchronous copies of the whole
+    // padded arrays into the caller's pageable vectors
+    t = std::chrono::steady_clock::now();
+    d2h(_resIdx.data(), d_resIdx, n * 4);
+    d2h(_resDist.data(), d_resDist, n * 4);
+    d_lastTiming.d2h_ms = msSince(t);
+    d_lastTiming.host_ms = hostMs;
+    d_lastTiming.total_ms = msSince(tAll);
+    d_lastTiming.d2h_bytes = 2 * n * 4;
+    d_lastTiming.columns = _nVec;
+    return;
+  }
+  t = std::chrono::steady_clock::now();
+  if (hipMemcpyAsync(h_stageCnt, d_resCnt, (size_t)_QN * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipStreamSynchronize(d_copyStream) != hipSuccess)
+    throw std::runtime_error("D2H copy failed");
+  uint maxc = 0;
+  for (uint q = 0; q < _QN; ++q) maxc = std::max(maxc, std::min(h_stageCnt[q], _nVec));
+  const size_t cols = maxc;
+  if (cols) {
+    if (hipMemcpy2DAsync(h_stageIdx, cols * 4, d_resIdx, (size_t)_nVec * 4, cols * 4, _QN, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess ||
+        hipEventRecord(d_evIdx, d_copyStream) != hipSuccess ||
+        hipMemcpy2DAsync(h_stageDist, cols * 4, d_resDist, (size_t)_nVec * 4, cols * 4, _QN, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess ||
+        hipEventRecord(d_evDist, d_copyStream) != hipSuccess)
+      throw std::runtime_error("D2H copy failed");
+    if (hipEventSynchronize(d_evIdx) != hipSuccess) throw std::runtime_error("D2H copy failed");
+  }
+  d_lastTiming.d2h_ms = msSince(t);
+  t = std::chrono::steady_clock::now();
+  scatterParallel<uint>(_resIdx.data(), h_stageIdx, h_stageCnt, _QN, _nVec, cols, 0xffffffffu);
+  hostMs += msSince(t);
+  t = std::chrono::steady_clock::now();
+  if (cols && hipEventSynchronize(d_evDist) != hipSuccess) throw std::runtime_error("D2H copy failed");
+  d_lastTiming.d2h_ms += msSince(t);
+  t = std::chrono::steady_clock::now();
+  scatterParallel<float>(_resDist.data(), h_stageDist, h_stageCnt, _QN, _nVec, cols, std::numeric_limits<float>::infinity());
+  hostMs += msSince(t);
+  d_lastTiming.host_ms = hostMs;
+  d_lastTiming.total_ms = msSince(tAll);
+  d_lastTiming.d2h_bytes = (size_t)_QN * 4 + 2 * cols * 4 * (size_t)_QN;
+  d_lastTiming.columns = maxc;
 }
 
 void PerturbationProTree::queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,

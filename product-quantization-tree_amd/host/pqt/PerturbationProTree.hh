@@ -19,6 +19,9 @@
 #include "../../../include/pqt_hip.h"
 
 typedef unsigned int uint;
+// the two HIP handle types the class keeps (same declarations as hip_runtime_api.h, so that this header needs no HIP include)
+typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
 
 namespace pqt {
 
@@ -83,7 +86,7 @@ class PerturbationProTree : public ProTree {
   size_t getNDevices() const { return d_devices.size() > 1 ? d_devices.size() : 1; }
   /** shadows ProTree's: with several devices every shard gets the table */
   void prepareDistSequence(uint _rows);
-  void prepareDistSequence(int _maxCluster, int _groupParts) { ProTree::prepareDistSequence(_maxCluster, _groupParts); }
+  void prepareDistSequence(int _maxCluster, int _groupParts);
   /** W of treequantizer<..,W,..> / k1 of queryKNN (PerturbationProTree.cu:8187); call before reading a tree */
   void setW(uint _w) { d_w = _w; }
   /** query bounds of treequantizer::query(boundVectors, boundBins, ..) (cpu_version/tools/query.cpp:42) */
@@ -163,6 +166,17 @@ class PerturbationProTree : public ProTree {
   const uint* getBinPrefix(uint _hashSize = 400000000u);
   const uint* getBinCounts(uint _hashSize = 400000000u);
 
+  /** wall-clock split of the last queryKNN call (no reference counterpart; bench.py's frontend_queryKNN leg reads it) */
+  struct CallTiming {
+    double kernels_ms = 0;   // pqt_query / pqt_multi_query including its final synchronisation
+    double d2h_ms = 0;       // waiting for the device-to-host copies (list lengths + the used columns of both arrays)
+    double host_ms = 0;      // resizing the result vectors, scattering the staged rows into them, writing the padding
+    double total_ms = 0;
+    size_t d2h_bytes = 0;    // bytes that crossed PCIe
+    uint columns = 0;        // columns copied per row = the longest list of the batch (<= _nVec)
+  };
+  const CallTiming& lastCallTiming() const { return d_lastTiming; }
+
   uint getNPerturbations() const { return 1; }
   pqt_stats lastStats();
   const std::vector<uint>& binIds() const { return h_binIds; }
@@ -173,6 +187,7 @@ class PerturbationProTree : public ProTree {
   void check(int rc, const char* what);
 
   void ensureResultBuffers(size_t _n);
+  void ensureStaging(size_t _n, size_t _qn);
   void releaseDeviceScratch();
 
   void uploadLines(size_t _N);
@@ -183,6 +198,11 @@ class PerturbationProTree : public ProTree {
   std::vector<int> d_devices;
   // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
   uint* d_resIdx; float* d_resDist; size_t d_resCap;
+  uint* d_resCnt; size_t d_resCntCap;                               // candidate-list length of every query of the last batch
+  uint* h_stageIdx; float* h_stageDist; size_t h_stageCap;          // pinned host staging of the used result columns
+  uint* h_stageCnt; size_t h_stageCntCap;
+  hipStream_t d_copyStream; hipEvent_t d_evIdx, d_evDist;
+  CallTiming d_lastTiming;
   uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;
   lineDescr* d_lineById; bool d_lineByIdValid;  // id-ordered device copy behind getLine()
   std::vector<uint> h_binOfVec;  // chunked build: bin id of every vector seen so far

@@ -45,12 +45,15 @@ int main(int argc, char* argv[]) {
     std::vector<float> qh = qr.data(qn);
     PerturbationProTree ppt(dim, p, p);
     ppt.setDevice((int)F.num("device"));
+    int queryDevice = (int)F.num("device");  // where the query batch is uploaded: the (first) device of the database
     {
       std::vector<int> devs;
       const std::string dl = F.str("devices");
       for (size_t a = 0; a < dl.size();) { size_t b = dl.find(',', a); if (b == std::string::npos) b = dl.size(); if (b > a) devs.push_back(atoi(dl.substr(a, b - a).c_str())); a = b + 1; }
       if (devs.empty() && F.num("gpus") > 1) for (int g = 0; g < (int)F.num("gpus"); ++g) devs.push_back(g);
       if (devs.size() > 1) { ppt.setDevices(devs); std::cout << "database range-sharded over " << devs.size() << " devices" << std::endl; }
+      else if (devs.size() == 1) { ppt.setDevice(devs[0]); queryDevice = devs[0]; }  // --devices N overrides --device like the longer lists do
+      if (devs.size() > 1) queryDevice = devs[0];
     }
     ppt.setW((uint)F.num("w"));
     ppt.prepareEmptyLambda(0, lp);
@@ -71,7 +74,7 @@ int main(int argc, char* argv[]) {
       std::cout << "read " << pre << ".prefix" << std::endl << "read " << pre << ".count" << std::endl << "read " << pre << ".dbIdx" << std::endl
                 << "read " << pre << "_" << lp << ".lines" << std::endl;
     }
-    if (hipSetDevice(ppt.getNDevices() > 1 ? (F.str("devices").empty() ? 0 : atoi(F.str("devices").c_str())) : (int)F.num("device")) != hipSuccess) { std::cerr << "no device" << std::endl; return 1; }
+    if (hipSetDevice(queryDevice) != hipSuccess) { std::cerr << "no device" << std::endl; return 1; }
     float* qd = nullptr;
     if (hipMalloc((void**)&qd, qh.size() * 4) != hipSuccess || hipMemcpy(qd, qh.data(), qh.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
       std::cerr << "query upload failed" << std::endl; return 1;

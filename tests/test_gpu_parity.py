@@ -8,7 +8,7 @@ order (see DESIGN.md "ties").
 import numpy as np
 import pytest
 
-from common import CONFIGS, fixture, pqt_pkg
+from common import CONFIGS, fixture, pqt_pkg, sift_like
 
 pytestmark = pytest.mark.gpu
 
@@ -1253,5 +1253,196 @@ def test_short_lists_sorted_by_one_wavefront_long_ones_by_the_block_kernel(name,
         ids2, dist2, cnt2 = idx.query(f.queries, bv, bb, k)
         assert "+small-lists" not in idx.last_path()
         assert np.array_equal(ids2, ids) and np.array_equal(bits(dist2), bits(dist)) and np.array_equal(cnt2, cnt)
+    finally:
+        idx.close()
+
+
+def test_multi_handle_on_distinct_devices_equals_single_index():
+    """the one-handle multi-GPU path with every shard on its OWN device -- hipMemcpyPeerAsync, hipDeviceEnablePeerAccess
+    and hipStreamWaitEvent on another device's event really execute.  Needs >= 2 GPUs; the 1-GPU test box skips (the same-device
+    variant above covers the protocol there)."""
+    import torch
+    pkg = pqt_pkg()
+    ndev = pkg.lib().pqt_device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 gfx950 devices (this box has %d)" % ndev)
+    f = fixture("cfg3_small")
+    c = f.cfg
+    ref = f.hip_index()
+    nsh = min(ndev, 4)
+    m = pkg.PqtMulti(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], list(range(nsh)))
+    try:
+        m.set_codebooks(f.cb1, f.cb2)
+        m.set_heuristic(f.heur)
+        m.set_bins(f.bin_ids, f.bin_sizes, f.members)
+        m.set_lines(f.codes)
+        Bv, Bb = BV_BB["cfg3_small"]
+        for qn in (f.queries.shape[0], 5):  # the second, smaller batch reuses the buffers; a third, larger one grows them
+            r_ids, r_d, r_c = ref.query(f.queries[:qn], Bv, Bb, 100)
+            h_ids, h_d, h_c = m.query(f.queries[:qn], Bv, Bb, 100)
+            assert np.array_equal(h_ids, r_ids) and np.array_equal(bits(h_d), bits(r_d)) and np.array_equal(h_c, r_c)
+        big = np.concatenate([f.queries, f.queries[::-1]])
+        r_ids, r_d, _ = ref.query(big, Bv, Bb, 100)
+        h_ids, h_d, _ = m.query(big, Bv, Bb, 100)
+        assert np.array_equal(h_ids, r_ids) and np.array_equal(bits(h_d), bits(r_d))
+    finally:
+        m.close()
+        ref.close()
+
+
+def test_multi_handle_heuristics_reach_every_shard_and_hostile_row_counts_are_clamped():
+    """(1) the CUDA-order table (prepareDistSequence(maxCluster, groupParts)) must be on EVERY shard -- the traversal is
+    sharded by query slice, so a table on shard 0 only orders one slice's bins differently; (2) pqt_multi_build_heuristic with
+    rows = 2^32 ("all rows") clamps to the table instead of throwing across the C-ABI; (3) pqt_multi_query_host with qn = 0 is OK."""
+    pkg = pqt_pkg()
+    f = fixture("tools_default")
+    c = f.cfg
+    ref = f.hip_index()
+    m = pkg.PqtMulti(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], [0, 0, 0])
+    try:
+        m.set_codebooks(f.cb1, f.cb2)
+        m.set_bins(f.bin_ids, f.bin_sizes, f.members)
+        m.set_lines(f.codes)
+        Bv, Bb = BV_BB["tools_default"]
+        ref.build_heuristic_cuda(c["C2"] * c["W"], 4096)
+        m.build_heuristic_cuda(c["C2"] * c["W"], 4096)
+        rows = min(4096, min(16, c["C2"] * c["W"]) ** c["P"])
+        want = ref.heuristic(rows)
+        L = pkg.lib()
+        for s in range(3):
+            got = np.zeros((rows, c["P"]), np.uint32)
+            assert L.pqt_index_get_heuristic(L.pqt_multi_shard(m.h, s), got.ctypes.data_as(pkg.u32p), rows) == 0
+            assert np.array_equal(got, want), s
+        bb = min(Bb, rows)
+        r_ids, r_d, r_c = ref.query(f.queries, Bv, bb, 50)
+        h_ids, h_d, h_c = m.query(f.queries, Bv, bb, 50)
+        assert np.array_equal(h_ids, r_ids) and np.array_equal(bits(h_d), bits(r_d)) and np.array_equal(h_c, r_c)
+        # "all rows": (W*C2)^P = 32^2 = 1024 tuples exist
+        m.build_heuristic(2 ** 32)
+        ref.build_heuristic(2 ** 32)
+        r_ids, r_d, _ = ref.query(f.queries, Bv, 1024, 50)
+        h_ids, h_d, _ = m.query(f.queries, Bv, 1024, 50)
+        assert np.array_equal(h_ids, r_ids) and np.array_equal(bits(h_d), bits(r_d))
+        z = np.zeros((0, c["D"]), np.float32)
+        e_ids, e_d, e_c = m.query(z, Bv, Bb, 10)
+        assert e_ids.shape == (0, 10)
+    finally:
+        m.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small"])
+def test_view_handle_serves_a_second_batch_in_flight(name):
+    """pqt_index_create_view: a second handle on the same loaded index (own scratch / stream / statistics).  Two batches enqueued back
+    to back on two streams -- one on the owner, one on the view -- return what the owner alone returns; the view follows the owner's
+    later changes (a longer heuristic prefix); loading into a view and asking it to build shared data are refused."""
+    import torch
+    pkg = pqt_pkg()
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        v = idx.view()
+        Bv, Bb = BV_BB[name]
+        q = torch.from_numpy(f.queries).cuda()
+        qn, k = q.shape[0], 64
+        h = qn // 2
+        with pytest.raises(pkg.PqtError):
+            v.set_codebooks(f.cb1, f.cb2)
+        o_v = [torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty((qn, k), dtype=torch.float32, device="cuda"), torch.empty(qn, dtype=torch.int32, device="cuda")]
+        with pytest.raises(pkg.PqtError):  # the owner has not served a call yet: the bin-ordered line store does not exist
+            v.query_dev(q, Bv, Bb, k, *o_v, sync=True)
+        r_ids, r_d, r_c = idx.query(f.queries, Bv, Bb, k)
+        s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+        o_a = [torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty((qn, k), dtype=torch.float32, device="cuda"), torch.empty(qn, dtype=torch.int32, device="cuda")]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            idx.query_dev(q[:h], Bv, Bb, k, o_a[0][:h], o_a[1][:h], o_a[2][:h], stream=s0.cuda_stream)
+            v.query_dev(q[h:], Bv, Bb, k, o_a[0][h:], o_a[1][h:], o_a[2][h:], stream=s1.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(o_a[0].cpu().numpy().view(np.uint32), r_ids) and np.array_equal(bits(o_a[1].cpu().numpy()), bits(r_d))
+        assert np.array_equal(o_a[2].cpu().numpy().view(np.uint32), r_c)
+        assert v.stats()["queries"] == qn - h and idx.stats()["queries"] == h
+        # the view sees what the owner loads later
+        rows = min(CONFIGS[name]["heur_rows"], 2 * Bb)
+        idx.set_heuristic(f.heur[:rows])
+        r2 = idx.query(f.queries, Bv, rows, k)
+        v.query_dev(q, Bv, rows, k, *o_v, sync=True)
+        assert np.array_equal(o_v[0].cpu().numpy().view(np.uint32), r2[0]) and np.array_equal(bits(o_v[1].cpu().numpy()), bits(r2[1]))
+    finally:
+        idx.close()
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_reference_sort_and_scan_self_checks_through_the_library_primitives(n):
+    """The reference's only sort / scan vectors (pqt/bitonicSort.cuh:213-252): sortTestLarge sorts the values N - tid that carry
+    tid and expects payload[tid] == N - tid - 1, scanTestLarge expects the exclusive scan of ones == tid, for N = 1024, 2048, 4096 --
+    fed to the primitives stage a8 is made of: the in-register wave network, the block-wide bitonic network, both radix selects, both scans."""
+    pkg = pqt_pkg()
+    want = (n - 1 - np.arange(n)).astype(np.uint32)
+    if n <= 2048:
+        assert np.array_equal(pkg.debug_sort_scan(0, n)[:n], want), "pqt_wave_sort_u64"
+    assert np.array_equal(pkg.debug_sort_scan(1, n)[:n], want), "pqt_bitonic_sort_u64"
+    if n == 1024:
+        for m in (512, 1024):  # the j-th smallest value is j + 1 = N - payload
+            assert np.array_equal(pkg.debug_sort_scan(2, m)[:m], (m - 1 - np.arange(m)).astype(np.uint32)), "pqt_wave_kth_u64"
+        for m in (64, 128, 256, 512):
+            assert np.array_equal(pkg.debug_sort_scan(0, m)[:m], (m - 1 - np.arange(m)).astype(np.uint32)), "pqt_wave_sort_u64 (short)"
+    got = pkg.debug_sort_scan(3, n)[:n]
+    asked = np.arange(0, n, n >> 6)
+    assert np.array_equal(got[asked], want[asked]) and (np.delete(got, asked) == 0xffffffff).all(), "pqt_block_kth_u64"
+    assert np.array_equal(pkg.debug_sort_scan(4, n)[:n], np.arange(n, dtype=np.uint32)), "pqt_wave_incl_scan"
+    s5 = pkg.debug_sort_scan(5, n)
+    assert np.array_equal(s5[:n], np.arange(n, dtype=np.uint32)) and s5[n] == n, "pqt_block_excl_scan"
+
+
+def test_config5_shape_throughput_mode_matches_the_checker_with_the_same_prefix():
+    """BASELINE configs[4] shape with the row limit lifted ("enumerate_beyond_wrap" -- NO reference counterpart: the reference's uint32
+    count of heuristic rows wraps to 0 and it enumerates nothing): with the best-first prefix of the sum-of-squares order supplied to
+    the engine and to the checker (whose limit is lifted the same way) the whole path -- a1/a2 at cb1 = 128 KB / cb2 = 8 MB, bin ids
+    in uint32 wrap-around (only parts 0..2 reach them), the cut, MODE 2 over a 2 MB coarse table, top-k -- is bit-identical."""
+    import importlib
+    import torch
+    from oracle import Oracle
+    hp = importlib.import_module("product-quantization-tree_amd.heuristic")
+    D, P, C1, C2, W, LP = 256, 8, 128, 64, 1, 32
+    n, nq = 4000, 24
+    data = np.concatenate([sift_like(n + 2000, 128, 901), sift_like(n + 2000, 128, 902)], 1)
+    rng = np.random.default_rng(9)
+    cb1 = data[n:n + C1].copy()
+    S = D // P
+    pick = rng.integers(0, n, (C1, C2))
+    cb2 = np.stack([data[pick][:, :, p * S:(p + 1) * S] for p in range(P)]).astype(np.float32)
+    base = data[:n]
+    queries = np.clip(np.rint(base[rng.integers(0, n, nq)] + rng.normal(0, 3, (nq, D))), 0, 255).astype(np.float32)
+    rows = 600
+    prefix = hp.heuristic_prefix_best_first(W * C2, P, rows)
+    assert prefix.shape == (rows, P) and (prefix[0] == 0).all() and int((prefix[1:9] ** 2).sum()) == 8  # the eight unit tuples follow the origin
+    o = Oracle(D, P, C1, C2, W, LP, heur_keep=16)
+    o.set_codebooks(cb1, cb2)
+    o.insert(base)
+    o.lift_tuple_wrap(rows)
+    o.set_heuristic(prefix)
+    idx = pqt_pkg().PqtIndex(D, P, C1, C2, W, LP)
+    try:
+        idx.set_codebooks(cb1, cb2)
+        idx.set_option("enumerate_beyond_wrap", 1)
+        idx.set_heuristic(prefix)
+        idx.set_bins(*o.export_bins())
+        idx.set_lines(o.export_codes())
+        o.set_sort_mode(1)
+        total = 0
+        for bv, bb, k in ((200, 600, 32), (50, 100, 8), (10 ** 6, 600, 200)):
+            ids, dist, cnt = idx.query(queries, bv, bb, k)
+            for qi in range(nq):
+                s_ids, s_d = o.query(queries[qi], bv, bb)
+                kk = min(k, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids), (bv, bb, qi, int(cnt[qi]), len(s_ids))
+                assert np.array_equal(ids[qi, :kk], s_ids[:kk]) and np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), (bv, bb, k, qi)
+                total += len(s_ids)
+        assert total > 10 * nq  # the lists are not empty: rows really are enumerated now
+        # default behaviour restored by the option: the reference's empty lists
+        idx.set_option("enumerate_beyond_wrap", 0)
+        _, _, cnt0 = idx.query(queries, 200, 600, 8)
+        assert np.all(cnt0 == 0)
     finally:
         idx.close()

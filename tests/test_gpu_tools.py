@@ -313,3 +313,39 @@ def test_bench_dataset_dir_real_data_leg(tmp_path):
     assert c["id_lists_identical_frac"] == 1.0
     assert c["engine"] == c["checker_on_same_index"]
     assert c["engine"]["recall@100"] >= c["engine"]["recall@1"] and c["engine"]["recall@100"] > 0.5
+
+
+@pytest.mark.parametrize("nvec", [16, 100, 4096])
+def test_frontend_queryKNN_compact_copy_equals_engine_and_legacy_copy(nvec, monkeypatch):
+    """pqt::PerturbationProTree::queryKNN (the call of tool_query.cpp:155): only the used columns cross PCIe and the padding is written on
+    the host -- the resized vectors must hold exactly what the engine's padded device arrays hold (ids, distance bits, 0xffffffff / +inf
+    padding, PerturbationProTree.cu:8278-8281 pads too), and what round 3's whole-array copy returned."""
+    import importlib
+    import torch
+    fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
+    f = fixture("cfg2_small")
+    c = f.cfg
+    fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes)
+    q = torch.from_numpy(f.queries).cuda()
+    qn, bv, bb = q.shape[0], 3000, 512
+    tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=2)
+    idx = f.hip_index()
+    idx.build_heuristic(bb)
+    gi = torch.empty((qn, nvec), dtype=torch.int32, device="cuda")
+    gd = torch.empty((qn, nvec), dtype=torch.float32, device="cuda")
+    gc = torch.empty(qn, dtype=torch.int32, device="cuda")
+    idx.query_dev(q, bv, bb, nvec, gi, gd, gc, sync=True)
+    assert np.array_equal(oi, gi.cpu().numpy().view(np.uint32))
+    assert np.array_equal(od.view(np.uint32), gd.cpu().numpy().view(np.uint32))
+    cnt = gc.cpu().numpy()
+    assert tm["columns"] == min(nvec, int(cnt.max())) and tm["d2h_bytes"] == qn * 4 + 2 * 4 * qn * tm["columns"]
+    short = cnt < nvec
+    if nvec == 4096:
+        assert short.any() and tm["columns"] < nvec  # lists shorter than the rows: padding really was filled on the host
+    for r in np.nonzero(short)[0][:8]:
+        assert (oi[r, cnt[r]:] == 0xffffffff).all() and np.isinf(od[r, cnt[r]:]).all()
+    monkeypatch.setenv("PQT_FRONTEND_LEGACY_COPY", "1")
+    tm2, oi2, od2 = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb)
+    assert np.array_equal(oi, oi2) and np.array_equal(od.view(np.uint32), od2.view(np.uint32)) and tm2["d2h_bytes"] == 2 * 4 * qn * nvec
+    fe.close()
+    idx.close()
