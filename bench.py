@@ -294,10 +294,12 @@ def kernel_bytes(w, qn, k, He, cand_local, fused_rs):
     return {"traverse": (trav, inter_trav), "rerank_select": (rs, inter_rs)}
 
 
-def time_steps(step, barrier, warmup, steps):
+def time_steps(step, barrier, warmup, steps, after_warmup=None):
     for _ in range(warmup):
         step()
     barrier()
+    if after_warmup is not None:
+        after_warmup()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -483,7 +485,11 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
     idx.set_option("stage_timing", period)
     if view is not None:
         view.set_option("stage_timing", period)
-    elapsed = time_steps(step, lambda: barrier(ctx), warmup, steps)
+    def drop_warmup_spans():  # exchange_ms covers the timed region only
+        if timer is not None:
+            for v_ in timer.spans.values():
+                v_.clear()
+    elapsed = time_steps(step, lambda: barrier(ctx), warmup, steps, drop_warmup_spans)
     idx.set_option("stage_timing", 1)  # later legs time every call
     if mode == "shard_db":
         out_idx.copy_(sbuf.out_idx)

@@ -111,7 +111,19 @@ __device__ __forceinline__ void pqt_bitonic_sort_u64(uint64_t* a, uint32_t n) {
 }
 
 // ---- wave / block scans (wave64) -----------------------------------------------------------------
+// inclusive scan over the 64 lanes: four row-local DPP steps (row_shr 1, 2, 4, 8; lanes whose source lies outside the row add 0) and two
+// row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six VALU-latency moves instead of six
+// ds_bpermute round trips (~24 issue cycles each plus the LDS latency, all dependent)
 __device__ __forceinline__ uint32_t pqt_wave_incl_scan(uint32_t v) {
+#ifndef PQT_NO_DPP_SCAN
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+#else
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -119,6 +131,7 @@ __device__ __forceinline__ uint32_t pqt_wave_incl_scan(uint32_t v) {
     if (lane >= d) v += o;
   }
   return v;
+#endif
 }
 // exclusive block scan; sPart must hold BLOCK/64 + 1 words; returns exclusive prefix, *total = block sum
 template <int BLOCK>

@@ -20,6 +20,10 @@ int launchQueryFused(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& t
   const int nw = envNW == 8 ? 8 : kFusedWaves;
   const size_t lds = (size_t)d.LP * d.C1 * d.C1 * 4 + (size_t)nw * perWave + 16;
   if (lds > kMaxLds) return pqtFail(PQT_ERR_LIMIT, "one-launch query kernel does not fit the LDS");
+#ifdef PQT_DEV_SIFT1M_ONLY
+  (void)nw; (void)qL1virt; (void)nLocal; (void)stride; (void)k; (void)nq; (void)oI; (void)oD; (void)ev0; (void)ev1; (void)grid; (void)st; (void)targs;
+  return pqtFail(PQT_ERR_LIMIT, "development build");
+#else
   auto kern = nw == 8 ? pqt_k_query_fused<8, 4, 4, 5, 1> : pqt_k_query_fused<kFusedWaves, 4, 4, 5, 1>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
@@ -29,4 +33,5 @@ int launchQueryFused(pqt_index* idx, const PqtTravArgs& targs, const TravPlan& t
                         nullptr, nullptr, nullptr, 0u, nullptr, nullptr, nullptr, nullptr, 0u};
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(nw * 64), (uint32_t)lds, st, ev0, ev1, 0u, targs, rargs, (uint32_t)perWave);
   return PQT_OK;
+#endif
 }

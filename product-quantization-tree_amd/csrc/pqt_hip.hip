@@ -170,6 +170,7 @@ int reorderLines(pqt_index* idx) {
   if (nbad) return fail(PQT_ERR_STATE, "bin members reference vector ids outside the line store [id_base, id_base + nvec)");
   if (idx->codesOwned && idx->d_codes) { (void)hipFree(idx->d_codes); idx->d_codes = nullptr; idx->codesOwned = false; idx->linesDropped = true; }
   if (idx->d_codesGrp) { (void)hipFree(idx->d_codesGrp); idx->d_codesGrp = nullptr; idx->grpG = 0; }
+  if (idx->d_codesX) { (void)hipFree(idx->d_codesX); idx->d_codesX = nullptr; idx->xcodeShift = 0; }
   idx->biasReady = false;
   idx->binOrdered = true;
   return PQT_OK;
@@ -187,6 +188,18 @@ int ensureGroupMajor(pqt_index* idx, int G) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(idx->stream));
   idx->grpG = G;
+  return PQT_OK;
+}
+int ensureXCode(pqt_index* idx, int c1Shift) {
+  if (idx->d_codesX && idx->xcodeShift == c1Shift) return PQT_OK;
+  if (idx->isView) return fail(PQT_ERR_STATE, "view handle asked to rebuild shared data (X-code store)");
+  int rc;
+  const size_t words = (size_t)idx->nIds * idx->dp.LP;
+  if ((rc = devAlloc(&idx->d_codesX, words))) return rc;
+  if (words) hipLaunchKernelGGL(pqt_k_xcode, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, idx->stream, idx->d_codesBin, (uint64_t)words, (uint32_t)c1Shift, idx->d_codesX);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(idx->stream));
+  idx->xcodeShift = c1Shift;
   return PQT_OK;
 }
 namespace {
@@ -337,6 +350,15 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     idx->runsCap = (uint64_t)qChunk * PQT_RUNCAP;
   }
   idx->curRuns = emitRuns;
+  // X-code rows for the exact rerank with the LDS table at C1 = 32 (SIFT1M shape): a second copy of the line store with cheaper
+  // address arithmetic (pqt_rs_query XC); not for stores beyond 16 GiB (the copy doubles their footprint) and not with bin runs
+  bool xcode = idx->useXCode != 0 && fused && !useBias && !wgG && coarseLds && d.C1 == 32 && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !emitRuns &&
+                     (size_t)idx->nIds * d.LP * 4 <= ((size_t)16 << 30);
+  const size_t lFusedX = coarseBytes + (size_t)kXcWaves * ((size_t)kXcSlots * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
+  const bool xcodeFits = lFusedX <= kMaxLds;
+  if (xcode && xcodeFits && (rc = ensureXCode(idx, 5))) return rc;
+  xcode = xcode && xcodeFits;
+  idx->curXCode = xcode;
   // 128 < k <= 4096 (queryKNN(.., 4096) of the reference front-end): workgroup-per-query fused rerank+select, distances on chip
   const uint32_t kcap = std::max<uint32_t>(2 * kP2, 1024);
   const size_t lBigBase = (size_t)d.LP * d.C1 * 4 + (size_t)kcap * 8 + 256 * 4 + 4 * 8 + 16;
@@ -367,7 +389,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     } else PQT_REC(EV_BEGIN);
     unsigned long long* const tstamp = (nq <= (1u << 16)) ? idx->d_tstamp : nullptr;  // debug buffer holds 65536 query records
     // rerank schedule of this chunk (decided here: for schedule 2 the traversal kernels register the queries by size class)
-    const uint32_t rsNW = useBias ? (uint32_t)biasNW : (uint32_t)kFusedWaves;
+    const uint32_t rsNW = useBias ? (uint32_t)biasNW : (xcode ? (uint32_t)kXcWaves : (uint32_t)kFusedWaves);
     static const int envGrid = getenv("PQT_RS_GRID") ? atoi(getenv("PQT_RS_GRID")) : 0;  // experiment: workgroups of the persistent rerank launch
     const uint32_t rsGrid = std::min<uint32_t>((nq + rsNW - 1) / rsNW, envGrid > 0 ? (uint32_t)envGrid : (uint32_t)idx->numCUs);
     const bool severalPerWave = fused && !wgG && nq > rsGrid * rsNW;
@@ -507,7 +529,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                                      e0, idx->lev1))) return rc;
           usedOneLaunch = true;
         } else
-        if ((rc = launchRerankSelect(idx, coarseLds, grid, emitRuns ? lRuns : lFused, st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
+        if ((rc = launchRerankSelect(idx, coarseLds, grid, emitRuns ? lRuns : (xcode ? lFusedX : lFused), st, idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_nLocal + q0,
                                      stride, k, nq, oI, oD, oP))) return rc;
         idx->poolDirty = false;
       }
@@ -516,8 +538,9 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
       // short lists (n <= 1024) first: wave-per-query evaluate + sort (pqt_k_rerank_sort_small); it hands the queries with longer
       // lists to the block-wide select kernel through fbList
-      const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32);
       const bool smallCL = coarseLds && coarseBytes + (size_t)8 * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16 <= kMaxLds;
+      // (eight wavefronts around their L1virt copies and key slots must fit the LDS: not at C1 = 128 with 32 line parts, BASELINE configs[4])
+      const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32) && (smallCL ? coarseBytes : 0) + (size_t)8 * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16 <= kMaxLds;
       usedSmallFirst = smallFirst;
       const uint32_t* bigQl = nullptr; const uint32_t* bigQc = nullptr;
       hipEvent_t bigEv0 = idx->lev0;
@@ -595,8 +618,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     if (fused) {
       if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "");
       else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
-      else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "");
-    } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + ((idx->smallLists && (d.LP == 16 || d.LP == 32)) ? (usedMid ? "+small-lists+mid-lists" : "+small-lists") : "");
+      else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "") + ((xcode && !usedOneLaunch) ? "-xcode" : "");
+    } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + (usedSmallFirst ? (usedMid ? "+small-lists+mid-lists" : "+small-lists") : "");
     else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
     idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks) + (usedOneLaunch ? " one-launch" : "");
   }
@@ -678,10 +701,10 @@ void pqt_index_destroy(pqt_index* idx) {
   for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
   if (idx->isView) {  // the arrays of the index belong to the owner
     idx->d_cb1 = idx->d_cb2 = idx->d_coarse = idx->d_cb1L = idx->d_cb2T = nullptr; idx->d_heur = idx->d_heur8 = nullptr; idx->d_heur4 = nullptr;
-    idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_filter = nullptr; idx->d_bias = nullptr;
+    idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_codesX = idx->d_filter = nullptr; idx->d_bias = nullptr;
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
-                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
+                  idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
                   idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
@@ -724,6 +747,8 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // materialising the candidate list.  Measured r02 (SIFT1M shape): traversal 0.066 -> 0.057 ms, but the rerank's expansion
   // of the runs (uniform v_readlane walk or 7-step LDS search per 64 candidates) sits in front of every row request where
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
+  // 0: the exact rerank with the LDS table reads the plain bin-ordered store instead of its X-code copy (same results; A/B and tests)
+  if (strcmp(name, "xcode") == 0) { idx->useXCode = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
@@ -1097,12 +1122,12 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   memset(&v, 0, sizeof(v));
   v.dp = x->dp; v.prm = x->prm;
   const void* ps[] = {x->d_cb1, x->d_cb2, x->d_coarse, x->d_cb1L, x->d_cb2T, x->d_heur, x->d_heur8, x->d_heur4, x->d_table, x->d_lower, x->d_ids,
-                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter};
+                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter, x->d_codesX};
   for (size_t j = 0; j < sizeof(ps) / sizeof(ps[0]); ++j) v.p[j] = ps[j];
   v.u[0] = x->heurRows; v.u[1] = x->maxMultiIndex; v.u[2] = x->nIds; v.u[3] = x->nTotal; v.u[4] = x->nCodes; v.u[5] = x->idBase; v.u[6] = x->scratchBudget;
   v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg;
   v.f[0] = x->coarseMax;
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1112,12 +1137,12 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->d_cb1 = (float*)v.p[0]; t->d_cb2 = (float*)v.p[1]; t->d_coarse = (float*)v.p[2]; t->d_cb1L = (float*)v.p[3]; t->d_cb2T = (float*)v.p[4];
   t->d_heur = (uint16_t*)v.p[5]; t->d_heur8 = (uint16_t*)v.p[6]; t->d_heur4 = (uint32_t*)v.p[7];
   t->d_table = (PqtBinEntry*)v.p[8]; t->d_lower = (uint32_t*)v.p[9]; t->d_ids = (uint32_t*)v.p[10];
-  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15];
+  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15]; t->d_codesX = (uint32_t*)v.p[16];
   t->codesOwned = false;
   t->heurRows = v.u[0]; t->maxMultiIndex = v.u[1]; t->nIds = v.u[2]; t->nTotal = v.u[3]; t->nCodes = v.u[4]; t->idBase = v.u[5]; t->scratchBudget = (size_t)v.u[6];
   t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3];
   t->coarseMax = v.f[0];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3];
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5];
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
@@ -1219,12 +1244,14 @@ int queryTop(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint3
 
 int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
               float* outDist, uint32_t* outCount, void* stream, int sync) {
+  refreshUserView(idx);  // a view takes the owner's state (sharded-ness included) before anything is checked
   if (idx && idx->sharded) return fail(PQT_ERR_INVALID, "sharded index: use pqt_query_shard + pqt_merge_topk");
   return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, nullptr, outCount, (hipStream_t)stream, sync);
 }
 
 int pqt_query_shard(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* outIdx,
                     float* outDist, uint32_t* outPos, uint32_t* outCount, void* stream, int sync) {
+  refreshUserView(idx);  // a view takes the owner's state (sharded-ness included) before anything is checked
   if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard");
   return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync);
 }
@@ -1268,6 +1295,7 @@ int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t 
 int pqt_query_shard_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k,
                          const unsigned long long* bins_dev, uint32_t cap, uint32_t* outIdx, float* outDist, uint32_t* outPos,
                          uint32_t* outCount, void* stream, int sync) {
+  refreshUserView(idx);  // a view takes the owner's state (sharded-ness included) before anything is checked
   if (idx && !idx->sharded) return fail(PQT_ERR_INVALID, "index was not loaded with pqt_index_set_bins_shard / _local");
   if (!bins_dev || cap == 0 || cap > PQT_GBIN_MAX) return fail(PQT_ERR_INVALID, "bin lists missing or capacity outside 1..256");
   return queryTop(idx, q_dev, qn, Bv, Bb, k, outIdx, outDist, outPos, outCount, (hipStream_t)stream, sync, bins_dev, cap);
@@ -1475,8 +1503,10 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms) {
 }
 
 int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host) {
-  if (!out_host || mode > 5) return fail(PQT_ERR_INVALID, "mode 0..5, out_host[n + 1]");
-  const bool p2 = n >= 64 && (n & (n - 1)) == 0;
+  if (!out_host || mode > 7) return fail(PQT_ERR_INVALID, "mode 0..7, out_host[n + 1]");
+  if (mode == 6) n = 384;  // six exchanges x 64 lanes
+  if (mode == 7) n = 64;
+  const bool p2 = (n >= 64 && (n & (n - 1)) == 0) || mode == 6;
   if (!p2 || n > 8192 || (mode == 0 && n > 2048) || (mode == 2 && n != 512 && n != 1024) || (mode == 5 && n < 256))
     return fail(PQT_ERR_INVALID, "n: a power of two, 64..8192 (wave sort <= 2048, wave select 512 | 1024, block scan >= 256)");
   HIPCHK(hipSetDevice(device));

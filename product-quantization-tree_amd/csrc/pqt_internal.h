@@ -39,6 +39,10 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 #define PQT_RS_NW 12
 #endif
 constexpr int kFusedWaves = PQT_RS_NW;
+// the exact rerank over X-code rows (pqt_rs_query XC, SIFT1M shape): 16 wavefronts per workgroup = 4 per SIMD under the 128-VGPR budget,
+// 384 key slots each (64 KB coarse table + 16 x (3 KB keys + 2 KB L1virt) + ticket lists = 147 KB of the 160 KB LDS)
+constexpr int kXcWaves = 16;
+constexpr int kXcSlots = 384;
 constexpr int kCtrRing = 4;
 constexpr int kPoolRing = 4;  // blocks of 16 draw counters + 8 x 64 registration counts behind the statistics ring (rerank schedule 2)
 constexpr size_t kPoolWords = 16 + 8 * PQT_SCHED_CLASSES;
@@ -73,6 +77,7 @@ struct pqt_index {
   uint32_t* d_fbList = nullptr; uint32_t* d_fbCount = nullptr; bool lastFilter = false;  // MODE 2 fallback list
   uint32_t* d_tvList = nullptr; uint32_t* d_tvCount = nullptr;  // pqt_query_shard_bins: queries whose exchanged bin list overflowed (traversed here)
    // opt-in adc_bias mode: per-row query-independent part of the ADC sum
+  uint32_t* d_codesX = nullptr; int xcodeShift = 0; int useXCode = -1 /* -1 auto, 0 off, 1 on where supported */; bool curXCode = false;  // X-code copy (pqt_k_xcode) for the LDS-table rerank
   uint32_t* d_codesGrp = nullptr; int grpG = 0;  // optional group-major copy [LP/G][nIds][G] for the workgroup-per-query rerank kernel  // bin-ordered copy the kernels read (row pos = code of ids[pos])
   // scratch arena
   float* d_qL1virt = nullptr; float* d_segD = nullptr; uint32_t* d_segBin = nullptr; uint32_t qCap = 0;
@@ -138,6 +143,7 @@ inline uint32_t* poolBlock(pqt_index* idx, uint32_t pos) {
 
 // ---- pqt_hip.hip
 int ensureGroupMajor(pqt_index* idx, int G);
+int ensureXCode(pqt_index* idx, int c1Shift);
 
 // ---- pqt_rerank_launch.hip: fused rerank + select launchers (one entry per kernel family; the template dispatch lives there)
 int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,

@@ -822,7 +822,13 @@ struct PqtRsArgs {
 //   inside that band (coarse look-ups from L2, ~k + a few candidates per query instead of thousands), and sorts those by
 //   the exact key.  If the band reaches the end of a full list (a cluster of > 256 - k near-ties) the query is appended
 //   to fbList and redone by the plain exact kernel (pqt_k_rerank_select_list) -- never a wrong answer, rarely a slow one.
-template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false>
+// XC (MODE 0, compile-time C1, coarse table in LDS): the rows come from the X-code copy of the line store (pqt_k_xcode: the two
+//   centroid bytes replaced by the byte offset A*4*C1 + B*4 of coarse[p][A][B] inside the part's table, lambda unchanged in the upper
+//   half): the three LDS addresses of a term cost 4 VALU instructions instead of 6, lambda is scaled by one packed FMA (the product
+//   u16 * 2^-13 is exact, so the FMA rounds like the separate multiply and add), and two CANDIDATES are evaluated per packed
+//   instruction (the running sums of both in one packed add) -- every candidate's own sequence of roundings is unchanged: same bits.
+// NSLOT: 8-byte key slots of the wavefront (best list + pending buffer): 512 by default, 384 in the 16-wavefront configuration
+template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
                                              unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
@@ -942,7 +948,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   uint32_t off0 = 0;
   // best-list size: k normally; MODE 2 keeps the 256 smallest MODE 1 keys (the k-th plus a band of near-ties)
   constexpr uint32_t BESTN = MODE == 2 ? 256u : (uint32_t)PQT_RS_BEST;
-  constexpr uint32_t SLOTS = PQT_RS_BEST + PQT_RS_PEND;
+  constexpr uint32_t SLOTS = NSLOT;
   static_assert(BESTN + 64u * UREQ <= SLOTS, "a batch of appended keys must fit behind the best list");
   const uint32_t kSel = MODE == 2 ? BESTN : k;
   if constexpr (MODE == 2) {
@@ -962,7 +968,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     if (PQT_RS_FINAL_SORT8 && final && have > BESTN) {
       // last flush: at most 512 keys are held; one pass of the 512-key in-register network (no LDS atomics, no scans)
       // replaces radix select + compaction + the small network
-      constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
+      constexpr int RK = NSLOT / 64;
       uint64_t key[RK];
 #pragma unroll
       for (int r = 0; r < RK; ++r) {
@@ -982,7 +988,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       return;
     }
     if (have > BESTN) {
-      constexpr int RK = (PQT_RS_BEST + PQT_RS_PEND) / 64;
+      constexpr int RK = NSLOT / 64;
       uint64_t key[RK];
 #pragma unroll
       for (int r = 0; r < RK; ++r) {
@@ -1017,6 +1023,82 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     }
     npend = 0;
     off0 = have;
+  };
+  // MODE 0, first phase (no threshold yet): every candidate's distance key goes to the 32-bit slot of its own visiting position --
+  // the key area holds 2 * SLOTS of them, so most queries (SIFT1M shape: 90 % have <= 743 candidates) are selected ONCE, at the end,
+  // instead of once per full pending buffer; no ballot ranking and no 64-bit key per candidate.  flush32 keeps the k smallest
+  // (radix select on the distance keys, ties at the k-th value in visiting order = the order of the 64-bit keys) as 64-bit keys in
+  // sKeys[0 .. k) and hands over to the threshold-filtered second phase above if candidates remain.
+#ifdef PQT_NO_PHASE1
+  constexpr bool kPhase1 = false;
+#else
+  constexpr bool kPhase1 = MODE == 0;
+#endif
+  constexpr uint32_t CAP32 = 2u * SLOTS;
+  uint32_t* const sK32 = reinterpret_cast<uint32_t*>(sKeys);
+  bool phase1 = kPhase1;
+  auto flush32 = [&](const uint32_t have, const bool final) {
+    constexpr int R32 = (int)(CAP32 / 64);
+    uint32_t k32[R32];
+#pragma unroll
+    for (int r = 0; r < R32; ++r) k32[r] = ((uint32_t)r * 64u < have) ? sK32[(uint32_t)r * 64u + lane < have ? (uint32_t)r * 64u + lane : 0u] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t kept = have;
+    if (have > kSel) {
+      const uint32_t t32 = pqt_wave_kth_u32<R32>(k32, have, kSel, reinterpret_cast<uint32_t*>(sKeys + BESTN));
+      // keys below the k-th value all stay; of those equal to it the first (k - #below) in visiting order
+      uint32_t below = 0;
+#pragma unroll
+      for (int r = 0; r < R32; ++r)
+        if ((uint32_t)r * 64u < have) below += (uint32_t)__popcll(__ballot((uint32_t)r * 64u + lane < have && k32[r] < t32));
+      const uint32_t needEq = kSel - below;
+      uint32_t cnt = 0, eqSeen = 0, lastEq = 0;
+#pragma unroll
+      for (int r = 0; r < R32; ++r) {
+        if ((uint32_t)r * 64u < have) {
+          const uint32_t e = (uint32_t)r * 64u + lane;
+          const bool v = e < have;
+          const bool isEq = v && k32[r] == t32;
+          uint32_t eqTot;
+          const uint32_t eqRk = pqt_ballot_rank(isEq, &eqTot);
+          const bool takeEq = isEq && eqSeen + eqRk < needEq;
+          const bool take = (v && k32[r] < t32) || takeEq;
+          uint32_t tot;
+          const uint32_t rk = pqt_ballot_rank(take, &tot);
+          if (take) sKeys[cnt + rk] = ((uint64_t)k32[r] << 32) | e;
+          // position of the last tie that was taken = low word of the largest kept key (the threshold of the second phase)
+          const unsigned long long tm = __ballot(takeEq);
+          if (tm) lastEq = (uint32_t)r * 64u + (63u - (uint32_t)__builtin_clzll(tm));
+          eqSeen += eqTot;
+          cnt += tot;
+        }
+      }
+      tau = ((uint64_t)t32 << 32) | lastEq;
+      kept = kSel;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R32; ++r) {
+        const uint32_t e = (uint32_t)r * 64u + lane;
+        if ((uint32_t)r * 64u < have && e < have) sKeys[e] = ((uint64_t)k32[r] << 32) | e;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (final) {
+      constexpr int FR = (int)(BESTN / 64);
+      uint64_t key[FR];
+#pragma unroll
+      for (int r = 0; r < FR; ++r) {
+        const uint32_t e = lane * FR + r;
+        key[r] = (e < kept) ? sKeys[e] : ~0ull;
+      }
+      if (!(dbg & 1)) pqt_wave_sort_u64<FR>(key);
+#pragma unroll
+      for (int r = 0; r < FR; ++r) sKeys[lane * FR + r] = key[r];
+      __builtin_amdgcn_wave_barrier();
+    }
+    npend = 0;
+    off0 = kept;
+    phase1 = false;
   };
 
   for (uint32_t base = 0;; base += 64 * U) {
@@ -1095,11 +1177,56 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         }
       }
       if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
+      float accX[U];
+      (void)accX;
+      if constexpr (XC) {
+        static_assert(MODE == 0 && C1M >= 2 && COARSE_LDS && (UREQ % 2) == 0, "X-code rows: exact rerank with the LDS table, compile-time C1, candidates in pairs");
+        constexpr uint32_t kBmask = 4u * ((1u << C1M) - 1u);  // B*4 sits in bits 2 .. C1M+1, A in bits C1M+2 .. 2*C1M+1 of the low half
+        const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
+        // absolute LDS byte addresses (the dynamic segment's base is a link-time constant the compiler otherwise adds to every
+        // address computed from smem_raw: one v_add per look-up); the L1virt copy of a wavefront is 4*C1*LP-aligned inside the
+        // segment, so with the segment at a 4*C1-aligned base OR-ing the centroid offset in is exact (checked by the launcher: base 0)
+        typedef __attribute__((address_space(3))) const float* lds_f32p;
+        const uint32_t vAbs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)reinterpret_cast<const unsigned char*>(sVirt);
+        const uint32_t cAbs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem_raw;
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+          pqt_f2 acc2 = {0.f, 0.f};
+#pragma unroll
+          for (int v = 0; v < LPV; ++v) {
+            const uint32_t w0[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+            const uint32_t w1[4] = {rows[u + 1][v].x, rows[u + 1][v].y, rows[u + 1][v].z, rows[u + 1][v].w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const uint32_t p = v * 4 + x;
+              pqt_f2 sb2, sa2, sc2, lam2;
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const uint32_t ww = h ? w1[x] : w0[x];
+                const uint32_t aC = (ww & 0xffffu) + cAbs;                                   // v_add_sdwa: coarse[p][A][B] inside the part's table
+                const uint32_t bV = (ww & kBmask) | vAbs;                                    // v_and_or: L1virt[p][B]
+                const uint32_t aV = ((ww >> C1M) & kBmask) | vAbs;                           // v_lshrrev + v_and_or: L1virt[p][A]
+                lam2[h] = (float)(ww >> 16);
+                sb2[h] = *(lds_f32p)(uintptr_t)(aV + p * (4u << C1M));
+                sa2[h] = *(lds_f32p)(uintptr_t)(bV + p * (4u << C1M));
+                sc2[h] = *(lds_f32p)(uintptr_t)(aC + p * (4u << (2 * C1M)));
+              }
+              lam2 = __builtin_elementwise_fma(lam2, kScale, kOff);  // == pqt_lambda_decode (exact product)
+              const pqt_f2 d2 = sb2 + lam2 * lam2 * sc2 + lam2 * (sa2 - sb2 - sc2);  // pqt_extract_distance per candidate
+              acc2 = acc2 + d2;
+            }
+          }
+          accX[u] = acc2[0];
+          accX[u + 1] = acc2[1];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t j = base + u * 64 + lane;
         const bool valid = j < n;
         float acc = 0.f;
+        if constexpr (XC) acc = accX[u];
+        else
         if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
           uint32_t x = 0;
 #pragma unroll
@@ -1154,12 +1281,16 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         }
         if constexpr (MODE != 0) acc = acc + rbias[u];
         // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
+        if (kPhase1 && phase1) {
+          if (valid) sK32[j] = pqt_f2key(acc);
+        } else {
         const uint64_t key = ((uint64_t)pqt_f2key(acc) << 32) | j;
         const bool pass = valid && key < tau;
         uint32_t tot;
         const uint32_t rk = pqt_ballot_rank(pass, &tot);
         if (pass) sKeys[off0 + npend + rk] = key;
         npend += tot;
+        }
       }
       __builtin_amdgcn_wave_barrier();
       if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsAdc += t - ts0; }
@@ -1167,6 +1298,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     // single flush site: when the pending buffer could overflow on the next batch, and once at the end
     const bool last = base + 64 * U >= n;
     if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
+    if (kPhase1 && phase1) {
+      const uint32_t seen = base + 64 * U < n ? base + 64 * U : n;  // candidates evaluated so far = keys in the 32-bit slots
+      if (last || seen + 64 * U > CAP32) {
+        if (tstamp) ts0 = __builtin_readcyclecounter();
+        flush32(seen, last);
+        if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
+      }
+    } else
     if (last || off0 + npend + 64 * U > SLOTS) {
       if (tstamp) ts0 = __builtin_readcyclecounter();
       flush(last);
@@ -1330,7 +1469,8 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 }
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
-          int MODE = 0, bool RUNS = false>
+          int MODE = 0, bool RUNS = false, bool XC = false /* A.codes = the X-code copy of the store, see pqt_rs_query */,
+          int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A) {
   const float* __restrict__ coarse = A.coarse; const uint32_t* __restrict__ nLocal = A.nLocal; const uint32_t qn = A.qn;
   const PqtDevParams& prm = A.prm; const uint32_t dbg = A.dbg; const uint32_t dynamic = A.dynamic; unsigned long long* __restrict__ zero8 = A.zero8;
@@ -1340,9 +1480,9 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * (PQT_RS_BEST + PQT_RS_PEND);
-  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * (PQT_RS_BEST + PQT_RS_PEND) * 8) + (size_t)wave * LP * C1;
-  const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)LP * C1 * 4);
+  uint64_t* sKeys = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * NSLOT;
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * NSLOT * 8) + (size_t)wave * LP * C1;
+  const size_t ticketOff = (size_t)nCoarse * 4 + (size_t)NW * ((size_t)NSLOT * 8 + (size_t)LP * C1 * 4);
   // Schedule.  Candidate counts differ several-fold between queries and wavefronts do not run equally fast (the
   // younger of two wavefronts on a SIMD loses the issue arbitration): with a static round-robin over the wavefronts the
   // launch lasted as long as its unluckiest wavefront, 50-60 % above the mean (debug timestamps).  So a workgroup owns
@@ -1549,7 +1689,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A
   while (q != 0xffffffffu) {
     uint32_t nN = 0, qN = 0xffffffffu;
     if (dynamic != 2) qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS, XC, NSLOT>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
     if (dynamic == 2) { qN = nextQuery(nN); if (dbg & 2) nN = 0; }
     q = qN;
     n = nN;
@@ -3471,6 +3611,19 @@ __global__ __launch_bounds__(256) void pqt_k_adc_bias(const uint32_t* __restrict
 }
 #endif  // PQT_MAIN_TU
 
+// X-code copy of the bin-ordered line store for the exact rerank with the coarse table in LDS (pqt_rs_query XC): every 4-byte code
+// {u8 A; u8 B; u16 lambda} (cpu_version/helper.hpp:39-90) becomes {u16 A*4*C1 + B*4; u16 lambda} -- the byte offset of
+// coarse[p][A][B] inside the part's [C1][C1] table, from which the two L1virt offsets A*4 and B*4 are one bit-field operation each.
+#ifdef PQT_MAIN_TU
+__global__ __launch_bounds__(256) void pqt_k_xcode(const uint32_t* __restrict__ in, uint64_t nWords, uint32_t c1Shift, uint32_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= nWords) return;
+  const uint32_t w = in[t];
+  const uint32_t A = w & 0xffu, B = (w >> 8) & 0xffu;
+  out[t] = (w & 0xffff0000u) | (A << (2 + c1Shift)) | (B << 2);
+}
+#endif  // PQT_MAIN_TU
+
 // group-major copy of the bin-ordered line store for pqt_k_rerank_select_wg: out[g][pos][x] = in[pos][g*G + x]
 #ifdef PQT_MAIN_TU
 __global__ __launch_bounds__(256) void pqt_k_group_major(const uint32_t* __restrict__ in, uint64_t nIds, uint32_t LP, uint32_t G,
@@ -3546,6 +3699,16 @@ __global__ __launch_bounds__(256) void pqt_k_debug_sortscan(uint32_t mode, uint3
       const uint32_t incl = pqt_wave_incl_scan(1u);
       out[e] = (e & ~63u) + incl - 1u;
     }
+  } else if (mode == 6) {
+    // the lane exchanges of the sorting networks: out[LMi * 64 + lane] = value held by lane ^ LM, LM = 1, 2, 4, 8, 16, 32 (first wavefront)
+    if (tid >= 64) return;
+    const uint32_t v = 0x9e3779b9u * (tid + 1u);
+    out[0 * 64 + tid] = pqt_lane_xor_u32<1>(v); out[1 * 64 + tid] = pqt_lane_xor_u32<2>(v); out[2 * 64 + tid] = pqt_lane_xor_u32<4>(v);
+    out[3 * 64 + tid] = pqt_lane_xor_u32<8>(v); out[4 * 64 + tid] = pqt_lane_xor_u32<16>(v); out[5 * 64 + tid] = pqt_lane_xor_u32<32>(v);
+  } else if (mode == 7) {
+    // inclusive wave scan of irregular values (v = (lane * 2654435761) >> 24), first wavefront
+    if (tid >= 64) return;
+    out[tid] = pqt_wave_incl_scan((tid * 2654435761u) >> 24);
   } else if (mode == 5) {
     uint32_t* sPart = reinterpret_cast<uint32_t*>(smem_raw);
     const uint32_t per = n / 256;  // ones held per thread (contiguous elements tid*per ..)

@@ -3,6 +3,34 @@
 // these (the bulk of the library's compile time) build in parallel with the rest; see pqt_internal.h.
 #include "pqt_internal.h"
 
+#ifdef PQT_DEV_SIFT1M_ONLY
+// Development builds only (scripts/r04_devlib.sh -> tune/lib_*.so, never the shipped library): just the kernel the SIFT1M-shape
+// headline launches, for edit-compile-measure cycles of seconds instead of minutes.  Everything else reports PQT_ERR_LIMIT.
+#ifndef PQT_RS_U16
+#define PQT_RS_U16 4
+#endif
+int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
+                       uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  if (!(idx->dp.LP == 16 && cl && !idx->sharded && idx->dp.C1 == 32 && !idx->curRuns)) return pqtFail(PQT_ERR_LIMIT, "development build: SIFT1M shape only");
+  auto kern = idx->curXCode ? pqt_k_rerank_select<kXcWaves, 4, 2, true, false, 5, 0, false, true, kXcSlots> : pqt_k_rerank_select<kFusedWaves, 4, PQT_RS_U16, true, false, 5>;
+  const uint32_t nwv = idx->curXCode ? (uint32_t)kXcWaves : (uint32_t)kFusedWaves;
+  int rc = allowLds(kern, lds);
+  if (rc) return rc;
+  const PqtRsArgs rargs{idx->curXCode ? idx->d_codesX : idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+                        idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, idx->curDynamic, idx->curZero8,
+                        nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(nwv * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
+  return PQT_OK;
+}
+int launchRSBiasAny(pqt_index*, int, bool, uint32_t, size_t, hipStream_t, const float*, const uint32_t*, uint64_t, uint32_t, uint32_t, uint32_t*, float*, uint32_t*) { return pqtFail(PQT_ERR_LIMIT, "development build"); }
+int rswgGroup(const PqtDevParams&) { return 0; }
+int launchRSWGAny(pqt_index*, int, uint32_t, hipStream_t, const float*, const uint32_t*, uint64_t, uint32_t, uint32_t*, float*, uint32_t*) { return pqtFail(PQT_ERR_LIMIT, "development build"); }
+int launchSmallLists(pqt_index*, bool, size_t, uint32_t, hipStream_t, const PqtRsArgs&, hipEvent_t) { return pqtFail(PQT_ERR_LIMIT, "development build"); }
+int launchMidLists(pqt_index*, size_t, uint32_t, hipStream_t, const PqtRsArgs&, uint32_t*, uint32_t*) { return pqtFail(PQT_ERR_LIMIT, "development build"); }
+int launchBigK(pqt_index*, bool, size_t, uint32_t, hipStream_t, const float*, const uint32_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, float*, uint32_t*, const uint32_t*, const uint32_t*, hipEvent_t, hipEvent_t) { return pqtFail(PQT_ERR_LIMIT, "development build"); }
+#else
+
 namespace {
 #ifndef PQT_RS_U16
 #define PQT_RS_U16 4   // candidates per lane in flight when LP = 16 (scaled so that U * LP/4 stays 16 code vectors)
@@ -19,15 +47,21 @@ int launchRS(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const fl
   const bool p2 = c1 > 1 && (c1 & (c1 - 1)) == 0;
   auto kern = p2 ? pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 1> : pqt_k_rerank_select<kFusedWaves, LPV, UV, CL, SH, 0>;
   if constexpr (CL) { if (c1 == 32) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5>; }  // compile-time C1 only where the table is in LDS
+  // X-code rows: 16 wavefronts per workgroup (4 per SIMD) around 384 key slots each, two candidates per lane in flight when the rows are 64 bytes
+  constexpr int UX = LPV >= 4 ? 2 : 4;
+  static_assert(PQT_RS_BEST + 64 * UX <= kXcSlots, "a batch of appended keys must fit behind the best list");
+  uint32_t nwv = (uint32_t)kFusedWaves;
+  if constexpr (CL) { if (c1 == 32 && idx->curXCode) { kern = pqt_k_rerank_select<kXcWaves, LPV, UX, true, SH, 5, 0, false, true, kXcSlots>; nwv = (uint32_t)kXcWaves; } }
   if constexpr (CL && LPV == 4) { if (c1 == 32 && idx->curRuns) kern = pqt_k_rerank_select<kFusedWaves, LPV, UV, true, SH, 5, 0, true>; }  // experimental bin-runs variant
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   // start/stop events ride on the dispatch packet itself (no separate event packets on the stream)
-  const PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+  const bool xc = CL && c1 == 32 && idx->curXCode;
+  const PqtRsArgs rargs{xc ? idx->d_codesX : idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
                         idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr /* buffer holds 65536 query records */, idx->curDynamic, idx->curZero8,
                         nullptr, 0, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr,
                         (CL && idx->curRuns) ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
-  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kFusedWaves * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
+  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(nwv * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
   return PQT_OK;
 }
 template <int LPV>
@@ -186,3 +220,5 @@ int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st
 #undef PQT_LAUNCH_BIG
   return PQT_OK;
 }
+
+#endif  // PQT_DEV_SIFT1M_ONLY

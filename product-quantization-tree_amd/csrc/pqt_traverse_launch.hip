@@ -16,6 +16,7 @@ int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp) {
   auto isP2 = [](uint32_t x) { return x != 0 && (x & (x - 1)) == 0; };
   // all layout strides powers of two (every BASELINE shape): the traversal uses shifts and masks
   tp.p2 = isP2(d.C1) && isP2(d.C2) && isP2(d.W) && isP2(d.LP) && isP2(d.D) && isP2(d.S) && isP2(d.SS) && isP2(d.R) && d.S >= 4;
+#ifndef PQT_DEV_SIFT1M_ONLY
   if (tp.fused && lTrav > 64 * 1024) {
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, false>, lTrav))) return rc;
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 2, false, false>, lTrav))) return rc;
@@ -34,6 +35,10 @@ int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp) {
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, false, true, 2>, lTrav))) return rc;
     if ((rc = allowLds(pqt_k_traverse<kTravWaves, 1, true, true, 2>, lTrav))) return rc;
   }
+#else
+  (void)rc;
+  if (tp.fused && lTrav > 64 * 1024) return pqtFail(PQT_ERR_LIMIT, "development build: SIFT1M shape only");
+#endif
   return PQT_OK;
 }
 // compile-time-shape instantiation the traversal of this index runs (0: run-time shape): the two BASELINE shapes, two-phase
@@ -55,11 +60,18 @@ void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPl
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
                                 else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
   const int shape = travShape(idx, targs);
+#ifdef PQT_DEV_SIFT1M_ONLY
+  // development builds (scripts/r04_devlib.sh): only the SIFT1M-shape instantiation; anything else launches nothing
+  (void)d; (void)travP2;
+  if (shape == 1 && !idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
+  return;
+#else
   if (shape == 1) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
                     else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 1>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
   else if (shape == 2) { if (idx->sharded) hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, true, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave);
                          else hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, 1, false, true, 2>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, targs, travPerWave); }
   else if (d.WC <= 64) PQT_LAUNCH_TR(1); else if (d.WC <= 128) PQT_LAUNCH_TR(2); else PQT_LAUNCH_TR(4);
+#endif
 #undef PQT_LAUNCH_TR
 #undef PQT_LAUNCH_TR1
 }

@@ -6,9 +6,22 @@
 #include <stdint.h>
 
 // value of lane (lane ^ LM).  LM = 1, 2, 8 are single DPP moves (VALU latency), LM = 4 two DPP moves and a select;
-// LM = 16, 32 go through ds_bpermute (LDS crossbar).
+// LM = 16, 32 use the gfx950 row / half swaps (v_permlane16_swap_b32: rows 1 and 3 of the first operand change places with rows 0
+// and 2 of the second; v_permlane32_swap_b32: the upper half of the first with the lower half of the second -- with both operands =
+// v, one of the two results holds the partner's value in every lane).  Measured issue cost (scripts/micro/valu_rate.hip): a
+// ds_bpermute_b32 occupies a wavefront for ~24 cycles plus the LDS round trip, a VALU op for ~5.
 template <int LM>
 __device__ __forceinline__ uint32_t pqt_lane_xor_u32(uint32_t v) {
+#ifndef PQT_NO_PERMLANE_SWAP
+  if (LM == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (threadIdx.x & 16) ? r[0] : r[1];
+  }
+  if (LM == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (threadIdx.x & 32) ? r[0] : r[1];
+  }
+#endif
   if (LM == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
   if (LM == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
   if (LM == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
@@ -148,4 +161,66 @@ __device__ __forceinline__ uint64_t pqt_wave_kth_u64(const uint64_t (&key)[R], u
   }
   __builtin_amdgcn_wave_barrier();
   return tau;
+}
+
+// ---- wave-wide min / max of u32 (row-local DPP steps + the two row broadcasts; lanes without a source keep their own value) ----------
+template <bool MAXV>
+__device__ __forceinline__ uint32_t pqt_wave_minmax_u32(uint32_t v) {
+#define PQT_MM_STEP(CTRL, RM) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, RM, 0xf, false); v = MAXV ? (o > v ? o : v) : (o < v ? o : v); }
+  PQT_MM_STEP(0x111, 0xf) PQT_MM_STEP(0x112, 0xf) PQT_MM_STEP(0x114, 0xf) PQT_MM_STEP(0x118, 0xf) PQT_MM_STEP(0x142, 0xa) PQT_MM_STEP(0x143, 0xc)
+#undef PQT_MM_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- k-th smallest (1-based, WITH multiplicity) of the u32 keys of one wavefront: element e = r * 64 + lane is valid iff e < have ------
+// Same most-significant-digit radix select as pqt_wave_kth_u64 on half-width keys: the in-range test is one subtraction and one
+// unsigned compare, the digit one shift; equal keys are allowed (the loop ends when the range is a single value).  hist: 256 u32 of LDS
+// owned by the wavefront.  Returns the k-th smallest VALUE; the caller resolves ties at that value.
+template <int R>
+__device__ __forceinline__ uint32_t pqt_wave_kth_u32(const uint32_t (&key)[R], const uint32_t have, uint32_t kth, uint32_t* hist) {
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if ((uint32_t)r * 64u < have) {  // uniform
+      const bool v = (uint32_t)r * 64u + lane < have;
+      mn = (v && key[r] < mn) ? key[r] : mn;
+      mx = (v && key[r] > mx) ? key[r] : mx;
+    }
+  }
+  uint32_t lo = pqt_wave_minmax_u32<false>(mn), hi = pqt_wave_minmax_u32<true>(mx);
+  for (int pass = 0; pass < 5; ++pass) {
+    const uint32_t range = hi - lo;
+    if (range == 0) break;
+    const int msb = 31 - __builtin_clz(range);
+    const uint32_t sh = msb > 7 ? (uint32_t)(msb - 7) : 0u;
+    reinterpret_cast<uint4*>(hist)[lane] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((uint32_t)r * 64u < have) {
+        const uint32_t d = key[r] - lo;
+        if ((uint32_t)r * 64u + lane < have && d <= range) atomicAdd(&hist[d >> sh], 1u);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint4 h = reinterpret_cast<const uint4*>(hist)[lane];
+    const uint32_t s = h.x + h.y + h.z + h.w;
+    const uint32_t incl = pqt_wave_incl_scan(s);
+    uint32_t before = incl - s;
+    const bool mine = before < kth && kth <= incl;
+    uint32_t b = lane * 4;
+    if (before + h.x < kth) { before += h.x; b += 1;
+      if (before + h.y < kth) { before += h.y; b += 1;
+        if (before + h.z < kth) { before += h.z; b += 1; } } }
+    const int owner = __builtin_ctzll(__ballot(mine));
+    b = (uint32_t)__builtin_amdgcn_readlane((int)b, owner);
+    before = (uint32_t)__builtin_amdgcn_readlane((int)before, owner);
+    kth -= before;
+    lo = lo + (b << sh);
+    const uint32_t top = lo + ((1u << sh) - 1u);
+    hi = top < hi ? top : hi;
+    __builtin_amdgcn_wave_barrier();
+  }
+  return lo;
 }

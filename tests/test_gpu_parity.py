@@ -877,7 +877,7 @@ def test_rerank_schedules_agree_on_large_batches(name, knobs, opts):
     # BASELINE configs[2]/[3] shape: 12 waves + bin runs
     ((128, 4, 64, 64, 1, 32), "rerank=mode2-nw12-runs", "rerank=mode1-nw12-runs"),
     # BASELINE configs[1] shape: the coarse table lives in LDS
-    ((128, 4, 32, 32, 2, 16), "rerank=lds-table", "rerank=mode1-nw12"),
+    ((128, 4, 32, 32, 2, 16), "rerank=lds-table-xcode", "rerank=mode1-nw12"),
 ])
 def test_kernel_path_taken_is_the_documented_one(shape, expect, expect_bias):
     from common import Fixture
@@ -1445,4 +1445,51 @@ def test_config5_shape_throughput_mode_matches_the_checker_with_the_same_prefix(
         _, _, cnt0 = idx.query(queries, 200, 600, 8)
         assert np.all(cnt0 == 0)
     finally:
+        idx.close()
+
+
+def test_cross_lane_primitives_exchange_and_scan():
+    """pqt_lane_xor_u32<LM> (the compare-exchange partner of every sorting network: DPP moves for LM <= 8, the gfx950 row / half swaps
+    v_permlane16_swap / v_permlane32_swap for LM = 16, 32) and the DPP wave scan, against their definitions."""
+    pkg = pqt_pkg()
+    got = pkg.debug_sort_scan(6, 64)
+    lane = np.arange(64, dtype=np.uint64)
+    for i in range(6):
+        want = ((np.uint64(0x9e3779b9) * ((lane ^ np.uint64(1 << i)) + np.uint64(1))) & np.uint64(0xffffffff)).astype(np.uint32)
+        assert np.array_equal(got[i * 64:(i + 1) * 64], want), "lane ^ %d" % (1 << i)
+    v = ((lane * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(24)
+    assert np.array_equal(pkg.debug_sort_scan(7, 64)[:64], np.cumsum(v).astype(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg2_dense", "ties", "wrap"])
+def test_xcode_rows_and_the_one_pass_selection_change_no_bit(name):
+    """The exact rerank with the LDS coarse table at C1 = 32 reads the X-code copy of the line store (coarse offset precomputed in the
+    code word, two candidates per packed instruction, 16 wavefronts per workgroup) and selects once over 32-bit distance keys held by
+    visiting position; option xcode = 0 runs the plain store with the 12-wavefront kernel.  Both must return the checker's lists bit for
+    bit -- including exact distance ties (fixture "ties": duplicated vectors), lists longer than the 32-bit key area (a second,
+    threshold-filtered phase), and k at both ends."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        Bv0, Bb = BV_BB[name]
+        f.oracle.set_sort_mode(1)
+        for Bv, k in ((Bv0, 100), (10 ** 6, 128), (10 ** 6, 1), (Bv0, 7)):
+            got = {}
+            for xc in (1, 0):
+                idx.set_option("xcode", xc)
+                got[xc] = idx.query(f.queries, Bv, Bb, k)
+                path = idx.last_path()
+                want_x = xc == 1 and CONFIGS[name]["C1"] == 32 and CONFIGS[name]["LP"] * 32 * 32 * 4 <= 65536
+                assert ("-xcode" in path) == want_x, (name, xc, path)
+            assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got[0], got[1])), (name, Bv, k)
+            ids, dist, cnt = got[1]
+            for qi, q in enumerate(f.queries):
+                s_ids, s_d = f.oracle.query(q, Bv, Bb)
+                kk = min(k, len(s_ids))
+                assert int(cnt[qi]) == len(s_ids)
+                assert np.array_equal(ids[qi, :kk], s_ids[:kk]) and np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), (name, Bv, k, qi)
+        if name == "cfg2_dense":
+            assert int(cnt.max()) > 768  # the second phase (lists beyond the 768 32-bit slots of a 16-wavefront workgroup) is exercised
+    finally:
+        f.oracle.set_sort_mode(0)
         idx.close()
