@@ -453,12 +453,17 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
     if mode == "shard_db":
         timer = ctx.sharding.ExchangeTimer(cuda=True)
         engine = ctx.sharding.PqtShardEngine(idx)
+        inflight = None
         if pipeline >= 2:
             if "view" not in W:
                 W["view"] = idx.view()
             view = W["view"]
-            sbuf = ctx.sharding.PipelineBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
             engines = (engine, ctx.sharding.PqtShardEngine(view))
+            if pipeline == 2:
+                inflight = ctx.sharding.BatchesInFlight(engines, ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
+                sbuf = inflight.bufs[0]
+            else:
+                sbuf = ctx.sharding.PipelineBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
         else:
             sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
     calls = [0]
@@ -469,7 +474,9 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
             return
         timer.on = calls[0] % period == 0  # the calls that carry the library's per-kernel events also carry the exchange events
         calls[0] += 1
-        if pipeline >= 2:
+        if pipeline == 2:
+            inflight.step(ctx.dist, ctx.world, queries, bv, bb, k, exchange=args.exchange, force_collectives=ctx.force_shard, traversal=args.traversal, timer=timer)
+        elif pipeline >= 3:
             ctx.sharding.sharded_query_pipelined(engines, ctx.dist, ctx.world, queries, bv, bb, k, sbuf, exchange=args.exchange, force_collectives=ctx.force_shard,
                                                  traversal=args.traversal, timer=timer)
         else:
@@ -491,6 +498,9 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
                 v_.clear()
     elapsed = time_steps(step, lambda: barrier(ctx), warmup, steps, drop_warmup_spans)
     idx.set_option("stage_timing", 1)  # later legs time every call
+    if mode == "shard_db" and pipeline == 2:
+        inflight.wait()
+        sbuf = inflight.bufs[inflight.last]
     if mode == "shard_db":
         out_idx.copy_(sbuf.out_idx)
         out_dist.copy_(sbuf.out_dist)
@@ -502,16 +512,19 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
     stage = dict(zip(STAGES, hist.mean(0).tolist())) if hist.shape[0] else dict.fromkeys(STAGES, 0.0)
     path = idx.last_path()
     if view is not None:
-        # two half batches: a kernel's time per step is the sum over the halves (they overlap in time); statistics likewise
-        h2 = view.stage_ms_history(min(len(timed_in_region), 32))
-        if h2.shape[0]:
-            for n_, v_ in zip(STAGES, h2.mean(0).tolist()):
-                stage[n_] += v_
-        st2 = view.stats()
-        for n_ in ("queries", "candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_bins", "ties_final", "filter_fallbacks"):
-            st[n_] = st[n_] + st2[n_]
+        if pipeline >= 3:
+            # two half batches: a kernel's time per step is the sum over the halves (they overlap in time); statistics likewise
+            h2 = view.stage_ms_history(min(len(timed_in_region), 32))
+            if h2.shape[0]:
+                for n_, v_ in zip(STAGES, h2.mean(0).tolist()):
+                    stage[n_] += v_
+            st2 = view.stats()
+            for n_ in ("queries", "candidates", "bins_visited", "bins_nonempty", "ties_l1", "ties_l2", "ties_bins", "ties_final", "filter_fallbacks"):
+                st[n_] = st[n_] + st2[n_]
+            path += " | two half batches in flight"
+        else:
+            path += " | two batches in flight"  # whole batches alternate between the index and its view: this handle's figures are one batch's
         view.set_option("stage_timing", 0)
-        path += " | two half batches in flight"
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if ctx.collectives:
         ctx.dist.all_reduce(tmax, op=ctx.dist.ReduceOp.MAX)
@@ -639,7 +652,8 @@ def make_line(ctx, args, W, R):
                    "traversal": args.traversal if mode == "shard_db" else None,
                    # range-sharded run: mean device time of each collective of a step (HIP events on the issuing stream around the call, on the
                    # steps that also carry the per-kernel events; with two half batches in flight: per half-batch call), this rank and all ranks
-                   "pipeline": ("two half batches in flight (half B's kernels run under half A's collectives)" if R["pipeline"] >= 2 else "one batch per step") if mode == "shard_db" else None,
+                   "pipeline": {1: "one batch at a time", 2: "two whole batches in flight (consecutive steps alternate between the index and a view of it on two streams: one batch's collectives pass under the other's kernels)",
+                                3: "two half batches in flight (half B's kernels run under half A's collectives)"}[R["pipeline"]] if mode == "shard_db" else None,
                    "exchange_ms": R["exchange_ms"],
                    "per_rank_stage_ms": R["per_rank"],
                    "collective_backend": ({"nccl": "rccl"}.get(ctx.backend, ctx.backend) if ctx.collectives else None), "collective_world_size": world,
@@ -757,9 +771,10 @@ def main():
                     help="range-sharded run: per-shard top-k exchanged by query slice (all-to-all, merged slices all-gathered) or by one all-gather of the whole lists")
     ap.add_argument("--traversal", default=None, choices=["sharded", "replicated"],
                     help="range-sharded run: traversal sharded by queries with one all-gather of the per-query bin lists (default) or replicated on every rank")
-    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2],
-                    help="range-sharded run: 2 = every step as two half batches in flight on two streams (the collectives of one half hide behind the kernels of "
-                         "the other), 1 = one batch per step; the line carries the other variant's step time as config.pipeline_ab")
+    ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
+                    help="range-sharded run: 2 = two whole batches in flight (consecutive steps alternate between two streams / handles: the collectives of one "
+                         "batch pass under the kernels of the other), 1 = one batch at a time, 3 = every step split into two half batches in flight; the line "
+                         "carries the one-batch-at-a-time step time as config.pipeline_ab (or the two-batches figure when run with --pipeline 1)")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
     ap.add_argument("--no-scaling-leg", action="store_true", help="--gpus 8 default (synth1b): skip the synth100m strong-scaling leg of the sweep")
     ap.add_argument("--option", action="append", default=[], help="name=value passed to pqt_index_set_option (e.g. adc_bias=1)")

@@ -1182,7 +1182,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       if constexpr (XC) {
         static_assert(MODE == 0 && C1M >= 2 && COARSE_LDS && (UREQ % 2) == 0, "X-code rows: exact rerank with the LDS table, compile-time C1, candidates in pairs");
         constexpr uint32_t kBmask = 4u * ((1u << C1M) - 1u);  // B*4 sits in bits 2 .. C1M+1, A in bits C1M+2 .. 2*C1M+1 of the low half
-        const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
+        const pqt_f2 kOff = {-1028.f, -1028.f};
         // absolute LDS byte addresses (the dynamic segment's base is a link-time constant the compiler otherwise adds to every
         // address computed from smem_raw: one v_add per look-up); the L1virt copy of a wavefront is 4*C1*LP-aligned inside the
         // segment, so with the segment at a 4*C1-aligned base OR-ing the centroid offset in is exact (checked by the launcher: base 0)
@@ -1206,12 +1206,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
                 const uint32_t aC = (ww & 0xffffu) + cAbs;                                   // v_add_sdwa: coarse[p][A][B] inside the part's table
                 const uint32_t bV = (ww & kBmask) | vAbs;                                    // v_and_or: L1virt[p][B]
                 const uint32_t aV = ((ww >> C1M) & kBmask) | vAbs;                           // v_lshrrev + v_and_or: L1virt[p][A]
-                lam2[h] = (float)(ww >> 16);
+                // 1024 + u16 * 2^-13 assembled in the mantissa (one byte permute; v_cvt_f32_u32 occupies the wavefront for 8 cycles, a
+                // plain VALU op for 5): lambda = that - 1028, exact like the reference's u16 * (8 / 65536) - 4
+                lam2[h] = __uint_as_float(__builtin_amdgcn_perm(ww, 0x44800000u, 0x03020706u));
                 sb2[h] = *(lds_f32p)(uintptr_t)(aV + p * (4u << C1M));
                 sa2[h] = *(lds_f32p)(uintptr_t)(bV + p * (4u << C1M));
                 sc2[h] = *(lds_f32p)(uintptr_t)(aC + p * (4u << (2 * C1M)));
               }
-              lam2 = __builtin_elementwise_fma(lam2, kScale, kOff);  // == pqt_lambda_decode (exact product)
+              lam2 = lam2 + kOff;  // == pqt_lambda_decode
               const pqt_f2 d2 = sb2 + lam2 * lam2 * sc2 + lam2 * (sa2 - sb2 - sc2);  // pqt_extract_distance per candidate
               acc2 = acc2 + d2;
             }

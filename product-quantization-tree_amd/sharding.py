@@ -320,6 +320,51 @@ def sharded_query_pipelined(engines, dist, world, q, bv, bb, k, pbuf, exchange="
     return pbuf.out_idx, pbuf.out_dist, pbuf.count
 
 
+class BatchesInFlight:
+    """Two WHOLE batches in flight (the collective latency "hidden by double-buffering batches"): consecutive steps
+    alternate between two slots -- each with its own ShardBuffers, engine (the index and a view of it: a handle serves one batch at
+    a time) and stream -- so the collectives of one batch pass while the other batch's kernels run, and every kernel keeps its full
+    size (splitting ONE batch into halves, sharded_query_pipelined, doubles the tails of the persistent rerank launches and was
+    measured slower on the one-device harness, profiles/r04_pipeline_one_device_*.json).  Every rank issues the collectives of all
+    steps in the same program order.  step() returns the slot's (out_idx, out_dist, count) views: valid once the slot's stream has
+    run (wait() / a device synchronisation), overwritten two steps later."""
+
+    def __init__(self, engines, world, qn, k, device, bin_cap=None, cuda=None):
+        self.engines = list(engines)
+        self.bufs = [ShardBuffers(world, qn, k, device, bin_cap), ShardBuffers(world, qn, k, device, bin_cap)]
+        self.cuda = (torch.device(device).type == "cuda") if cuda is None else cuda
+        self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if self.cuda else [None, None]
+        self.n = 0
+        self.last = None
+        if self.cuda:  # whatever the caller enqueued so far (the queries) is visible to both streams
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            for s_ in self.streams:
+                s_.wait_event(ev)
+
+    def step(self, dist, world, q, bv, bb, k, **kw):
+        slot = self.n & 1
+        self.n += 1
+        self.last = slot
+        if self.cuda:
+            with torch.cuda.stream(self.streams[slot]):
+                return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
+        return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
+
+    def wait(self):
+        """The caller's current stream waits for everything issued on both slots."""
+        if self.cuda:
+            cur = torch.cuda.current_stream()
+            for s_ in self.streams:
+                ev = torch.cuda.Event()
+                ev.record(s_)
+                cur.wait_event(ev)
+
+    def result(self):
+        b = self.bufs[self.last if self.last is not None else 0]
+        return b.out_idx, b.out_dist, b.count
+
+
 class PqtShardEngine:
     """Adapter of a sharded PqtIndex (HIP) to the engine protocol; enqueues on the current torch stream."""
 

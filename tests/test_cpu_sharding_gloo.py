@@ -129,7 +129,15 @@ def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", b
         # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
         timer = sh.ExchangeTimer(cuda=False)
         timer.on = True
-        if pipelined:
+        if pipelined == "batches":
+            # two WHOLE batches in flight: three consecutive steps alternate between two buffer sets; every step must give the full answer
+            fl = sh.BatchesInFlight((eng, eng), world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
+            for _ in range(3):
+                oi, od, cnt = fl.step(dist, world, queries, bv, bb, k, exchange=exchange, traversal=traversal, timer=timer)
+                oi, od, cnt = oi.clone(), od.clone(), cnt.clone()
+            assert fl.n == 3 and fl.last == 0 and fl.result()[0].data_ptr() == fl.bufs[0].out_idx.data_ptr()
+            buf = None
+        elif pipelined:
             # two half batches in flight (4 + 3 queries: both halves have padded slices), interleaved stage by stage
             pbuf = sh.PipelineBuffers(world, queries.shape[0], k, "cpu", bin_cap=bin_cap or None)
             oi, od, cnt = sh.sharded_query_pipelined((eng, eng), dist, world, queries, bv, bb, k, pbuf, exchange=exchange, traversal=traversal, timer=timer)
@@ -139,7 +147,7 @@ def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", b
             oi, od, cnt = sh.sharded_query(eng, dist, world, queries, bv, bb, k, buf, exchange=exchange, traversal=traversal, timer=timer)
         tm = timer.means_ms()
         want = (["bins_allgather"] if traversal == "sharded" else []) + (["topk_allgather"] if exchange == "allgather" else ["topk_alltoall", "merged_allgather"])
-        assert sorted(n_ for n_ in tm if n_ != "calls_timed") == sorted(want) and tm["calls_timed"] == (2 if pipelined else 1), tm
+        assert sorted(n_ for n_ in tm if n_ != "calls_timed") == sorted(want) and tm["calls_timed"] == (3 if pipelined == "batches" else 2 if pipelined else 1), tm
         if traversal == "sharded" and buf is not None:
             trailer = buf.bins_all[:queries.shape[0], buf.bin_cap].numpy().view(np.uint64) & np.uint64(0xffffffff)
             over = int((trailer == 0xffffffff).sum())
@@ -256,6 +264,23 @@ def test_gloo_two_half_batches_in_flight_equal_unsharded(world, exchange, traver
     q = ctx.Queue()
     port = 35500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (19 if traversal == "replicated" else 0)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, bin_cap, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,exchange,traversal", [(2, "alltoall", "sharded"), (3, "allgather", "replicated")])
+def test_gloo_two_whole_batches_in_flight(world, exchange, traversal):
+    """BatchesInFlight: consecutive steps alternate between two buffer sets / engines (on the GPU: two streams), every rank issues all
+    collectives in program order, and each step returns the unsharded engine's answer."""
+    fixture("odd")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + (os.getpid() % 2000) + 7 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, None, "batches")) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

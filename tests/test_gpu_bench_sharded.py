@@ -92,11 +92,11 @@ def test_eight_gpu_default_code_path_with_two_ranks_and_small_stand_ins():
     assert "strong_scaling_leg" in d["scaling_vs_1gpu_what"]
 
 
-@pytest.mark.parametrize("pipeline", [2, 1])
+@pytest.mark.parametrize("pipeline", [2, 1, 3])
 def test_bare_command_launches_its_own_ranks_and_reports_the_exchange(pipeline):
     """`python bench.py --gpus 2` with NO rank environment (the driver's own command form): bench.py re-executes itself under
     torch.distributed.run, rank 0 prints the one line, and the line carries the per-collective device times (exchange_ms), every
-    rank's stage times, and the step time of the other schedule (two half batches in flight vs one batch) with identical results."""
+    rank's stage times, and the step time of the other schedule (two batches in flight vs one at a time) with identical results."""
     env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1")
     for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k_, None)
@@ -110,10 +110,11 @@ def test_bare_command_launches_its_own_ranks_and_reports_the_exchange(pipeline):
     ex = c["exchange_ms"]
     assert set(ex) == {"bins_allgather", "topk_alltoall", "merged_allgather", "calls_timed"}, ex
     assert all(ex[n_] > 0 for n_ in ("bins_allgather", "topk_alltoall", "merged_allgather"))
-    assert ex["calls_timed"] == (4 if pipeline == 2 else 2)  # 2 of the 4 timed steps carry events; two half-batch calls each when pipelined
+    assert ex["calls_timed"] == (4 if pipeline == 3 else 2)  # 2 of the 4 timed steps carry events; two half-batch calls each with --pipeline 3
     pr = c["per_rank_stage_ms"]
     assert [r_["rank"] for r_ in pr] == [0, 1] and all(r_["stage_ms"]["rerank_select"] > 0 and r_["candidates"] > 0 for r_ in pr)
-    assert ("two half batches" in c["pipeline"]) == (pipeline == 2) and ("two half batches in flight" in c["kernel_path"]) == (pipeline == 2)
+    tag = {1: "one batch at a time", 2: "two whole batches in flight", 3: "two half batches in flight"}[pipeline]
+    assert tag in c["pipeline"] and (pipeline == 1 or tag.replace("whole ", "") in c["kernel_path"])
     ab = c["pipeline_ab"]
     assert "error" not in ab, ab
-    assert ab["results_identical"] is True and ab["other"] == "pipeline=%d" % (3 - pipeline) and ab["other_ms_per_step"] > 0
+    assert ab["results_identical"] is True and ab["other"] == "pipeline=%d" % (2 if pipeline == 1 else 1) and ab["other_ms_per_step"] > 0
