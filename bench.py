@@ -925,8 +925,10 @@ def main():
                                  devices=(dev.index or 0,))
             del codes_h
             leg = {"what": "wall clock of PerturbationProTree::queryKNN per call (mean of 5 after 1 warm-up), this workload's index handed over as host arrays; "
-                           "compact = only the first max(list length) columns of both arrays cross PCIe into pinned staging, padding written on the host; "
-                           "legacy_copy = the whole padded [QN][nVec] arrays copied into the caller's pageable vectors (round 3)"}
+                           "compact = the library's own choice: a large result with at least half of it padding is packed on the device (pqt_compact_results), only the "
+                           "filled prefixes cross PCIe into pinned staging while 8 host threads write the padding with streaming stores and then scatter the rows "
+                           "(packed = 1); small or dense results are copied whole (packed = 0); legacy_copy = always the whole padded [QN][nVec] arrays into the "
+                           "caller's pageable vectors (round 3)"}
             for name_, qn_, nvec_, bv_, bb_ in (("qn4096_nvec4096_knobs_4096_4096", min(4096, qn), 4096, 4096, 4096), ("qn4096_nvec100", min(4096, qn), 100, args.bv, args.bb),
                                                 ("qn%d_nvec100" % qn, qn, 100, args.bv, args.bb)):
                 e_ = {}

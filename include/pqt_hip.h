@@ -221,6 +221,12 @@ int pqt_query(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t bound_ve
 int pqt_query_host(pqt_index* idx, const float* q_host, uint32_t qn, uint32_t bound_vectors,
                    uint32_t bound_bins, uint32_t k, uint32_t* out_idx_host, float* out_dist_host,
                    uint32_t* out_count_host);
+/* Hand-over helper for padded result arrays (the front-end's queryKNN(.., 4096) fills a few hundred of the 4096 slots of a row:
+ * PerturbationProTree.cu:8278-8281 copies the padded arrays whole): offsets_dev[q] = sum_{i<q} min(count[i], k), offsets_dev[qn] = total,
+ * and the first min(count, k) entries of every row of idx_dev / dist_dev [qn][k] packed back to back in packed_*_dev (capacity
+ * qn * k).  Enqueued on hip_stream (NULL: the handle's own stream, i.e. behind a pqt_query issued with NULL).  Device pointers. */
+int pqt_compact_results(pqt_index* idx, uint32_t qn, uint32_t k, const uint32_t* idx_dev, const float* dist_dev, const uint32_t* count_dev,
+                        uint32_t* offsets_dev, uint32_t* packed_idx_dev, float* packed_dist_dev, void* hip_stream, int sync);
 /* Oracle-parity entry: the reference's WHOLE sorted candidate list, treequantizer::query(boundVectors,
  * boundBins, vec, out) (treequantizer.hpp:323-350) for a batch -- row q of out_idx_dev / out_dist_dev [QN][cap] holds the
  * list of query q, out_count_dev[QN] (required) its true length; a list longer than `cap` is cut after its first cap

@@ -1369,6 +1369,20 @@ int pqt_merge_topk(pqt_index* idx, uint32_t nsh, uint32_t qn, uint32_t k, const 
   return PQT_OK;
 }
 
+int pqt_compact_results(pqt_index* idx, uint32_t qn, uint32_t k, const uint32_t* idx_dev, const float* dist_dev, const uint32_t* count_dev,
+                        uint32_t* offsets_dev, uint32_t* packed_idx_dev, float* packed_dist_dev, void* stream, int sync) {
+  if (!idx || !idx_dev || !dist_dev || !count_dev || !offsets_dev || !packed_idx_dev || !packed_dist_dev || !k) return fail(PQT_ERR_INVALID, "null argument");
+  if ((uint64_t)qn * k > 0xffffffffull) return fail(PQT_ERR_LIMIT, "more than 2^32 result slots in one batch");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  hipStream_t st = stream ? (hipStream_t)stream : idx->stream;
+  hipLaunchKernelGGL(pqt_k_row_offsets, dim3(1), dim3(1024), 0, st, count_dev, qn, k, offsets_dev);
+  if (qn) hipLaunchKernelGGL(pqt_k_compact_rows, dim3((qn + 3) / 4), dim3(256), 0, st, idx_dev, dist_dev, offsets_dev, qn, k, packed_idx_dev, packed_dist_dev);
+  HIPCHK(hipGetLastError());
+  if (sync) HIPCHK(hipStreamSynchronize(st));
+  return PQT_OK;
+}
+
 uint64_t pqt_debug_stride(const pqt_index* idx) { return idx ? idx->stride : 0; }
 
 int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd, uint32_t* segbin, uint32_t* candIdx,

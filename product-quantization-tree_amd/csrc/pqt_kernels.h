@@ -3721,3 +3721,33 @@ __global__ __launch_bounds__(256) void pqt_k_debug_sortscan(uint32_t mode, uint3
   }
 }
 #endif  // PQT_MAIN_TU
+
+
+// ===================================================================================================
+// Compaction of padded result rows for the host hand-over (pqt_compact_results): the front-end's queryKNN(.., 4096) returns rows of
+// 4096 slots of which a few hundred are filled; only the filled prefix of every row should cross PCIe.
+//   pqt_k_row_offsets: offsets[q] = sum_{i<q} min(count[i], k), offsets[qn] = total (one workgroup, chunks of 1024 rows)
+//   pqt_k_compact_rows: one wavefront per row copies its first min(count, k) (id, distance) pairs to the packed arrays
+// ===================================================================================================
+#ifdef PQT_MAIN_TU
+__global__ __launch_bounds__(1024) void pqt_k_row_offsets(const uint32_t* __restrict__ count, uint32_t qn, uint32_t k, uint32_t* __restrict__ offsets) {
+  __shared__ uint32_t sPart[1024 / 64 + 1];
+  uint32_t run = 0;
+  for (uint32_t b = 0; b < qn; b += 1024) {
+    const uint32_t q = b + threadIdx.x;
+    const uint32_t c = q < qn ? (count[q] < k ? count[q] : k) : 0u;
+    uint32_t total = 0;
+    const uint32_t ex = pqt_block_excl_scan<1024>(c, sPart, &total);
+    if (q < qn) offsets[q] = run + ex;
+    run += total;
+  }
+  if (threadIdx.x == 0) offsets[qn] = run;
+}
+__global__ __launch_bounds__(256) void pqt_k_compact_rows(const uint32_t* __restrict__ idx, const float* __restrict__ dist, const uint32_t* __restrict__ offsets,
+                                                            uint32_t qn, uint32_t k, uint32_t* __restrict__ outIdx, float* __restrict__ outDist) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (q >= qn) return;
+  const uint32_t o = offsets[q], c = offsets[q + 1] - o;
+  for (uint32_t i = lane; i < c; i += 64) { outIdx[o + i] = idx[(size_t)q * k + i]; outDist[o + i] = dist[(size_t)q * k + i]; }
+}
+#endif  // PQT_MAIN_TU

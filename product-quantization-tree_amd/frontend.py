@@ -52,12 +52,12 @@ class FrontEnd:
 
     def queryKNN(self, q_dev_ptr, qn, nvec, bv, bb, reps=1, want_results=True):
         """reps calls of queryKNN on the same two std::vectors; returns (timing dict of per-call means, idx [qn][nvec] u32, dist f32)."""
-        t = np.zeros(6, np.float64)
+        t = np.zeros(7, np.float64)
         oi = np.empty((qn, nvec), np.uint32) if want_results else None
         od = np.empty((qn, nvec), np.float32) if want_results else None
         rc = lib().pqtfe_queryKNN(self.h, q_dev_ptr, qn, nvec, bv, bb, reps, t.ctypes.data, oi.ctypes.data if want_results else None,
                                   od.ctypes.data if want_results else None)
         if rc:
             raise RuntimeError("pqtfe_queryKNN: " + lib().pqtfe_last_error().decode())
-        tm = dict(zip(("total_ms", "kernels_ms", "d2h_ms", "host_ms", "d2h_bytes", "columns"), t.tolist()))
+        tm = dict(zip(("total_ms", "kernels_ms", "d2h_ms", "host_ms", "d2h_bytes", "columns", "packed"), t.tolist()))
         return tm, oi, od

@@ -43,7 +43,7 @@ void* pqtfe_create(uint32_t dim, uint32_t p, uint32_t c1, uint32_t c2, uint32_t 
 
 void pqtfe_destroy(void* h) { delete static_cast<Fe*>(h); }
 
-// `reps` calls of queryKNN(resIdx, resDist, q_dev, qn, nvec) on the SAME two vectors (tool_query's loop reuses them); timing[6] =
+// `reps` calls of queryKNN(resIdx, resDist, q_dev, qn, nvec) on the SAME two vectors (tool_query's loop reuses them); timing[7] =
 // means over the calls of {total, kernels, d2h, host} ms, bytes over PCIe and columns copied per row; the vectors of the last call are
 // copied to out_idx / out_dist when those are not null
 int pqtfe_queryKNN(void* h, const float* q_dev, uint32_t qn, uint32_t nvec, uint32_t bv, uint32_t bb, int reps, double* timing, uint32_t* out_idx,
@@ -51,13 +51,13 @@ int pqtfe_queryKNN(void* h, const float* q_dev, uint32_t qn, uint32_t nvec, uint
   try {
     Fe* f = static_cast<Fe*>(h);
     f->t.setBounds(bv, bb);
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
       f->t.queryKNN(f->idx, f->dist, q_dev, qn, nvec);
       const PerturbationProTree::CallTiming& c = f->t.lastCallTiming();
-      acc[0] += c.total_ms; acc[1] += c.kernels_ms; acc[2] += c.d2h_ms; acc[3] += c.host_ms; acc[4] += (double)c.d2h_bytes; acc[5] += c.columns;
+      acc[0] += c.total_ms; acc[1] += c.kernels_ms; acc[2] += c.d2h_ms; acc[3] += c.host_ms; acc[4] += (double)c.d2h_bytes; acc[5] += c.columns; acc[6] += c.packed ? 1.0 : 0.0;
     }
-    if (timing) for (int i = 0; i < 6; ++i) timing[i] = acc[i] / (reps > 0 ? reps : 1);
+    if (timing) for (int i = 0; i < 7; ++i) timing[i] = acc[i] / (reps > 0 ? reps : 1);
     if (out_idx) memcpy(out_idx, f->idx.data(), f->idx.size() * 4);
     if (out_dist) memcpy(out_dist, f->dist.data(), f->dist.size() * 4);
     return 0;

@@ -12,8 +12,50 @@
 #include <map>
 #include <stdexcept>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <emmintrin.h>
 
 namespace pqt {
+
+// ---- host side of queryKNN's hand-over ----------------------------------------------------------------------------------------------
+// A small persistent pool (the padded arrays of one 4096-query batch at _nVec = 4096 are 2 x 67 MB of host memory to write: one thread
+// does 13 GB/s with plain stores, eight do 100 GB/s with streaming stores -- profiles/r04_hostfill.txt).
+class HostPool {
+ public:
+  explicit HostPool(int n) : d_n(n), d_gen(0), d_left(0), d_stop(false) {
+    for (int t = 1; t < n; ++t) d_th.emplace_back([this, t] { run(t); });
+  }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(d_mu); d_stop = true; ++d_gen; }
+    d_cv.notify_all();
+    for (auto& t : d_th) t.join();
+  }
+  int size() const { return d_n; }
+  // job(t, n) on every thread t of n (the caller is thread 0); returns when all are done
+  void run_all(const std::function<void(int, int)>& job) {
+    { std::lock_guard<std::mutex> lk(d_mu); d_job = &job; d_left = d_n - 1; ++d_gen; }
+    d_cv.notify_all();
+    job(0, d_n);
+    std::unique_lock<std::mutex> lk(d_mu);
+    d_done.wait(lk, [this] { return d_left == 0; });
+    d_job = nullptr;
+  }
+ private:
+  void run(int t) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int, int)>* job;
+      { std::unique_lock<std::mutex> lk(d_mu); d_cv.wait(lk, [&] { return d_gen != seen; }); seen = d_gen; if (d_stop) return; job = d_job; }
+      if (job) (*job)(t, d_n);
+      { std::lock_guard<std::mutex> lk(d_mu); if (--d_left == 0) d_done.notify_one(); }
+    }
+  }
+  int d_n; std::vector<std::thread> d_th; std::mutex d_mu; std::condition_variable d_cv, d_done;
+  const std::function<void(int, int)>* d_job = nullptr; unsigned long long d_gen; int d_left; bool d_stop;
+};
+
 
 ProQuantization::ProQuantization(uint _dim, uint _p) : d_dim(_dim), d_p(_p), d_vl(_p ? _dim / _p : 0), d_nClusters(0) {}
 ProQuantization::~ProQuantization() {}
@@ -30,8 +72,8 @@ void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_resCnt(nullptr), d_resCntCap(0),
-      h_stageIdx(nullptr), h_stageDist(nullptr), h_stageCap(0), h_stageCnt(nullptr), h_stageCntCap(0), d_copyStream(nullptr), d_evIdx(nullptr), d_evDist(nullptr),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_resCnt(nullptr), d_offsets(nullptr), d_packIdx(nullptr), d_packDist(nullptr),
+      h_stageIdx(nullptr), h_stageDist(nullptr), h_stageCap(0), h_offsets(nullptr), h_stageCntCap(0), d_copyStream(nullptr), d_evIdx(nullptr), d_evDist(nullptr), d_pool(nullptr),
       d_lastTiming(), d_hashPrefix(nullptr),
       d_hashCounts(nullptr), d_hashSizeHeld(0), d_lineById(nullptr), d_lineByIdValid(false), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
@@ -42,11 +84,15 @@ void PerturbationProTree::releaseDeviceScratch() {
   if (d_resCnt) (void)hipFree(d_resCnt);
   if (h_stageIdx) (void)hipHostFree(h_stageIdx);
   if (h_stageDist) (void)hipHostFree(h_stageDist);
-  if (h_stageCnt) (void)hipHostFree(h_stageCnt);
+  if (h_offsets) (void)hipHostFree(h_offsets);
+  if (d_offsets) (void)hipFree(d_offsets);
+  if (d_packIdx) (void)hipFree(d_packIdx);
+  if (d_packDist) (void)hipFree(d_packDist);
+  h_offsets = nullptr; d_offsets = nullptr; d_packIdx = nullptr; d_packDist = nullptr;
   if (d_evIdx) (void)hipEventDestroy(d_evIdx);
   if (d_evDist) (void)hipEventDestroy(d_evDist);
   if (d_copyStream) (void)hipStreamDestroy(d_copyStream);
-  d_resCnt = nullptr; d_resCntCap = 0; h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0; h_stageCnt = nullptr; h_stageCntCap = 0;
+  d_resCnt = nullptr; h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0; h_stageCntCap = 0;
   d_copyStream = nullptr; d_evIdx = d_evDist = nullptr;
   if (d_hashPrefix) (void)hipFree(d_hashPrefix);
   if (d_hashCounts) (void)hipFree(d_hashCounts);
@@ -56,6 +102,7 @@ void PerturbationProTree::releaseDeviceScratch() {
 }
 
 PerturbationProTree::~PerturbationProTree() {
+  delete d_pool;
   (void)hipSetDevice(d_device);
   releaseDeviceScratch();
   if (d_idx) pqt_index_destroy(d_idx);
@@ -74,7 +121,8 @@ void PerturbationProTree::ensureResultBuffers(size_t _n) {
   d_resCap = _n;
 }
 
-// pinned staging of queryKNN's results (grown on demand, lives as long as the object) + the copy stream and its two events
+// queryKNN's packed hand-over: pinned host staging and device buffers for the packed rows and their offsets (grown on demand, alive as
+// long as the object), the copy stream and its two events
 void PerturbationProTree::ensureStaging(size_t _n, size_t _qn) {
   if (!d_copyStream) {
     if (hipStreamCreateWithFlags(&d_copyStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d_evIdx, hipEventDisableTiming) != hipSuccess ||
@@ -84,22 +132,24 @@ void PerturbationProTree::ensureStaging(size_t _n, size_t _qn) {
   if (_n > h_stageCap) {
     if (h_stageIdx) (void)hipHostFree(h_stageIdx);
     if (h_stageDist) (void)hipHostFree(h_stageDist);
-    h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0;
-    if (hipHostMalloc((void**)&h_stageIdx, _n * 4, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&h_stageDist, _n * 4, hipHostMallocDefault) != hipSuccess)
-      throw std::runtime_error("pinned host allocation failed");
+    if (d_packIdx) (void)hipFree(d_packIdx);
+    if (d_packDist) (void)hipFree(d_packDist);
+    h_stageIdx = nullptr; h_stageDist = nullptr; d_packIdx = nullptr; d_packDist = nullptr; h_stageCap = 0;
+    // (the packed rows of a batch that takes this path fill at most half of the padded size; the staging is sized for the worst case once)
+    if (hipHostMalloc((void**)&h_stageIdx, _n * 4, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&h_stageDist, _n * 4, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&d_packIdx, _n * 4) != hipSuccess || hipMalloc((void**)&d_packDist, _n * 4) != hipSuccess)
+      throw std::runtime_error("staging allocation failed");
     h_stageCap = _n;
   }
-  if (_qn > h_stageCntCap) {
-    if (h_stageCnt) (void)hipHostFree(h_stageCnt);
-    h_stageCnt = nullptr; h_stageCntCap = 0;
-    if (hipHostMalloc((void**)&h_stageCnt, _qn * 4, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("pinned host allocation failed");
-    h_stageCntCap = _qn;
-  }
-  if (_qn > d_resCntCap) {
+  if (_qn + 1 > h_stageCntCap) {
+    if (h_offsets) (void)hipHostFree(h_offsets);
+    if (d_offsets) (void)hipFree(d_offsets);
     if (d_resCnt) (void)hipFree(d_resCnt);
-    d_resCnt = nullptr; d_resCntCap = 0;
-    if (hipMalloc((void**)&d_resCnt, _qn * 4) != hipSuccess) throw std::runtime_error("device allocation failed");
-    d_resCntCap = _qn;
+    h_offsets = nullptr; d_offsets = nullptr; d_resCnt = nullptr; h_stageCntCap = 0;
+    if (hipHostMalloc((void**)&h_offsets, (_qn + 1) * 4, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&d_offsets, (_qn + 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&d_resCnt, (_qn + 1) * 4) != hipSuccess)
+      throw std::runtime_error("staging allocation failed");
+    h_stageCntCap = _qn + 1;
   }
 }
 
@@ -577,35 +627,24 @@ void PerturbationProTree::ensureHeuristic(uint rows) {
 }
 
 namespace {
-// rows [r0, r1) of a padded result array: the first cnt[r] entries from the compact staging rows (pitch `cols`), the reference's
-// padding behind them
-template <class T>
-void scatterRows(T* dst, const T* stage, const uint* cnt, size_t r0, size_t r1, size_t nVec, size_t cols, T pad) {
-  for (size_t r = r0; r < r1; ++r) {
-    const size_t c = std::min<size_t>(cnt[r], nVec);
-    T* d = dst + r * nVec;
-    if (c) memcpy(d, stage + r * cols, c * sizeof(T));
-    std::fill(d + c, d + nVec, pad);
-  }
-}
-template <class T>
-void scatterParallel(T* dst, const T* stage, const uint* cnt, size_t rows, size_t nVec, size_t cols, T pad) {
-  const size_t words = rows * nVec;
-  size_t nt = words < ((size_t)1 << 18) ? 1 : std::min<size_t>(std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())), rows);
-  if (nt <= 1) { scatterRows(dst, stage, cnt, 0, rows, nVec, cols, pad); return; }
-  std::vector<std::thread> th;
-  for (size_t t = 1; t < nt; ++t) th.emplace_back(scatterRows<T>, dst, stage, cnt, rows * t / nt, rows * (t + 1) / nt, nVec, cols, pad);
-  scatterRows(dst, stage, cnt, 0, rows / nt, nVec, cols, pad);
-  for (auto& x : th) x.join();
+// n 32-bit words of value v at p with streaming (non-temporal) 16-byte stores: the padding is written once and not read back here
+inline void fillStream32(void* p, size_t n, uint32_t v) {
+  uint32_t* w = static_cast<uint32_t*>(p);
+  size_t i = 0;
+  while (i < n && (reinterpret_cast<uintptr_t>(w + i) & 15)) w[i++] = v;
+  const __m128i x = _mm_set1_epi32((int)v);
+  for (; i + 4 <= n; i += 4) _mm_stream_si128(reinterpret_cast<__m128i*>(w + i), x);
+  for (; i < n; ++i) w[i] = v;
 }
 double msSince(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 }  // namespace
 
 // Same contract as the reference (PerturbationProTree.cu:8179-8183, 8278-8281): the two vectors are resized to _QN * _nVec and every
-// row is padded.  What changed against round 3 (two synchronous pageable copies of the whole padded [QN][nVec] arrays -- 134 MB per
-// 4096-query batch at _nVec = 4096, ~82 % of it padding): the engine reports each query's list length, only the first
-// max(length) columns cross PCIe (one strided copy per array into pinned staging owned by the object), and the padding is written
-// on the host by a few threads while the second array is still in flight.
+// row is padded (here: id 0xffffffff, distance +inf).  Round 3 copied the whole padded arrays with two synchronous copies -- 134 MB per
+// 4096-query batch at _nVec = 4096, ~82 % of it padding, 2.4 ms at the PCIe rate against 0.4 ms of kernels.  Now, for large sparse
+// results: the filled prefixes are packed on the device (pqt_compact_results), only they cross PCIe (into pinned staging owned by the
+// object) while a few host threads write the padding with streaming stores, and the same threads then scatter the packed rows.
+// Small or dense results (every row full, e.g. _nVec = 100) are copied straight into the caller's vectors as before.
 void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec) {
   const auto tAll = std::chrono::steady_clock::now();
   pqt_index* h = handle();
@@ -622,53 +661,76 @@ void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float
   if (!_QN || !_nVec) return;
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
   ensureResultBuffers(n);
-  ensureStaging(n, _QN);
+  const bool legacyCopy = getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr;  // measurement only (bench.py's "legacy_copy" leg): always the whole-array copy
+  // the packed hand-over pays for itself on large results only (two extra kernels, one extra round trip, thread wake-ups)
+  static const size_t packMin = getenv("PQT_FRONTEND_PACK_MIN_BYTES") ? (size_t)atoll(getenv("PQT_FRONTEND_PACK_MIN_BYTES")) : ((size_t)8 << 20);  // (tests lower it)
+  const bool tryCompact = !legacyCopy && n * 8 >= packMin && n <= 0xffffffffull;
+  if (tryCompact) ensureStaging(n, _QN);
   auto t = std::chrono::steady_clock::now();
-  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, d_resCnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
-  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, d_resCnt, nullptr, 1), "queryKNN");
-  d_lastTiming.kernels_ms = msSince(t);
-  const bool legacyCopy = getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr;  // read per call: bench.py toggles it between its two legs
-  if (legacyCopy) {
-    // measurement only (profiles/r04_frontend_queryKNN.json "before"): round 3's hand-over -- two synchronous copies of the whole
-    // padded arrays into the caller's pageable vectors
+  uint* cnt = tryCompact ? d_resCnt : nullptr;
+  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, tryCompact ? 0 : 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
+  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, tryCompact ? 0 : 1), "queryKNN");
+  size_t total = n;
+  if (tryCompact) {
+    // offsets + packed rows behind the query on the handle's stream (NULL = the same stream pqt_query used); one synchronisation
+    check(pqt_compact_results(h, _QN, _nVec, d_resIdx, d_resDist, d_resCnt, d_offsets, d_packIdx, d_packDist, nullptr, 1), "pqt_compact_results");
+    d_lastTiming.kernels_ms = msSince(t);
+    t = std::chrono::steady_clock::now();
+    if (hipMemcpyAsync(h_offsets, d_offsets, ((size_t)_QN + 1) * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipStreamSynchronize(d_copyStream) != hipSuccess)
+      throw std::runtime_error("D2H copy failed");
+    total = h_offsets[_QN];
+    d_lastTiming.d2h_ms = msSince(t);
+  } else d_lastTiming.kernels_ms = msSince(t);
+  if (!tryCompact || total * 2 > n) {
+    // dense (or small) result: the device arrays go straight into the caller's vectors
     t = std::chrono::steady_clock::now();
     d2h(_resIdx.data(), d_resIdx, n * 4);
     d2h(_resDist.data(), d_resDist, n * 4);
-    d_lastTiming.d2h_ms = msSince(t);
+    d_lastTiming.d2h_ms += msSince(t);
     d_lastTiming.host_ms = hostMs;
     d_lastTiming.total_ms = msSince(tAll);
-    d_lastTiming.d2h_bytes = 2 * n * 4;
+    d_lastTiming.d2h_bytes = 2 * n * 4 + (tryCompact ? ((size_t)_QN + 1) * 4 : 0);
     d_lastTiming.columns = _nVec;
+    d_lastTiming.packed = false;
     return;
   }
   t = std::chrono::steady_clock::now();
-  if (hipMemcpyAsync(h_stageCnt, d_resCnt, (size_t)_QN * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipStreamSynchronize(d_copyStream) != hipSuccess)
-    throw std::runtime_error("D2H copy failed");
-  uint maxc = 0;
-  for (uint q = 0; q < _QN; ++q) maxc = std::max(maxc, std::min(h_stageCnt[q], _nVec));
-  const size_t cols = maxc;
-  if (cols) {
-    if (hipMemcpy2DAsync(h_stageIdx, cols * 4, d_resIdx, (size_t)_nVec * 4, cols * 4, _QN, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess ||
-        hipEventRecord(d_evIdx, d_copyStream) != hipSuccess ||
-        hipMemcpy2DAsync(h_stageDist, cols * 4, d_resDist, (size_t)_nVec * 4, cols * 4, _QN, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess ||
-        hipEventRecord(d_evDist, d_copyStream) != hipSuccess)
+  if (total) {
+    if (hipMemcpyAsync(h_stageIdx, d_packIdx, total * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipEventRecord(d_evIdx, d_copyStream) != hipSuccess ||
+        hipMemcpyAsync(h_stageDist, d_packDist, total * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipEventRecord(d_evDist, d_copyStream) != hipSuccess)
       throw std::runtime_error("D2H copy failed");
-    if (hipEventSynchronize(d_evIdx) != hipSuccess) throw std::runtime_error("D2H copy failed");
   }
-  d_lastTiming.d2h_ms = msSince(t);
-  t = std::chrono::steady_clock::now();
-  scatterParallel<uint>(_resIdx.data(), h_stageIdx, h_stageCnt, _QN, _nVec, cols, 0xffffffffu);
+  if (!d_pool) d_pool = new HostPool((int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+  uint* const oi = _resIdx.data(); float* const od = _resDist.data();
+  const uint* const off = h_offsets; const size_t nv = _nVec, qn = _QN;
+  // phase A (while the packed rows are in flight): the padding of both arrays
+  d_pool->run_all([=](int tid, int nt) {
+    for (size_t r = qn * tid / nt; r < qn * (tid + 1) / nt; ++r) {
+      const size_t c = off[r + 1] - off[r];
+      fillStream32(oi + r * nv + c, nv - c, 0xffffffffu);
+      fillStream32(od + r * nv + c, nv - c, 0x7f800000u);
+    }
+    _mm_sfence();
+  });
   hostMs += msSince(t);
   t = std::chrono::steady_clock::now();
-  if (cols && hipEventSynchronize(d_evDist) != hipSuccess) throw std::runtime_error("D2H copy failed");
+  if (total && (hipEventSynchronize(d_evIdx) != hipSuccess || hipEventSynchronize(d_evDist) != hipSuccess)) throw std::runtime_error("D2H copy failed");
   d_lastTiming.d2h_ms += msSince(t);
   t = std::chrono::steady_clock::now();
-  scatterParallel<float>(_resDist.data(), h_stageDist, h_stageCnt, _QN, _nVec, cols, std::numeric_limits<float>::infinity());
+  const uint* const si = h_stageIdx; const float* const sd = h_stageDist;
+  // phase B: the packed rows into their places
+  d_pool->run_all([=](int tid, int nt) {
+    for (size_t r = qn * tid / nt; r < qn * (tid + 1) / nt; ++r) {
+      const size_t o = off[r], c = off[r + 1] - o;
+      if (c) { memcpy(oi + r * nv, si + o, c * 4); memcpy(od + r * nv, sd + o, c * 4); }
+    }
+  });
   hostMs += msSince(t);
   d_lastTiming.host_ms = hostMs;
   d_lastTiming.total_ms = msSince(tAll);
-  d_lastTiming.d2h_bytes = (size_t)_QN * 4 + 2 * cols * 4 * (size_t)_QN;
-  d_lastTiming.columns = maxc;
+  d_lastTiming.d2h_bytes = ((size_t)_QN + 1) * 4 + 2 * total * 4;
+  d_lastTiming.columns = (uint)(total / _QN);
+  d_lastTiming.packed = true;
 }
 
 void PerturbationProTree::queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,

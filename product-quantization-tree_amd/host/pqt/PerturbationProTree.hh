@@ -25,6 +25,8 @@ typedef struct ihipEvent_t* hipEvent_t;
 
 namespace pqt {
 
+class HostPool;  // PerturbationProTree.cpp
+
 /** where a vector array lives: the reference's createTree / buildKBestDB take DEVICE pointers (ProTree.hh:82,
  *  PerturbationProTree.hh:53); the tools of this tree read files into host memory, so both are accepted */
 enum MemSpace { HOST_PTR = 0, DEVICE_PTR = 1 };
@@ -173,7 +175,8 @@ class PerturbationProTree : public ProTree {
     double host_ms = 0;      // resizing the result vectors, scattering the staged rows into them, writing the padding
     double total_ms = 0;
     size_t d2h_bytes = 0;    // bytes that crossed PCIe
-    uint columns = 0;        // columns copied per row = the longest list of the batch (<= _nVec)
+    uint columns = 0;        // mean entries copied per row (packed hand-over) or _nVec (whole-array copy)
+    bool packed = false;     // the packed hand-over was taken (large result, at least half of it padding)
   };
   const CallTiming& lastCallTiming() const { return d_lastTiming; }
 
@@ -198,10 +201,11 @@ class PerturbationProTree : public ProTree {
   std::vector<int> d_devices;
   // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
   uint* d_resIdx; float* d_resDist; size_t d_resCap;
-  uint* d_resCnt; size_t d_resCntCap;                               // candidate-list length of every query of the last batch
-  uint* h_stageIdx; float* h_stageDist; size_t h_stageCap;          // pinned host staging of the used result columns
-  uint* h_stageCnt; size_t h_stageCntCap;
+  uint* d_resCnt; uint* d_offsets; uint* d_packIdx; float* d_packDist;  // list lengths, row offsets and packed rows of the last batch (device)
+  uint* h_stageIdx; float* h_stageDist; size_t h_stageCap;              // pinned host staging of the packed rows
+  uint* h_offsets; size_t h_stageCntCap;
   hipStream_t d_copyStream; hipEvent_t d_evIdx, d_evDist;
+  HostPool* d_pool;                                                      // host threads that write the padding and scatter the packed rows
   CallTiming d_lastTiming;
   uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;
   lineDescr* d_lineById; bool d_lineByIdValid;  // id-ordered device copy behind getLine()

@@ -316,36 +316,47 @@ def test_bench_dataset_dir_real_data_leg(tmp_path):
 
 
 @pytest.mark.parametrize("nvec", [16, 100, 4096])
-def test_frontend_queryKNN_compact_copy_equals_engine_and_legacy_copy(nvec, monkeypatch):
-    """pqt::PerturbationProTree::queryKNN (the call of tool_query.cpp:155): only the used columns cross PCIe and the padding is written on
-    the host -- the resized vectors must hold exactly what the engine's padded device arrays hold (ids, distance bits, 0xffffffff / +inf
-    padding, PerturbationProTree.cu:8278-8281 pads too), and what round 3's whole-array copy returned."""
-    import importlib
-    import torch
-    fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
-    f = fixture("cfg2_small")
-    c = f.cfg
-    fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes)
-    q = torch.from_numpy(f.queries).cuda()
-    qn, bv, bb = q.shape[0], 3000, 512
-    tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=2)
-    idx = f.hip_index()
-    idx.build_heuristic(bb)
-    gi = torch.empty((qn, nvec), dtype=torch.int32, device="cuda")
-    gd = torch.empty((qn, nvec), dtype=torch.float32, device="cuda")
-    gc = torch.empty(qn, dtype=torch.int32, device="cuda")
-    idx.query_dev(q, bv, bb, nvec, gi, gd, gc, sync=True)
-    assert np.array_equal(oi, gi.cpu().numpy().view(np.uint32))
-    assert np.array_equal(od.view(np.uint32), gd.cpu().numpy().view(np.uint32))
-    cnt = gc.cpu().numpy()
-    assert tm["columns"] == min(nvec, int(cnt.max())) and tm["d2h_bytes"] == qn * 4 + 2 * 4 * qn * tm["columns"]
-    short = cnt < nvec
+def test_frontend_queryKNN_packed_handover_equals_engine_and_whole_array_copy(nvec):
+    """pqt::PerturbationProTree::queryKNN (the call of tool_query.cpp:155): a large sparse result is packed on the device, only the filled
+    prefixes cross PCIe and host threads write the padding; small or dense results are copied whole.  Either way the resized vectors must
+    hold exactly what the engine's padded device arrays hold (ids, distance bits, 0xffffffff / +inf padding --
+    PerturbationProTree.cu:8278-8281 pads too).  Runs in a child process per variant (the pack threshold is read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import importlib, os, sys, json
+        import numpy as np, torch
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        from common import fixture
+        fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
+        nvec = %d
+        f = fixture("cfg2_small")
+        c = f.cfg
+        fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes)
+        q = torch.from_numpy(f.queries).cuda()
+        qn, bv, bb = q.shape[0], 3000, 512
+        tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=2)
+        idx = f.hip_index()
+        idx.build_heuristic(bb)
+        gi = torch.empty((qn, nvec), dtype=torch.int32, device="cuda"); gd = torch.empty((qn, nvec), dtype=torch.float32, device="cuda"); gc = torch.empty(qn, dtype=torch.int32, device="cuda")
+        idx.query_dev(q, bv, bb, nvec, gi, gd, gc, sync=True)
+        cnt = gc.cpu().numpy()
+        ok = bool(np.array_equal(oi, gi.cpu().numpy().view(np.uint32)) and np.array_equal(od.view(np.uint32), gd.cpu().numpy().view(np.uint32)))
+        filled = int(np.minimum(cnt, nvec).sum())
+        pad_ok = all((oi[r, cnt[r]:] == 0xffffffff).all() and np.isinf(od[r, cnt[r]:]).all() for r in np.nonzero(cnt < nvec)[0][:8])
+        print("RESULT " + json.dumps({"ok": ok, "pad_ok": pad_ok, "packed": tm["packed"], "bytes": tm["d2h_bytes"], "filled": filled, "qn": qn, "short": int((cnt < nvec).sum())}))
+    """ % (ROOT, nvec))
+    res = {}
+    for variant, env_extra in (("packed", {"PQT_FRONTEND_PACK_MIN_BYTES": "0"}), ("whole", {"PQT_FRONTEND_LEGACY_COPY": "1"}), ("default", {})):
+        env = dict(os.environ, **env_extra)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r = __import__("json").loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert r["ok"] and r["pad_ok"], (variant, r)
+        res[variant] = r
+    r = res["packed"]
     if nvec == 4096:
-        assert short.any() and tm["columns"] < nvec  # lists shorter than the rows: padding really was filled on the host
-    for r in np.nonzero(short)[0][:8]:
-        assert (oi[r, cnt[r]:] == 0xffffffff).all() and np.isinf(od[r, cnt[r]:]).all()
-    monkeypatch.setenv("PQT_FRONTEND_LEGACY_COPY", "1")
-    tm2, oi2, od2 = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb)
-    assert np.array_equal(oi, oi2) and np.array_equal(od.view(np.uint32), od2.view(np.uint32)) and tm2["d2h_bytes"] == 2 * 4 * qn * nvec
-    fe.close()
-    idx.close()
+        assert r["short"] > 0 and r["packed"] == 1.0 and r["bytes"] == (r["qn"] + 1) * 4 + 2 * 4 * r["filled"], r  # only the filled prefixes crossed PCIe
+    else:
+        assert r["packed"] == 0.0  # every row is full: more than half of the padded size is data -> whole-array copy
+    assert res["whole"]["packed"] == 0.0 and res["whole"]["bytes"] == 2 * 4 * res["whole"]["qn"] * nvec
+    assert res["default"]["packed"] == 0.0  # 32 queries: below the 8 MB threshold
