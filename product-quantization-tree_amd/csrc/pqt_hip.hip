@@ -538,25 +538,41 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
       // short lists (n <= 1024) first: wave-per-query evaluate + sort (pqt_k_rerank_sort_small); it hands the queries with longer
       // lists to the block-wide select kernel through fbList
-      const bool smallCL = coarseLds && coarseBytes + (size_t)8 * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16 <= kMaxLds;
-      // (eight wavefronts around their L1virt copies and key slots must fit the LDS: not at C1 = 128 with 32 line parts, BASELINE configs[4])
-      const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32) && (smallCL ? coarseBytes : 0) + (size_t)8 * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16 <= kMaxLds;
+      constexpr int SNW = kSmallWaves;
+      const bool smallCL = coarseLds && coarseBytes + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 4) + 16 <= kMaxLds;
+      // (the wavefronts' L1virt copies and key slots must fit the LDS: not at C1 = 128 with 32 line parts, BASELINE configs[4])
+      const bool smallFirst = idx->smallLists && (d.LP == 16 || d.LP == 32) && (smallCL ? coarseBytes : 0) + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 4) + 16 <= kMaxLds;
       usedSmallFirst = smallFirst;
       const uint32_t* bigQl = nullptr; const uint32_t* bigQc = nullptr;
       hipEvent_t bigEv0 = idx->lev0;
+      bool padSideUsed = false;
       if (smallFirst) {
-        constexpr int SNW = 8;
-        const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 8) + 16;
+        const size_t lSmall = (smallCL ? coarseBytes : 0) + (size_t)SNW * (d.LP * d.C1 * 4 + PQT_RSS_MAXN * 4) + 16;
         HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 8, st));
+        // the padding of the rows (k - n slots each: most of a 4096-slot row) is written on a side stream beside the sort kernels
+        const bool padSide = idx->padSide;
+        padSideUsed = padSide;
+        if (padSide) {
+          if (!idx->padStream) {
+            HIPCHK(hipStreamCreateWithFlags(&idx->padStream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&idx->evPadFork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&idx->evPadJoin, hipEventDisableTiming));
+          }
+          HIPCHK(hipEventRecord(idx->evPadFork, st));  // the traversal's candidate counts are final
+          HIPCHK(hipStreamWaitEvent(idx->padStream, idx->evPadFork, 0));
+          hipLaunchKernelGGL(pqt_k_pad_rows, dim3(nq), dim3(256), 0, idx->padStream, idx->d_nLocal + q0, nq, k, oI, oD, oP);
+          HIPCHK(hipEventRecord(idx->evPadJoin, idx->padStream));
+        }
         PqtRsArgs sa{};
+        sa.padDone = padSide ? 1u : 0u;
         sa.codes = idx->d_codesBin; sa.ids = idx->d_ids; sa.qL1virt = v; sa.coarse = idx->d_coarse; sa.cand = idx->d_cand; sa.candPos = idx->d_candPos;
         sa.nLocal = idx->d_nLocal + q0; sa.stride = stride; sa.k = k; sa.qn = nq; sa.prm = d; sa.outIdx = oI; sa.outDist = oD; sa.outPos = oP; sa.counters = idx->ctr; sa.dbg = idx->dbg & 15u; sa.nIds = idx->nIds;
         const uint32_t sgrid = std::min<uint32_t>((nq + SNW - 1) / SNW, (uint32_t)idx->numCUs);
         if (!(idx->dbg & 32768u)) { if ((rc = launchSmallLists(idx, smallCL, lSmall, sgrid, st, sa, idx->lev0))) return rc; }  // (debug bit: bisecting)
         bigQl = idx->d_fbList; bigQc = idx->d_fbCount;
         bigEv0 = nullptr;
-        // lists of 1025..2048 candidates: second wave-per-query pass (4 wavefronts around 16 KB of keys each), SIFT1M shape
-        const size_t lMid = coarseBytes + (size_t)4 * (d.LP * d.C1 * 4 + 2048 * 8) + 16;
+        // lists of 1025..2048 candidates: second wave-per-query pass (8 wavefronts around 8 KB of key slots each), SIFT1M shape
+        const size_t lMid = coarseBytes + (size_t)kMidWaves * (d.LP * d.C1 * 4 + 2048 * 4) + 16;
         if (smallCL && d.LP == 16 && lMid <= kMaxLds && idx->smallLists && !(idx->dbg & (32768u | 131072u))) {
           sa.qlist = idx->d_fbList; sa.qcount = idx->d_fbCount;
           if ((rc = launchMidLists(idx, lMid, (uint32_t)idx->numCUs, st, sa, idx->d_fbList + idx->qCap, idx->d_fbCount + 1))) return rc;
@@ -567,6 +583,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (!(smallFirst && (idx->dbg & 16384u))) {
       if ((rc = launchBigK(idx, bigCL, lBig, nq, st, v, idx->d_nLocal + q0, stride, k, kP2, kcap, oI, oD, oP, bigQl, bigQc, bigEv0, idx->lev1))) return rc;
       }
+      if (padSideUsed) HIPCHK(hipStreamWaitEvent(st, idx->evPadJoin, 0));
       if (!leanEvents) PQT_REC(EV_RERANK);
     } else {
     if (d.LP % 4 == 0)
@@ -697,6 +714,9 @@ void pqt_index_destroy(pqt_index* idx) {
       l.erase(std::remove(l.begin(), l.end(), idx), l.end());
     }
   }
+  if (idx->evPadFork) (void)hipEventDestroy(idx->evPadFork);
+  if (idx->evPadJoin) (void)hipEventDestroy(idx->evPadJoin);
+  if (idx->padStream) (void)hipStreamDestroy(idx->padStream);
   if (idx->evFork) (void)hipEventDestroy(idx->evFork);
   for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
   if (idx->isView) {  // the arrays of the index belong to the owner
@@ -752,6 +772,7 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
+  if (strcmp(name, "pad_side_stream") == 0) { idx->padSide = (value != 0); return PQT_OK; }  // 0: the k > 128 sort kernels write the padding of their rows themselves
   if (strcmp(name, "small_lists") == 0) { idx->smallLists = (value != 0); return PQT_OK; }  // 0: every query of a 128 < k <= 4096 call through the block-wide select kernel
   if (strcmp(name, "exact_filter") == 0) { idx->exactFilter = (value != 0); return PQT_OK; }  // 0: workgroup-per-query exact kernel for big coarse tables
   if (strcmp(name, "static_shapes") == 0) { idx->noShape = (value == 0); return PQT_OK; }  // 0: run-time-shape traversal even on the BASELINE shapes

@@ -41,6 +41,9 @@ constexpr int kRing = 32;        // per-stage event sets of the last kRing query
 constexpr int kFusedWaves = PQT_RS_NW;
 // the exact rerank over X-code rows (pqt_rs_query XC, SIFT1M shape): 16 wavefronts per workgroup = 4 per SIMD under the 128-VGPR budget,
 // 384 key slots each (64 KB coarse table + 16 x (3 KB keys + 2 KB L1virt) + ticket lists = 147 KB of the 160 KB LDS)
+// k > 128 short-list kernels (pqt_k_rerank_sort_small): wavefronts per workgroup of the first pass (lists <= 1024) and of the second (<= 2048)
+constexpr int kSmallWaves = 12;
+constexpr int kMidWaves = 8;
 constexpr int kXcWaves = 16;
 constexpr int kXcSlots = 384;
 constexpr int kCtrRing = 4;
@@ -107,6 +110,7 @@ struct pqt_index {
   // slots, so that one piece's (latency-bound) traversal and the tail of its rerank launch fill the gaps of the others'
   static constexpr int kMaxViews = 3;
   pqt_index* views[kMaxViews] = {nullptr, nullptr, nullptr}; pqt_index* owner = nullptr; bool isView = false; int overlap = -1 /* -1 auto, 0 off, 1 on, n >= 2: n pieces */;
+  hipStream_t padStream = nullptr; hipEvent_t evPadFork = nullptr, evPadJoin = nullptr; bool padSide = true;  // k > 128: padding of the result rows on a side stream
   bool userView = false;                 // created by pqt_index_create_view: refreshed from the owner at every call
   std::vector<pqt_index*> userViews;     // views handed to the caller (destroyed with the owner at the latest)
   hipEvent_t evFork = nullptr, evJoin[kMaxViews] = {nullptr, nullptr, nullptr};

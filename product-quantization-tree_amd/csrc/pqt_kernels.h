@@ -800,6 +800,7 @@ struct PqtRsArgs {
   uint32_t* pool; uint32_t* poolNext;
   // ... the traversal's registration lists (see PqtTravArgs): pool x is drawn class by class, largest first
   const uint32_t* schedCnt; const unsigned long long* schedList; uint32_t schedCap;
+  uint32_t padDone;  // k > 128 kernels: the padding behind the results is written elsewhere (pqt_k_pad_rows)
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -3434,25 +3435,16 @@ __global__ __launch_bounds__(PQT_RSB_NT) void pqt_k_rerank_select_big(
 // LDS: [coarse LP*C1*C1*4 when it fits] + NW * LP*C1*4 + 16 bytes.
 // ===================================================================================================
 #define PQT_RSS_MAXN 1024
-// sorts the 64*R keys at sKey (LDS, element e of the wave at sKey[e]) in place: blocked register layout for the network
-template <int R>
-__device__ __forceinline__ void pqt_wave_sort_lds(uint64_t* sKey) {
-  const uint32_t lane = threadIdx.x & 63;
-  uint64_t key[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) key[r] = sKey[lane * R + r];
-  pqt_wave_sort_u64<R>(key);
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < R; ++r) sKey[lane * R + r] = key[r];
-}
-// (few instantiations on purpose -- the four sorting networks dominate the compile time: C1 and the sharded outputs are run-time.
-// Three phases per query so that nothing big is live across the network: keys -> LDS (rows of 4 candidates per lane in flight),
-// sort (R keys per lane in registers, nothing else), results read back from LDS in coalesced order.  The first version kept
-// keys, positions and rows in registers across all phases: 256 VGPRs + 2 KB of scratch per lane.)
-// MAXN = 2048, LIST = true is the second pass: the lists of 1025..2048 candidates the first pass set aside (A.qlist / A.qcount), four
-// wavefronts per workgroup around 16 KB of keys each; each half is sorted by the 16-keys-per-lane network and the halves are joined by one
-// bitonic merge level with 32 keys per lane (the second half read back in reverse).  What is longer still goes to bigList.
+// (few instantiations on purpose -- the sorting networks dominate the compile time: C1 and the sharded outputs are run-time.)
+// Key slots are 32 bits: phase 1 stores only the distance key, in the slot of the candidate's visiting position; the network works on
+// (distance key << 32 | position) in registers; the results leave through the same slots in two rounds (positions, then distance keys),
+// read back in coalesced order.  Half the LDS per wavefront of the 64-bit slots of round 3: 12 wavefronts (3 per SIMD) instead of 8 around
+// the 64 KB coarse table for lists of <= 1024 candidates, 8 (2 per SIMD) instead of 4 for the second pass.
+// MAXN = 2048, LIST = true is the second pass: the lists of 1025..2048 candidates the first pass set aside (A.qlist / A.qcount); each half is
+// sorted by the 16-keys-per-lane network and the halves are joined by one bitonic merge level with 32 keys per lane (the second half read
+// back in reverse).  What is longer still goes to bigList.
+// A.padDone != 0: the padding behind the results is written by pqt_k_pad_rows on another stream (the rows are 4096 slots of which a few
+// hundred are filled: 27 KB of stores per query that the compute wavefronts need not issue).
 template <int NW, int LPV, bool COARSE_LDS, int MAXN = PQT_RSS_MAXN, bool LIST = false>
 __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsArgs A, uint32_t* __restrict__ bigList, uint32_t* __restrict__ bigCount) {
   static_assert(MAXN == 1024 || MAXN == 2048, "key slots per wavefront");
@@ -3465,9 +3457,9 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
   const uint32_t nCoarse = COARSE_LDS ? LP * C1 * C1 : 0;
   float* sCoarse = (float*)smem_raw;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint64_t* sKey = (uint64_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * MAXN;
-  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 8) + (size_t)wave * LP * C1;
-  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 8 + (size_t)NW * LP * C1 * 4);
+  uint32_t* sK32 = (uint32_t*)(smem_raw + (size_t)nCoarse * 4) + (size_t)wave * MAXN;
+  float* sVirt = (float*)(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 4) + (size_t)wave * LP * C1;
+  uint32_t* sTicket = reinterpret_cast<uint32_t*>(smem_raw + (size_t)nCoarse * 4 + (size_t)NW * MAXN * 4 + (size_t)NW * LP * C1 * 4);
   if (threadIdx.x == 0) sTicket[0] = 0;
   if (COARSE_LDS) for (uint32_t t = threadIdx.x; t < nCoarse; t += NW * 64) sCoarse[t] = A.coarse[t];
   __syncthreads();
@@ -3475,6 +3467,7 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
   const uint32_t G = gridDim.x, k = A.k;
   const uint32_t nWork = LIST ? *A.qcount : A.qn;
   const uint32_t L = blockIdx.x < nWork ? (nWork - blockIdx.x + G - 1) / G : 0u;  // this workgroup's queries (list entries): b, b + G, ...
+  uint32_t tiesAcc = 0;
   for (;;) {
     uint32_t t = 0;
     if (lane == 0) t = atomicAdd(sTicket, 1u);
@@ -3496,9 +3489,9 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
     }
     __builtin_amdgcn_wave_barrier();
     const uint32_t* cid = A.cand + (size_t)q * A.stride;
-    // ---- phase 1: every candidate's key (reference association, p ascending: bit-exact) -> LDS
+    // ---- phase 1: every candidate's distance key (reference association, p ascending: bit-exact) -> the slot of its visiting position
     constexpr int U = 4;  // candidates per lane whose rows are in flight together
-    if (A.dbg & 1u) { for (uint32_t j = lane; j < n; j += 64) sKey[j] = ((uint64_t)(n - j) << 32) | j; }
+    if (A.dbg & 1u) { for (uint32_t j = lane; j < n; j += 64) sK32[j] = n - j; }
     else
     for (uint32_t base = 0; base < n; base += 64 * U) {
       uint32_t pos[U];
@@ -3529,69 +3522,126 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_rerank_sort_small(const PqtRsAr
             acc = acc + pqt_extract_distance(sa, sb, sc, lam);
           }
         }
-        if (j < n) sKey[j] = ((uint64_t)pqt_f2key(acc) << 32) | j;
+        if (j < n) sK32[j] = pqt_f2key(acc);
       }
     }
-    // ---- phase 2: pad to the network size, sort
-    const uint32_t nSort = n <= 128 ? 128u : n <= 256 ? 256u : n <= 512 ? 512u : n <= 1024 ? 1024u : 2048u;
-    for (uint32_t e = n + lane; e < nSort; e += 64) sKey[e] = ~0ull;
     __builtin_amdgcn_wave_barrier();
-    if (A.dbg & 2u) {}
-    else if (nSort == 128) pqt_wave_sort_lds<2>(sKey);
-    else if (nSort == 256) pqt_wave_sort_lds<4>(sKey);
-    else if (nSort == 512) pqt_wave_sort_lds<8>(sKey);
-    else if (nSort == 1024) pqt_wave_sort_lds<16>(sKey);
-    else if constexpr (MAXN > 1024) {
-#pragma nounroll
-      for (int h = 0; h < 2; ++h) { pqt_wave_sort_lds<16>(sKey + h * 1024); __builtin_amdgcn_wave_barrier(); }
-      uint64_t key[32];
+    const uint32_t kk = n < k ? n : k;
+    // results leave in two rounds through the 32-bit slots: round 0 = visiting positions -> ids (+ global positions), round 1 = distances
+    auto emit = [&](const int round) {
+      __builtin_amdgcn_wave_barrier();
+      if (A.dbg & 4u) return;
+      if (round == 0) {
+        for (uint32_t i0 = 0; i0 < kk; i0 += 256) {
+          uint32_t sp[4], gp[4];
 #pragma unroll
-      for (int r = 0; r < 32; ++r) { const uint32_t e = lane * 32 + r; key[r] = sKey[e < 1024u ? e : 3071u - e]; }  // ascending | descending = bitonic
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * 64 + lane;
+            uint32_t jj = i < kk ? sK32[i] : 0u;
+            if ((A.dbg & 8u) && jj >= n) jj = 0;
+            sp[u] = i < kk ? cid[jj] : 0u;
+            gp[u] = (SHARDED && i < kk) ? A.candPos[(size_t)q * A.stride + jj] : 0xffffffffu;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; if ((A.dbg & 8u) && sp[u] >= A.nIds) sp[u] = 0; sp[u] = i < kk ? A.ids[sp[u]] : 0xffffffffu; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + u * 64 + lane;
+            if (i < kk) { const size_t o = (size_t)q * k + i; A.outIdx[o] = sp[u]; if (SHARDED) A.outPos[o] = gp[u]; }
+          }
+        }
+      } else {
+        for (uint32_t i = lane; i < kk; i += 64) {
+          const uint32_t dk = sK32[i];
+          if (i + 1 < kk && sK32[i + 1] == dk) ++tiesAcc;
+          A.outDist[(size_t)q * k + i] = pqt_key2f(dk);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    // sorts the first 64 * R slots (padded with +inf keys behind n) and emits them
+    auto sortEmit = [&](auto rTag) {
+      constexpr int R = decltype(rTag)::value;
+      uint64_t key[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) { const uint32_t e = lane * R + r; key[r] = e < n ? (((uint64_t)sK32[e] << 32) | e) : ~0ull; }
+      __builtin_amdgcn_wave_barrier();
+      if (!(A.dbg & 2u)) pqt_wave_sort_u64<R>(key);
+#pragma unroll
+      for (int r = 0; r < R; ++r) sK32[lane * R + r] = (uint32_t)key[r];
+      emit(0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) sK32[lane * R + r] = (uint32_t)(key[r] >> 32);
+      emit(1);
+    };
+    if (n <= 128) sortEmit(std::integral_constant<int, 2>{});
+    else if (n <= 256) sortEmit(std::integral_constant<int, 4>{});
+    else if (n <= 512) sortEmit(std::integral_constant<int, 8>{});
+    else if (n <= 1024) sortEmit(std::integral_constant<int, 16>{});
+    else if constexpr (MAXN > 1024) {
+      // two sorted halves (16 keys per lane each), then ONE merge level over [first half ascending | second half descending]
+      uint64_t ka[16], kb[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t e = lane * 16 + r;
+        ka[r] = ((uint64_t)sK32[e] << 32) | e;
+        kb[r] = 1024u + e < n ? (((uint64_t)sK32[1024u + e] << 32) | (1024u + e)) : ~0ull;
+      }
+      __builtin_amdgcn_wave_barrier();
+      pqt_wave_sort_u64<16>(ka);
+      pqt_wave_sort_u64<16>(kb);
+      uint64_t key[32];
+      auto bit = [](const uint32_t e) -> uint32_t { return e < 1024u ? e : 3071u - e; };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sK32[lane * 16 + r] = (uint32_t)(ka[r] >> 32); sK32[1024 + lane * 16 + r] = (uint32_t)(kb[r] >> 32); }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) key[r] = (uint64_t)sK32[bit(lane * 32 + r)] << 32;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sK32[lane * 16 + r] = (uint32_t)ka[r]; sK32[1024 + lane * 16 + r] = (uint32_t)kb[r]; }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) key[r] |= sK32[bit(lane * 32 + r)];
       __builtin_amdgcn_wave_barrier();
       pqt_sort_merge<32, 2048, 1024>(key, (int)lane);
 #pragma unroll
-      for (int r = 0; r < 32; ++r) sKey[lane * 32 + r] = key[r];
+      for (int r = 0; r < 32; ++r) sK32[lane * 32 + r] = (uint32_t)key[r];
+      emit(0);
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sK32[lane * 32 + r] = (uint32_t)(key[r] >> 32);
+      emit(1);
     }
-    __builtin_amdgcn_wave_barrier();
-    // ---- phase 3: results in coalesced order, 4 slots per lane in flight; padding behind them
-    const uint32_t kk = n < k ? n : k;
-    uint32_t ties = 0;
-    for (uint32_t i0 = 0; i0 < ((A.dbg & 4u) ? 0u : kk); i0 += 256) {
-      uint32_t jj[4], sp[4], gp[4], dk[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * 64 + lane;
-        const uint64_t key = i < kk ? sKey[i] : 0ull;
-        jj[u] = (uint32_t)key; dk[u] = (uint32_t)(key >> 32);
-        if ((A.dbg & 8u) && jj[u] >= n) jj[u] = 0;
-        if (i + 1 < kk && (uint32_t)(sKey[i + 1] >> 32) == dk[u]) ++ties;
-        sp[u] = i < kk ? cid[jj[u]] : 0u;
-        gp[u] = (SHARDED && i < kk) ? A.candPos[(size_t)q * A.stride + jj[u]] : 0xffffffffu;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * 64 + lane; if ((A.dbg & 8u) && sp[u] >= A.nIds) sp[u] = 0; sp[u] = i < kk ? A.ids[sp[u]] : 0xffffffffu; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * 64 + lane;
-        if (i < kk) {
-          const size_t o = (size_t)q * k + i;
-          A.outIdx[o] = sp[u];
-          A.outDist[o] = pqt_key2f(dk[u]);
-          if (SHARDED) A.outPos[o] = gp[u];
-        }
+    if (!A.padDone) {
+      for (uint32_t i = ((A.dbg & 4u) ? 0u : kk) + lane; i < k; i += 64) {
+        const size_t o = (size_t)q * k + i;
+        A.outIdx[o] = 0xffffffffu;
+        A.outDist[o] = __uint_as_float(0x7f800000u);
+        if (SHARDED) A.outPos[o] = 0xffffffffu;
       }
     }
-    for (uint32_t i = ((A.dbg & 4u) ? 0u : kk) + lane; i < k; i += 64) {
-      const size_t o = (size_t)q * k + i;
-      A.outIdx[o] = 0xffffffffu;
-      A.outDist[o] = __uint_as_float(0x7f800000u);
-      if (SHARDED) A.outPos[o] = 0xffffffffu;
-    }
-    pqt_count_ties(&A.counters[3], ties);
     }
     __builtin_amdgcn_wave_barrier();
   }
+  pqt_count_ties(&A.counters[3], tiesAcc);
 }
+
+// padding of the result rows [min(n, k), k) of every query: ids 0xffffffff, distances +inf (positions 0xffffffff); launched on a side
+// stream beside the k > 128 rerank kernels, which then write only the entries that exist
+#ifdef PQT_MAIN_TU
+__global__ __launch_bounds__(256) void pqt_k_pad_rows(const uint32_t* __restrict__ nLocal, uint32_t qn, uint32_t k, uint32_t* __restrict__ outIdx,
+                                                       float* __restrict__ outDist, uint32_t* __restrict__ outPos) {
+  const uint32_t q = blockIdx.x;
+  if (q >= qn) return;
+  const uint32_t n = nLocal[q] < k ? nLocal[q] : k;
+  for (uint32_t i = n + threadIdx.x; i < k; i += 256) {
+    const size_t o = (size_t)q * k + i;
+    outIdx[o] = 0xffffffffu;
+    outDist[o] = __uint_as_float(0x7f800000u);
+    if (outPos) outPos[o] = 0xffffffffu;
+  }
+}
+#endif  // PQT_MAIN_TU
 
 // opt-in "adc_bias" mode: bias[pos] = sum_p (l*l*c - l*c), c = coarse[p][A][B], of the row at position pos of the
 // bin-ordered store, summed in p order (f32, separate multiply and add).  lane = one row.

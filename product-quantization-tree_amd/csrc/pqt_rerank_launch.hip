@@ -178,7 +178,7 @@ int launchRSWGAny(pqt_index* idx, int G, uint32_t nq, hipStream_t st, const floa
 }
 
 int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, hipEvent_t ev0) {
-  constexpr int SNW = 8;
+  constexpr int SNW = kSmallWaves;
   int rc;
 #define PQT_LAUNCH_SMALL(LPVV, CL)                                                                                            \
   do { auto kern = pqt_k_rerank_sort_small<SNW, LPVV, CL>;                                                                     \
@@ -192,10 +192,10 @@ int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStre
 
 // second pass of the short-list path: lists of 1025..2048 candidates (SIFT1M shape with the coarse table in LDS only)
 int launchMidLists(pqt_index* idx, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, uint32_t* outList, uint32_t* outCount) {
-  auto kern = pqt_k_rerank_sort_small<4, 4, true, 2048, true>;
+  auto kern = pqt_k_rerank_sort_small<kMidWaves, 4, true, 2048, true>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(4 * 64), (uint32_t)lds, st, sa, outList, outCount);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kMidWaves * 64), (uint32_t)lds, st, sa, outList, outCount);
   return PQT_OK;
 }
 
