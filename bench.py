@@ -438,7 +438,7 @@ def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
                 chunked=w.get("chunk", n) < n, mode=mode, qn=qn)
 
 
-def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
+def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fresh=False):
     """W warm-up steps, then exactly `steps` timed steps of the hot path between barriers (+ device synchronisation); the
     per-kernel HIP events ride on every period-th call.  Returns the timing, the stage means and the outputs.
     Range-sharded mode: pipeline = 2 (default, --pipeline) runs every step as two half batches in flight (sharding.py:
@@ -467,10 +467,18 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None):
         else:
             sbuf = ctx.sharding.ShardBuffers(ctx.world, qn, k, dev, bin_cap=ctx.sharding.bin_cap_for(bb))
     calls = [0]
+    # fresh=True (single GPU): every step answers its OWN batch of queries (drawn before the timed region), so nothing a step reads --
+    # candidate rows, bin-table entries, intermediates -- was put into a cache by the step before it
+    qlist = None
+    if fresh and mode != "shard_db":
+        qlist = [sift_like(qn, W["w"]["D"], 0xF2E5A000 + 7 * i, dev) for i in range(warmup + steps)]
+        torch.cuda.synchronize(dev)
 
     def step():
         if mode != "shard_db":
-            idx.query_dev(queries, bv, bb, k, out_idx, out_dist, out_cnt, stream=ctx.stream)
+            qq = queries if qlist is None else qlist[calls[0] % len(qlist)]
+            calls[0] += 1
+            idx.query_dev(qq, bv, bb, k, out_idx, out_dist, out_cnt, stream=ctx.stream)
             return
         timer.on = calls[0] % period == 0  # the calls that carry the library's per-kernel events also carry the exchange events
         calls[0] += 1
@@ -728,6 +736,42 @@ def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
     return leg, R
 
 
+def dram_side_figures(ctx, args, W, bv, bb, k, steps, kleg):
+    """How much of the dominant launch's algorithmic rate can be DRAM traffic (FETCH_SIZE counts Infinity-Cache hits,
+    and the bench re-issues one batch).  (1) the same knob set with a FRESH batch of queries every step; (2) the distinct database rows one
+    batch touches: every candidate of every query (pqt_query_candidates: the whole lists) -> distinct vector ids -> unique_row_bytes =
+    distinct * 4 * LP, reuse_factor = candidates / distinct.  A launch must bring at least the distinct rows that no cache held before it:
+    with fresh batches and distinct rows far beyond the 256 MiB Infinity Cache that is (nearly) all of them, so
+    dram_GBps_lower_bound = unique_row_bytes / launch time; the repeated touches of a row inside a launch are what caches can serve."""
+    w, qn, dev, idx = W["w"], W["qn"], ctx.dev, W["idx"]
+    Rf = time_path(ctx, args, W, bv, bb, k, steps, 2, period=2, fresh=True)
+    # distinct rows of the standard batch
+    cap = int(min(bv + W["meta"]["max_bin"] + 64, 2 ** 31 - 1))
+    oi = torch.empty((qn, cap), dtype=torch.int32, device=dev)
+    od = torch.empty((qn, cap), dtype=torch.float32, device=dev)
+    oc = torch.empty(qn, dtype=torch.int32, device=dev)
+    idx.query_candidates_dev(W["queries"], bv, bb, cap, oi, od, oc, stream=ctx.stream, sync=True)
+    del od
+    valid = torch.arange(cap, device=dev)[None, :] < oc[:, None].clamp(max=cap)
+    ids = oi[valid]
+    total = int(ids.numel())
+    distinct = int(torch.unique(ids).numel())
+    del oi, valid, ids
+    torch.cuda.empty_cache()
+    row_bytes = 4 * w["LP"] + 4  # code row + its id
+    launch_ms_fresh = float(Rf["stage"]["rerank_select"])
+    out = {"fresh_queries_per_step": {"queries_per_sec": Rf["qps"], "ms_per_step": Rf["ms_per_step"], "stage_ms": Rf["stage"],
+                                      "vs_same_batch_every_step": Rf["qps"] / kleg["queries_per_sec"]},
+           "candidates_per_batch": total, "distinct_rows_per_batch": distinct, "reuse_factor": total / max(distinct, 1),
+           "unique_row_bytes": distinct * row_bytes, "algorithmic_row_bytes": total * row_bytes,
+           "infinity_cache_bytes": 256 << 20,
+           "dram_GBps_lower_bound": distinct * row_bytes / max(launch_ms_fresh, 1e-9) / 1e6,
+           "dram_frac_of_hbm_peak_lower_bound": distinct * row_bytes / max(launch_ms_fresh, 1e-9) / 1e6 / HBM_PEAK_GBS,
+           "what": "fresh batch per step: nothing a launch reads was cached by the launch before; distinct rows x row bytes must come from DRAM when they exceed the "
+                   "Infinity Cache many times over (lower bound of the DRAM read rate of the rerank launch); achieved / frac above price ALL touches, repeated ones included"}
+    return out
+
+
 def hbm_roofline_leg(ctx, args):
     """BASELINE configs[2] inside the default N = 1 command: 100 M vectors (12.8 GB of line codes: HBM resident), 10 k queries, the
     reference-default knobs and the CUDA library's (4096, 4096).  `value` stays the SIFT1M-shape number."""
@@ -739,6 +783,10 @@ def hbm_roofline_leg(ctx, args):
     steps = max(4, min(args.steps, 10))
     for bv, bb in ((20000, 500), (4096, 4096)):
         leg["knobs_%d_%d" % (bv, bb)], _ = knob_leg(ctx, args, W, bv, bb, args.k, steps, 2)
+        try:
+            leg["knobs_%d_%d" % (bv, bb)]["dram_side"] = dram_side_figures(ctx, args, W, bv, bb, args.k, steps, leg["knobs_%d_%d" % (bv, bb)])
+        except Exception as e:
+            leg["knobs_%d_%d" % (bv, bb)]["dram_side"] = {"error": repr(e)[:300]}
     W["idx"].close()
     del W
     torch.cuda.empty_cache()
@@ -977,6 +1025,28 @@ def main():
             torch.cuda.synchronize(dev)
         except Exception as e:
             out["config"]["no_stage_events"] = {"error": repr(e)[:200]}
+
+    # ---- the headline step with the host-to-device copy of the query batch inside the timed region (pinned host buffer,
+    # same stream); `value` above starts with the queries resident in HBM
+    if mode == "single" and not os.environ.get("PQT_BENCH_NO_PIPELINE"):
+        try:
+            qh = torch.empty(queries.shape, dtype=queries.dtype, pin_memory=True)
+            qh.copy_(queries)
+            qd = torch.empty_like(queries)
+            oi1, od1, oc1 = torch.empty_like(out_idx), torch.empty_like(out_dist), torch.empty_like(out_cnt)
+            idx.set_option("stage_timing", 0)
+
+            def step_h2d():
+                qd.copy_(qh, non_blocking=True)
+                idx.query_dev(qd, args.bv, args.bb, k, oi1, od1, oc1, stream=stream)
+            t_h = time_steps(step_h2d, lambda: torch.cuda.synchronize(dev), 3, args.steps) / args.steps
+            idx.set_option("stage_timing", 1)
+            out["config"]["h2d_included"] = {"queries_per_sec": qn / t_h, "ms_per_step": t_h * 1e3, "h2d_bytes_per_step": int(qh.numel() * 4),
+                                             "results_identical": bool(torch.equal(oi1, out_idx) and torch.equal(od1, out_dist)),
+                                             "what": "every step first copies its %d x %d f32 queries from pinned host memory on the launch stream (no stage events); results stay in HBM" % (qn, w["D"])}
+            del qh, qd, oi1, od1, oc1
+        except Exception as e:
+            out["config"]["h2d_included"] = {"error": repr(e)[:200]}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle restatement of cpu_version's query(), bounded sample ----------
     if mode == "single" and not args.no_cpu and not W["chunked"]:
