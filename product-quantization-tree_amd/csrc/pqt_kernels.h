@@ -1928,6 +1928,33 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     sL1[t] = d;
   }
   __builtin_amdgcn_wave_barrier();
+  if (C1 > 64 && C1 <= 256 && W <= 4) {
+    // many first-level cells, few of them expanded (BASELINE configs[4]: C1 = 128, W = 1): W rounds of a wave-wide arg-min per part over
+    // (distance key << 32 | cell) -- ties go to the lower cell like the stable order -- instead of every cell's rank against all others
+    // (C1 = 128: ~10 k instructions per query, 41 % of a traversal at that shape: profiles/r04_cfg5_phase_clocks.txt).  The tie
+    // statistic counts the exact ties that touch a selected cell (every tie that can influence the result is of this kind).
+    for (uint32_t p = 0; p < P; ++p) {
+      uint64_t kc[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const uint32_t c = lane + 64u * r; kc[r] = c < C1 ? (((uint64_t)pqt_f2key(sL1[PQT_MUL(p, C1, shC1) + c]) << 32) | c) : ~0ull; }
+      for (uint32_t w = 0; w < W; ++w) {
+        uint64_t m = kc[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) m = kc[r] < m ? kc[r] : m;
+        { const uint64_t o = pqt_lane_xor_u64<1>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<2>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<4>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<8>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<16>(m); m = o < m ? o : m; }
+        { const uint64_t o = pqt_lane_xor_u64<32>(m); m = o < m ? o : m; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ties += (kc[r] != m && kc[r] != ~0ull && (uint32_t)(kc[r] >> 32) == (uint32_t)(m >> 32)) ? 1u : 0u;
+          if (kc[r] == m) { sOrd[PQT_MUL(p, W, shW) + w] = (uint32_t)m; kc[r] = ~0ull; }
+        }
+      }
+    }
+  } else
   for (uint32_t t = lane; t < P * C1; t += 64) {
     const uint32_t p = PQT_DIV(t, C1, shC1), c = PQT_MOD(t, C1);
     const float my = sL1[t];
