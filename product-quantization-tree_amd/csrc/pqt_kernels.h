@@ -1186,10 +1186,11 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         const pqt_f2 kOff = {-1028.f, -1028.f};
         // absolute LDS byte addresses (the dynamic segment's base is a link-time constant the compiler otherwise adds to every
         // address computed from smem_raw: one v_add per look-up); the L1virt copy of a wavefront is 4*C1*LP-aligned inside the
-        // segment, so with the segment at a 4*C1-aligned base OR-ing the centroid offset in is exact (checked by the launcher: base 0)
+        // segment, so with the segment at a 4*C1-aligned base (0: no static LDS in these kernels) OR-ing the centroid offset in is exact
         typedef __attribute__((address_space(3))) const float* lds_f32p;
         const uint32_t vAbs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)reinterpret_cast<const unsigned char*>(sVirt);
         const uint32_t cAbs = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem_raw;
+        if (vAbs & kBmask) __builtin_trap();  // (uniform; cannot happen with the launchers' LDS layouts: the kernel has no static LDS in front of the dynamic segment)
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
           pqt_f2 acc2 = {0.f, 0.f};
