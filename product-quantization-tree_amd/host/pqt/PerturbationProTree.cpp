@@ -668,7 +668,9 @@ void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float
   if (tryCompact) ensureStaging(n, _QN);
   auto t = std::chrono::steady_clock::now();
   uint* cnt = tryCompact ? d_resCnt : nullptr;
-  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, tryCompact ? 0 : 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
+  // (several devices: pqt_multi_query runs on the multi handle's own stream, not on the stream of shard 0's handle that the compaction
+  // below is enqueued on -- it is waited for here)
+  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
   else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, tryCompact ? 0 : 1), "queryKNN");
   size_t total = n;
   if (tryCompact) {

@@ -331,7 +331,8 @@ def test_frontend_queryKNN_packed_handover_equals_engine_and_whole_array_copy(nv
         nvec = %d
         f = fixture("cfg2_small")
         c = f.cfg
-        fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes)
+        devs = tuple(int(x) for x in os.environ.get("PQT_TEST_FE_DEVICES", "0").split(","))
+        fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes, devices=devs)
         q = torch.from_numpy(f.queries).cuda()
         qn, bv, bb = q.shape[0], 3000, 512
         tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=2)
@@ -346,7 +347,10 @@ def test_frontend_queryKNN_packed_handover_equals_engine_and_whole_array_copy(nv
         print("RESULT " + json.dumps({"ok": ok, "pad_ok": pad_ok, "packed": tm["packed"], "bytes": tm["d2h_bytes"], "filled": filled, "qn": qn, "short": int((cnt < nvec).sum())}))
     """ % (ROOT, nvec))
     res = {}
-    for variant, env_extra in (("packed", {"PQT_FRONTEND_PACK_MIN_BYTES": "0"}), ("whole", {"PQT_FRONTEND_LEGACY_COPY": "1"}), ("default", {})):
+    variants = [("packed", {"PQT_FRONTEND_PACK_MIN_BYTES": "0"}), ("whole", {"PQT_FRONTEND_LEGACY_COPY": "1"}), ("default", {})]
+    if nvec == 4096:  # the same through the one-object multi-shard handle (two range shards on this device): its own stream, then the compaction
+        variants.append(("packed_two_shards", {"PQT_FRONTEND_PACK_MIN_BYTES": "0", "PQT_TEST_FE_DEVICES": "0,0"}))
+    for variant, env_extra in variants:
         env = dict(os.environ, **env_extra)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -360,3 +364,5 @@ def test_frontend_queryKNN_packed_handover_equals_engine_and_whole_array_copy(nv
         assert r["packed"] == 0.0  # every row is full: more than half of the padded size is data -> whole-array copy
     assert res["whole"]["packed"] == 0.0 and res["whole"]["bytes"] == 2 * 4 * res["whole"]["qn"] * nvec
     assert res["default"]["packed"] == 0.0  # 32 queries: below the 8 MB threshold
+    if nvec == 4096:
+        assert res["packed_two_shards"]["packed"] == 1.0
