@@ -427,7 +427,7 @@ def stream_read_GBps(nbytes=4 << 30, reps=5, device=0):
 
 def debug_sort_scan(mode, n, device=0):
     """The reference's sort / scan self-check patterns through the library's primitives (include/pqt_hip.h: pqt_debug_sort_scan)."""
-    out = np.zeros(max(n, 384) + 1, np.uint32)
+    out = np.zeros(max(n, 512) + 1, np.uint32)
     _chk(lib().pqt_debug_sort_scan(device, mode, n, _p(out, u32p)))
     return out
 

@@ -2046,6 +2046,40 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
         key[m][r] = pos < WC ? (((uint64_t)pqt_f2key(sD2[PQT_MUL(p, WC, shWC) + pos]) << 32) | pos) : ~0ull;
       }
     }
+#ifndef PQT_NO_SORT32
+    if constexpr (WCR == 1) {
+      // 64 entries per part, one per lane: the network runs on 32-bit keys -- the distance key with its low 6 bits replaced by the entry's
+      // position (unique, so min / max compare-exchanges do) -- a third of the instructions of the (distance key, position) u64 network.
+      // That order equals the exact one unless two neighbours of the result agree in the upper 26 bits of their distance keys and stand
+      // in the wrong (distance, position) order; every lane checks its successor, and a part where that happens is sorted again by the
+      // u64 network (two second-level distances within 2^-17 of each other, relatively: rare on any data, certain for exact duplicates).
+      uint32_t k32[PM];
+#pragma unroll
+      for (int m = 0; m < PM; ++m) k32[m] = ((uint32_t)(key[m][0] >> 32) & ~63u) | ((uint32_t)key[m][0] & 63u);
+#pragma unroll
+      for (int m = 0; m < PM; ++m) { uint32_t t[1] = {k32[m]}; pqt_wave_sort_u32<1>(t); k32[m] = t[0]; }
+      unsigned long long bad = 0;
+#pragma unroll
+      for (int m = 0; m < PM; ++m) {
+        const uint32_t p = p0 + m < P ? p0 + m : p0;
+        const uint32_t pos = k32[m] & 63u;
+        const uint64_t full = ((uint64_t)pqt_f2key(sD2[PQT_MUL(p, WC, shWC) + pos]) << 32) | pos;  // exact key of the entry now at rank `lane`
+        const uint64_t nxt = pqt_lane_down1_u64(full);                                               // ... of the entry at rank lane + 1
+        if (__ballot(lane < 63 && pos < WC && (uint32_t)nxt < WC && nxt < full)) bad |= 1ull << m;
+        key[m][0] = (uint32_t)full < WC ? full : ~0ull;
+      }
+      if (bad) {  // uniform, rare
+#pragma unroll
+        for (int m = 0; m < PM; ++m) {
+          if ((bad >> m) & 1ull) {
+            const uint32_t p = p0 + m < P ? p0 + m : p0;
+            key[m][0] = lane < WC ? (((uint64_t)pqt_f2key(sD2[PQT_MUL(p, WC, shWC) + lane]) << 32) | lane) : ~0ull;
+            pqt_wave_sort_u64<1>(key[m]);
+          }
+        }
+      }
+    } else
+#endif
 #pragma unroll
     for (int m = 0; m < PM; ++m) pqt_wave_sort_u64<WCR>(key[m]);
 #pragma unroll
@@ -3785,6 +3819,8 @@ __global__ __launch_bounds__(256) void pqt_k_debug_sortscan(uint32_t mode, uint3
     const uint32_t v = 0x9e3779b9u * (tid + 1u);
     out[0 * 64 + tid] = pqt_lane_xor_u32<1>(v); out[1 * 64 + tid] = pqt_lane_xor_u32<2>(v); out[2 * 64 + tid] = pqt_lane_xor_u32<4>(v);
     out[3 * 64 + tid] = pqt_lane_xor_u32<8>(v); out[4 * 64 + tid] = pqt_lane_xor_u32<16>(v); out[5 * 64 + tid] = pqt_lane_xor_u32<32>(v);
+    out[6 * 64 + tid] = pqt_lane_down1_u32(v);  // value of lane + 1 (lane 63: its own)
+    { uint32_t t[1] = {(0x9e3779b9u * (tid + 1u)) | 1u}; pqt_wave_sort_u32<1>(t); out[7 * 64 + tid] = t[0]; }  // the u32 network on 64 distinct keys
   } else if (mode == 7) {
     // inclusive wave scan of irregular values (v = (lane * 2654435761) >> 24), first wavefront
     if (tid >= 64) return;

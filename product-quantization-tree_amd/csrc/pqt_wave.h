@@ -39,6 +39,15 @@ __device__ __forceinline__ uint64_t pqt_lane_xor_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// value of lane + 1 (lane 63 gets its own): DPP row shift + the row's first lane through a row broadcast is not a single move on
+// gfx9; wave_shr-style moves are -- v_mov_b32 wave_shl:1 reads lane + 1
+__device__ __forceinline__ uint32_t pqt_lane_down1_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);  // wave_shl:1
+}
+__device__ __forceinline__ uint64_t pqt_lane_down1_u64(uint64_t v) {
+  return ((uint64_t)pqt_lane_down1_u32((uint32_t)(v >> 32)) << 32) | pqt_lane_down1_u32((uint32_t)v);
+}
+
 // one compare-exchange stage (K = bitonic block size, J = partner distance) of the network
 template <int R, int K, int J>
 __device__ __forceinline__ void pqt_sort_stage(uint64_t (&key)[R], const int lane) {
@@ -223,4 +232,51 @@ __device__ __forceinline__ uint32_t pqt_wave_kth_u32(const uint32_t (&key)[R], c
     __builtin_amdgcn_wave_barrier();
   }
   return lo;
+}
+
+// ---- the same bitonic network over UNIQUE u32 keys (R per lane, blocked layout): a compare-exchange is one lane move + min + max + select
+// instead of two moves, a 64-bit compare and two selects -- a third of the instructions of the u64 network.  Callers that need a
+// (value, position) order build keys whose low bits hold the position and check the result against the full order (pqt_k_traverse's
+// part sorts: truncated distance key | position, exact unless two distances agree in all but their last bits -- then the u64 network runs).
+template <int R, int K, int J>
+__device__ __forceinline__ void pqt_sort_stage32(uint32_t (&key)[R], const int lane) {
+  if constexpr (J < R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const int r2 = r | J;
+        const bool desc = (K < R) ? ((r & K) != 0) : (((lane * R) & K) != 0);
+        const uint32_t a = key[r], b = key[r2];
+        const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+        key[r] = desc ? mx : mn;
+        key[r2] = desc ? mn : mx;
+      }
+    }
+  } else {
+    constexpr int LM = J / R;
+    const bool isLow = (lane & LM) == 0;
+    const bool asc = ((lane * R) & K) == 0;
+    const bool keepMax = (isLow != asc);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t o = pqt_lane_xor_u32<LM>(key[r]);
+      const uint32_t a = key[r];
+      const uint32_t mn = a < o ? a : o, mx = a < o ? o : a;
+      key[r] = keepMax ? mx : mn;
+    }
+  }
+}
+template <int R, int K, int J>
+__device__ __forceinline__ void pqt_sort_merge32(uint32_t (&key)[R], const int lane) {
+  pqt_sort_stage32<R, K, J>(key, lane);
+  if constexpr (J > 1) pqt_sort_merge32<R, K, J / 2>(key, lane);
+}
+template <int R, int K>
+__device__ __forceinline__ void pqt_sort_level32(uint32_t (&key)[R], const int lane) {
+  pqt_sort_merge32<R, K, K / 2>(key, lane);
+  if constexpr (K < 64 * R) pqt_sort_level32<R, K * 2>(key, lane);
+}
+template <int R>
+__device__ __forceinline__ void pqt_wave_sort_u32(uint32_t (&key)[R]) {
+  pqt_sort_level32<R, 2>(key, (int)(threadIdx.x & 63));
 }

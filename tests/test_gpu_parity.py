@@ -1457,6 +1457,9 @@ def test_cross_lane_primitives_exchange_and_scan():
     for i in range(6):
         want = ((np.uint64(0x9e3779b9) * ((lane ^ np.uint64(1 << i)) + np.uint64(1))) & np.uint64(0xffffffff)).astype(np.uint32)
         assert np.array_equal(got[i * 64:(i + 1) * 64], want), "lane ^ %d" % (1 << i)
+    vals = ((np.uint64(0x9e3779b9) * (lane + np.uint64(1))) & np.uint64(0xffffffff)).astype(np.uint32)
+    assert np.array_equal(got[6 * 64:7 * 64], np.concatenate([vals[1:], vals[63:]])), "lane + 1"
+    assert np.array_equal(got[7 * 64:8 * 64], np.sort(vals | np.uint32(1))), "pqt_wave_sort_u32"
     v = ((lane * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(24)
     assert np.array_equal(pkg.debug_sort_scan(7, 64)[:64], np.cumsum(v).astype(np.uint32))
 
