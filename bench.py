@@ -676,6 +676,7 @@ def make_line(ctx, args, W, R):
                    "algorithmic_bytes_per_query": ex["path_bytes_q"],
                    "path_GBps": ex["path_bytes_q"] * qn * R["steps"] / R["elapsed"] / 1e9,
                    "path_frac_of_hbm_peak": ex["path_bytes_q"] * qn * R["steps"] / R["elapsed"] / 1e9 / HBM_PEAK_GBS,
+                   "device_bytes": W["idx"].device_bytes(),  # this rank's handle: the line store and its derived copies, tables, scratch
                    "stage_ms": stage, "dominant_kernel_by_time": ex["dominant"], "build_s": {k_: meta[k_] for k_ in ("t_data", "t_encode", "t_csr")}},
         "roofline": roof,
     }
@@ -728,6 +729,7 @@ def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
     r1, r10, r100 = recalls(W, R["out_idx"])
     leg = {"query": "query(boundVectors=%d, boundBins=%d), k=%d" % (bv, bb, k), "queries_per_sec": R["qps"], "ms_per_step": R["ms_per_step"], "steps": steps, "warmup": warmup,
            "stage_ms": R["stage"], "kernel_path": R["path"], "mean_candidates": float(R["out_cnt"].to(torch.int64).float().mean()),
+           "device_bytes": W["idx"].device_bytes(),
            "mean_bins_visited": ex["He"], "filter_fallbacks": R["st"].get("filter_fallbacks"),
            "recall@1": r1, "recall@100": r100,
            "algorithmic_bytes_per_query": ex["path_bytes_q"], "path_frac_of_hbm_peak": ex["path_bytes_q"] * W["qn"] * steps / R["elapsed"] / 1e9 / HBM_PEAK_GBS,

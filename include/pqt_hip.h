@@ -239,6 +239,11 @@ int pqt_query_candidates(pqt_index* idx, const float* q_dev, uint32_t qn, uint32
  * codes_bin_dev[n_local][LP] = the line codes in the same order (row i = code of ids_dev[i]).  Owned by the handle, valid
  * until the bins / lines are replaced.  Each out pointer may be NULL. */
 int pqt_index_device_arrays(const pqt_index* idx, const uint32_t** ids_dev, const uint32_t** codes_bin_dev, uint64_t* n_local);
+/* Device memory held by a handle, in bytes: out8[0] id-ordered line store (owned copy, dropped once the bin-ordered one exists), [1] bin-ordered
+ * line store, [2] its group-major copy (coarse table beyond the LDS), [3] its X-code copy (LDS-table rerank at C1 = 32), [4] row bias + member
+ * ids, [5] bin table + presence bitmap, [6] codebooks, coarse table, heuristic prefix, [7] the scratch arena as sized by the calls so far.
+ * (bench.py reports them as config.device_bytes: the copies of the line store are what an index costs per GPU.) */
+int pqt_index_device_bytes(const pqt_index* idx, uint64_t* out8);
 /* Multi-GPU merge helper: out of `nshards` per-shard results (as gathered by an all-gather of pqt_query_shard
  * outputs) produce the global first-k per query.  Each of idx/dist/pos points at shard 0's [QN][k] block; the block of
  * shard s starts shard_stride 32-bit words later (0 = QN*k, i.e. [shard][QN][k]; 3*QN*k when the three arrays of a

@@ -46,7 +46,7 @@ EXPORTS = [
     "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_build_heuristic_cuda", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
-    "pqt_merge_topk", "pqt_compact_results", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
+    "pqt_merge_topk", "pqt_compact_results", "pqt_index_device_bytes", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
     "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
     "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
     "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
@@ -108,6 +108,7 @@ def lib():
     L.pqt_merge_topk.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_compact_results.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_index_device_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pqt_rerank_exact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64,
                                    C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_debug_stride.argtypes = [C.c_void_p]
@@ -308,6 +309,15 @@ class PqtIndex:
         s = pqt_stats()
         _chk(self.L.pqt_get_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def device_bytes(self):
+        """Device memory of this handle by purpose (include/pqt_hip.h: pqt_index_device_bytes)."""
+        out = (C.c_uint64 * 8)()
+        _chk(self.L.pqt_index_device_bytes(self.h, out))
+        names = ("lines_id_order_owned", "lines_bin_order", "lines_group_major", "lines_xcode", "bias_and_ids", "bin_table_and_bitmap", "tree_and_heuristic", "scratch")
+        d = dict(zip(names, [int(v) for v in out]))
+        d["total"] = sum(d.values())
+        return d
 
     def last_path(self):
         """Kernel variants of the last query call, e.g. 'traverse=fused-shape2 rerank=mode2-nw12-runs chunks=1'."""

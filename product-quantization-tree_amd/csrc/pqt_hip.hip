@@ -1404,6 +1404,21 @@ int pqt_compact_results(pqt_index* idx, uint32_t qn, uint32_t k, const uint32_t*
   return PQT_OK;
 }
 
+int pqt_index_device_bytes(const pqt_index* idx, uint64_t* out8) {
+  if (!idx || !out8) return fail(PQT_ERR_INVALID, "null argument");
+  const PqtDevParams& d = idx->dp;
+  const uint64_t rows = idx->nIds, lp4 = (uint64_t)d.LP * 4;
+  out8[0] = (idx->d_codes && idx->codesOwned) ? idx->nCodes * lp4 : 0;                 // id-ordered line store as handed over (owned copy; dropped after the reorder)
+  out8[1] = idx->d_codesBin ? rows * lp4 : 0;                                           // bin-ordered line store
+  out8[2] = idx->d_codesGrp ? rows * lp4 : 0;                                           // group-major copy (coarse table beyond the LDS)
+  out8[3] = idx->d_codesX ? rows * lp4 : 0;                                             // X-code copy (LDS-table rerank at C1 = 32)
+  out8[4] = (idx->d_bias ? rows * 4 : 0) + rows * 4;                                    // row bias + member ids
+  out8[5] = (idx->tableBits ? ((uint64_t)1 << idx->tableBits) * (sizeof(PqtBinEntry) + (idx->d_lower ? 4 : 0)) : 0) + (idx->filterBits ? ((uint64_t)1 << idx->filterBits) / 8 : 0);  // bin table + presence bitmap
+  out8[6] = (uint64_t)d.C1 * d.D * 8 + (uint64_t)d.P * d.C1 * d.C2 * d.S * 8 + (uint64_t)d.LP * d.C1 * d.C1 * 4 + idx->heurRows * 22;  // codebooks (+ re-tiled copies), coarse table, heuristic
+  out8[7] = idx->candCap * (idx->sharded ? 12 : 8) + (uint64_t)idx->qCap * ((uint64_t)d.LP * d.C1 * 4 + (uint64_t)d.P * d.WC * 8 + 32) + idx->sortCap * 8;  // scratch arena of this handle
+  return PQT_OK;
+}
+
 uint64_t pqt_debug_stride(const pqt_index* idx) { return idx ? idx->stride : 0; }
 
 int pqt_debug_read(const pqt_index* idx, uint32_t qn, float* l1virt, float* segd, uint32_t* segbin, uint32_t* candIdx,
