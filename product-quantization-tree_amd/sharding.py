@@ -347,6 +347,10 @@ class BatchesInFlight:
         self.n += 1
         self.last = slot
         if self.cuda:
+            # what the caller enqueued on its stream up to here (a new query batch, say) is visible to the slot's stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.streams[slot].wait_event(ev)
             with torch.cuda.stream(self.streams[slot]):
                 return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
         return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
