@@ -75,12 +75,16 @@ int launchRS1(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st
 }  // namespace
 int launchRerankSelect(pqt_index* idx, bool cl, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
                        uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+#ifdef PQT_DEV_CFG3_ONLY
+  return pqtFail(PQT_ERR_LIMIT, "development build: configs[2]/[3] filter kernels only");
+#else
   switch (idx->dp.LP / 4) {
     case 1: return launchRS1<1>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
     case 2: return launchRS1<2>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
     case 4: return launchRS1<4>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
     default: return launchRS1<8>(idx, cl, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP);
   }
+#endif
 }
 
 namespace {
@@ -100,8 +104,13 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
                  uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
   constexpr int UV = LPV >= 8 ? 2 : 4;
   const uint32_t c1 = idx->dp.C1;
+#ifdef PQT_DEV_CFG3_ONLY
+  if (c1 != 64) return pqtFail(PQT_ERR_LIMIT, "development build: C1 = 64 only");
+  auto kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE>;
+#else
   auto kern = c1 == 64 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE> : c1 == 32 ? pqt_k_rerank_select<NW, LPV, UV, false, SH, 5, MODE>
                                                                                          : pqt_k_rerank_select<NW, LPV, UV, false, SH, 1, MODE>;
+#endif
   constexpr bool kRunsVariant = NW == 12 && LPV == 8;  // bin runs: BASELINE configs[2]/[3] shape only
   if constexpr (kRunsVariant) { if (idx->curRuns) kern = pqt_k_rerank_select<NW, LPV, UV, false, SH, 6, MODE, true>; }
   int rc = allowLds(kern, lds);
@@ -165,19 +174,31 @@ int launchRSBiasAny(pqt_index* idx, int nw, bool filter, uint32_t grid, size_t l
 #define PQT_LAUNCH_BIAS1(NWV, LPVV, MD) (idx->sharded ? launchRSBias<NWV, LPVV, true, MD>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP) \
                                                       : launchRSBias<NWV, LPVV, false, MD>(idx, grid, lds, st, v, nl, stride, k, nq, oI, oD, oP))
 #define PQT_LAUNCH_BIAS(NWV, LPVV) (filter ? PQT_LAUNCH_BIAS1(NWV, LPVV, 2) : PQT_LAUNCH_BIAS1(NWV, LPVV, 1))
+#ifdef PQT_DEV_CFG3_ONLY
+  if (!(idx->dp.LP == 32 && nw == 12 && filter)) return pqtFail(PQT_ERR_LIMIT, "development build: LP = 32, 12 wavefronts, exact filter only");
+  return PQT_LAUNCH_BIAS1(12, 8, 2);
+#else
   return idx->dp.LP == 16 ? (nw == 12 ? PQT_LAUNCH_BIAS(12, 4) : PQT_LAUNCH_BIAS(6, 4)) : (nw == 12 ? PQT_LAUNCH_BIAS(12, 8) : PQT_LAUNCH_BIAS(6, 8));
+#endif
 #undef PQT_LAUNCH_BIAS1
 #undef PQT_LAUNCH_BIAS
 }
 
 int launchRSWGAny(pqt_index* idx, int G, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
                   uint32_t* oI, float* oD, uint32_t* oP) {
+#ifdef PQT_DEV_CFG3_ONLY
+  return pqtFail(PQT_ERR_LIMIT, "development build");
+#else
   return G == 4 ? launchRSWG<4>(idx, nq, st, v, nl, stride, k, oI, oD, oP)
        : G == 2 ? launchRSWG<2>(idx, nq, st, v, nl, stride, k, oI, oD, oP)
                 : launchRSWG<1>(idx, nq, st, v, nl, stride, k, oI, oD, oP);
+#endif
 }
 
 int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, hipEvent_t ev0) {
+#ifdef PQT_DEV_CFG3_ONLY
+  return pqtFail(PQT_ERR_LIMIT, "development build");
+#else
   constexpr int SNW = kSmallWaves;
   int rc;
 #define PQT_LAUNCH_SMALL(LPVV, CL)                                                                                            \
@@ -188,19 +209,27 @@ int launchSmallLists(pqt_index* idx, bool cl, size_t lds, uint32_t grid, hipStre
   else { if (cl) PQT_LAUNCH_SMALL(8, true); else PQT_LAUNCH_SMALL(8, false); }
 #undef PQT_LAUNCH_SMALL
   return PQT_OK;
+#endif
 }
 
 // second pass of the short-list path: lists of 1025..2048 candidates (SIFT1M shape with the coarse table in LDS only)
 int launchMidLists(pqt_index* idx, size_t lds, uint32_t grid, hipStream_t st, const PqtRsArgs& sa, uint32_t* outList, uint32_t* outCount) {
+#ifdef PQT_DEV_CFG3_ONLY
+  return pqtFail(PQT_ERR_LIMIT, "development build");
+#else
   auto kern = pqt_k_rerank_sort_small<kMidWaves, 4, true, 2048, true>;
   int rc = allowLds(kern, lds);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kMidWaves * 64), (uint32_t)lds, st, sa, outList, outCount);
   return PQT_OK;
+#endif
 }
 
 int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k,
                uint32_t kP2, uint32_t kcap, uint32_t* oI, float* oD, uint32_t* oP, const uint32_t* qlist, const uint32_t* qcount, hipEvent_t ev0, hipEvent_t ev1) {
+#ifdef PQT_DEV_CFG3_ONLY
+  return pqtFail(PQT_ERR_LIMIT, "development build");
+#else
   const PqtDevParams& d = idx->dp;
   int rc;
 #define PQT_LAUNCH_BIG(CL, SH, VEC)                                                                                         \
@@ -219,6 +248,7 @@ int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st
   }
 #undef PQT_LAUNCH_BIG
   return PQT_OK;
+#endif
 }
 
 #endif  // PQT_DEV_SIFT1M_ONLY

@@ -117,5 +117,18 @@ for bv, bb in ((20000, 500), (4096, 4096)):
             med = lambda c: int(np.median(c))
             res["shard0_rerank_clocks_median"] = {"total": med(r[:, 4] & 0xffffffff), "setup": med(r[:, 7]), "row_wait": med(r[:, 1]), "adc_filter": med(r[:, 2]), "flush": med(r[:, 3]),
                                                   "band_reevaluation": med(r[:, 8]), "output": med(r[:, 9]), "candidates": med(r[:, 10])}
+            # wavefront-slot timeline on the 100 MHz wall clock: how much of the launch the slots are busy, and how ragged its end is
+            start = (ts[:, 13] >> np.uint64(32)).astype(np.int64); end = (ts[:, 14] >> np.uint64(32)).astype(np.int64); slot = (ts[:, 14] & np.uint64(0xffff)).astype(np.int64)
+            ns = int(slot.max()) + 1; busy = np.zeros(ns); last = np.zeros(ns); cnt = np.zeros(ns); t0 = start.min()
+            np.add.at(busy, slot, end - start); np.add.at(cnt, slot, 1); np.maximum.at(last, slot, end - t0)
+            res["shard0_rerank_timeline_us"] = {"slots": ns, "span": float(end.max() - t0) / 100, "slot_busy_mean": float(busy.mean()) / 100, "queries_per_slot_min_max": [int(cnt.min()), int(cnt.max())],
+                                                "slot_last_end_p10_med_p90_max": [float(np.percentile(last, x)) / 100 for x in (10, 50, 90, 100)],
+                                                "query_us_p10_med_p90_max": [float(np.percentile(end - start, x)) / 100 for x in (10, 50, 90, 100)]}
+    if os.environ.get("PQT_SHARD_DUMP"):  # results of this library for a cross-library comparison (scripts/r04_run14.sh)
+        idx.query_dev(queries, bv, bb, k, oi, od, oc, stream=st.cuda_stream)
+        shards[0].query_shard_bins_dev(queries, bv, bb, k, bins_all, cap, pack2[0], pack2[1].view(torch.float32), pack2[2], C2, stream=st.cuda_stream, sync=True)
+        torch.cuda.synchronize()
+        np.savez(os.environ["PQT_SHARD_DUMP"] + "_%d_%d.npz" % (bv, bb), oi=oi.cpu().numpy(), od=od.view(torch.int32).cpu().numpy(), oc=oc.cpu().numpy(),
+                 si=pack2[0].cpu().numpy(), sd=pack2[1].cpu().numpy(), sp=pack2[2].cpu().numpy(), sc=C2.cpu().numpy())
     out["knobs"]["%d_%d" % (bv, bb)] = res
 print(json.dumps(out, indent=1))
