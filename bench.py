@@ -551,7 +551,66 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fre
                 path=path, exchange_ms=exchange_ms, per_rank=per_rank, pipeline=pipeline)
 
 
-def roofline_block(ctx, args, W, R):
+LIVE_TRAFFIC_BUDGET_S = [480.0]  # what is left for the child runs under rocprofv3 --pmc of this bench run (all legs together)
+
+
+def live_traffic_wanted(ctx, args):
+    """N = 1 on a GPU, not switched off (--no-live-traffic / PQT_BENCH_NO_LIVE_TRAFFIC: the test suite), not inside a profiler run."""
+    return (ctx.world == 1 and not args.no_live_traffic and torch.cuda.is_available() and not os.environ.get("PQT_BENCH_NO_LIVE_TRAFFIC")
+            and not any(e.startswith(("ROCPROF", "ROCP_")) for e in os.environ))
+
+
+def live_traffic(args, wl_name, bv, bb, k, kernel, fetch_factor):
+    """HBM-side bytes of one launch of `kernel`, collected NOW: this very command (same workload and knobs, 3 + 2 steps, no checker legs) is run twice
+    as a child under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: MI355X_MICROARCH.md's recipe and
+    corrections, the same as scripts/r04_profile.sh) and the per-dispatch means are combined as FETCH * fetch_factor + WRITE.  Returns
+    (bytes or None, description).  Outside the timed region; bounded to ~5 minutes in the worst case, ~1 minute normally."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    if LIVE_TRAFFIC_BUDGET_S[0] < 40.0:
+        return None, "the run's budget for live counter passes is spent"
+    opts = list(args.option)
+    if not any(o.startswith("overlap=") for o in opts):
+        opts.append("overlap=0")  # every call in one piece: all dispatches of the kernel are full-size launches
+    child = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-gt", "--no-hbm-leg", "--no-live-traffic", "--steps", "3", "--warmup", "2",
+             "--workload", wl_name, "--bv", str(bv), "--bb", str(bb), "--k", str(k), "--iso-noise", str(args.iso_noise), "--lat-noise", str(args.lat_noise),
+             "--centers", str(args.centers), "--center-scale", str(args.center_scale), "--query-mode", args.query_mode]
+    for o in opts:
+        child += ["--option", o]
+    env = dict(os.environ, TMPDIR="/tmp", PQT_BENCH_NO_PIPELINE="1")
+    pat = re.compile(r"\b%s[<(]" % re.escape(kernel))
+    means, disp, t_all = {}, 0, time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for attempt in (1, 2):  # (rocprofv3 --pmc occasionally hangs at process start on this image: bounded, one retry)
+            d = tempfile.mkdtemp(prefix="pqt_pmc_", dir="/tmp")
+            try:
+                subprocess.run([rp, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child, env=env, cwd="/tmp",
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=max(30.0, min(75.0 if WORKLOADS[wl_name]["n_base"] <= 10_000_000 else 150.0, LIVE_TRAFFIC_BUDGET_S[0] - (time.time() - t_all))))
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r["Counter_Name"] == ctr and pat.search(r["Kernel_Name"]):
+                            vals.append(float(r["Counter_Value"]))
+            except Exception as e:  # timeout, missing counters, unreadable output
+                log("[bench] live traffic pass %s attempt %d failed: %r" % (ctr, attempt, e))
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+            if vals:
+                break
+        if not vals:
+            LIVE_TRAFFIC_BUDGET_S[0] -= time.time() - t_all
+            return None, "rocprofv3 --pmc %s pass gave no dispatch of %s" % (ctr, kernel)
+        means[ctr], disp = sum(vals) / len(vals), len(vals)
+    LIVE_TRAFFIC_BUDGET_S[0] -= time.time() - t_all
+    return (means["FETCH_SIZE"] * fetch_factor + means["WRITE_SIZE"]) * 1024.0, (
+        "measured in this run: two child runs of this command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), mean of %d "
+        "dispatches, FETCH_SIZE x %.0f (gfx950 correction for this row width, profiles/r01_pmc_calibration.json) + WRITE_SIZE, KiB -> bytes; %.0f s outside the timed region"
+        % (disp, fetch_factor, time.time() - t_all))
+
+
+def roofline_block(ctx, args, W, R, live=False):
     """`roofline` object of the dominant kernel (largest mean launch duration over the timed steps) + the whole-path figures."""
     w, qn, k, st, stage = W["w"], W["qn"], R["k"], R["st"], R["stage"]
     LP, C1 = w["LP"], w["C1"]
@@ -590,8 +649,17 @@ def roofline_block(ctx, args, W, R):
                 traffic_source = "committed profile (profiles/pmc_latest.json: %s); not collected in this run" % pms.get("source", "rocprofv3 --pmc passes")
     except Exception:
         traffic = None
+    traffic_committed = traffic
+    if live:
+        # default N = 1 line: collected live, so that a change of the kernel's memory behaviour shows in the driver's line; the committed profile's
+        # figure rides along (roofline.traffic_committed_profile) and stands in only when the collection fails
+        lt, why = live_traffic(args, W["name"], R["bv"], R["bb"], k, rr_name, 2.0 if LP * 4 >= 128 else 1.0)
+        if lt is not None:
+            traffic, traffic_source = lt, why
+        else:
+            traffic_source = "live collection failed (%s); %s" % (why, traffic_source or "no committed profile of this command")
     roof = {"bound": "hbm", "kernel": rr_name, "achieved": rr_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "frac": rr_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_committed_profile": traffic_committed,
             "traffic_ratio": (traffic / rr_bytes) if (traffic and rr_bytes) else None,
             "resident": resident, "line_store_bytes": store_bytes,
             "avg_launch_ms": rr_ms,
@@ -631,7 +699,7 @@ def make_line(ctx, args, W, R):
         agg = torch.tensor([r1, r10, r100, ncand_mean], dtype=torch.float64, device=dev)
         dist.all_reduce(agg)
         r1, r10, r100, ncand_mean = (agg / world).tolist()
-    roof, ex = roofline_block(ctx, args, W, R)
+    roof, ex = roofline_block(ctx, args, W, R, live=live_traffic_wanted(ctx, args))
     meta, st, stage = W["meta"], R["st"], R["stage"]
     shard_par = "%d GPUs: db range-sharded by vector id (%d vectors per rank, built by the rank itself), %s, %s" % (
         world, ex["n_local"],
@@ -721,11 +789,11 @@ def ranks_agree(ctx, R):
     return bool(lo_c.item() == hi_c.item())
 
 
-def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
+def knob_leg(ctx, args, W, bv, bb, k, steps, warmup, live=False):
     """One knob set on an index that is already built: q/s, stage ms, roofline of its dominant kernel."""
     set_heuristic_rows(ctx, W["idx"], W["w"], max(bb, 1))
     R = time_path(ctx, args, W, bv, bb, k, steps, warmup, period=2)
-    roof, ex = roofline_block(ctx, args, W, R)
+    roof, ex = roofline_block(ctx, args, W, R, live=live)
     r1, r10, r100 = recalls(W, R["out_idx"])
     leg = {"query": "query(boundVectors=%d, boundBins=%d), k=%d" % (bv, bb, k), "queries_per_sec": R["qps"], "ms_per_step": R["ms_per_step"], "steps": steps, "warmup": warmup,
            "stage_ms": R["stage"], "kernel_path": R["path"], "mean_candidates": float(R["out_cnt"].to(torch.int64).float().mean()),
@@ -733,7 +801,7 @@ def knob_leg(ctx, args, W, bv, bb, k, steps, warmup):
            "mean_bins_visited": ex["He"], "filter_fallbacks": R["st"].get("filter_fallbacks"),
            "recall@1": r1, "recall@100": r100,
            "algorithmic_bytes_per_query": ex["path_bytes_q"], "path_frac_of_hbm_peak": ex["path_bytes_q"] * W["qn"] * steps / R["elapsed"] / 1e9 / HBM_PEAK_GBS,
-           "roofline": {k_: roof[k_] for k_ in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_source",
+           "roofline": {k_: roof[k_] for k_ in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "traffic_source", "traffic_committed_profile",
                                                  "traffic_ratio", "resident", "line_store_bytes", "other_kernels")}}
     return leg, R
 
@@ -784,7 +852,7 @@ def hbm_roofline_leg(ctx, args):
            "build_s": {k_: W["meta"][k_] for k_ in ("t_data", "t_encode", "t_csr")}}
     steps = max(4, min(args.steps, 10))
     for bv, bb in ((20000, 500), (4096, 4096)):
-        leg["knobs_%d_%d" % (bv, bb)], _ = knob_leg(ctx, args, W, bv, bb, args.k, steps, 2)
+        leg["knobs_%d_%d" % (bv, bb)], _ = knob_leg(ctx, args, W, bv, bb, args.k, steps, 2, live=args.live_traffic_hbm and live_traffic_wanted(ctx, args))
         try:
             leg["knobs_%d_%d" % (bv, bb)]["dram_side"] = dram_side_figures(ctx, args, W, bv, bb, args.k, steps, leg["knobs_%d_%d" % (bv, bb)])
         except Exception as e:
@@ -813,6 +881,10 @@ def main():
                     "where torch's reduce kernels crash the profiler on this image")
     ap.add_argument("--extras", action="store_true", help="also run the side legs (knob set (4096,4096), exact re-rank of the top-k, "
                     "opt-in ADC modes); off by default so that a profile of the default command contains only the headline path's launches")
+    ap.add_argument("--no-live-traffic", action="store_true", help="N = 1: do not collect roofline.traffic live (two child runs under rocprofv3 --pmc, ~1 min); "
+                                                                   "the committed profile's figure is used instead")
+    ap.add_argument("--live-traffic-hbm", action="store_true", help="also collect the traffic of the hbm_roofline_leg's launches live (four child runs that build the 100 M index: "
+                                                                    "minutes; scripts/r04_profile_all.sh does); by default that leg carries the committed profile's figures")
     ap.add_argument("--no-hbm-leg", action="store_true", help="N = 1: skip config.hbm_roofline_leg (the 100 M-vector configuration beside the headline)")
     ap.add_argument("--hbm-workload", default="synth100m", choices=list(WORKLOADS), help="workload of the hbm_roofline_leg (tests use a small one)")
     ap.add_argument("--shard-db", action="store_true", help="(default for --gpus N > 1) range-shard the database")

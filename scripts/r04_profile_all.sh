@@ -13,7 +13,7 @@ tail -4 gpurun_out/prof_a.log gpurun_out/prof_b.log gpurun_out/prof_c.log | cut 
 cd /tmp && PQT_BENCH_NO_PIPELINE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_default -o r04_default -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --option overlap=0 > $GRAFT_REPO_ROOT/gpurun_out/prof/r04_default_bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof/r04_default_bench.log; cd $GRAFT_REPO_ROOT
 cp /tmp/prof_default/r04_default_kernel_stats.csv gpurun_out/prof/ 2>/dev/null
 grep pqt_k gpurun_out/prof/r04_default_kernel_stats.csv | cut -c1-200
-python bench.py 2> gpurun_out/bench/default.log | grep '^{"metric' > gpurun_out/bench/r04_bench_default.json
+python bench.py --live-traffic-hbm 2> gpurun_out/bench/default.log | grep '^{"metric' > gpurun_out/bench/r04_bench_default.json
 python bench.py --extras --no-hbm-leg 2> gpurun_out/bench/extras.log | grep '^{"metric' > gpurun_out/bench/r04_bench_default_extras.json
 python bench.py --workload synth10m 2> gpurun_out/bench/s10m.log | grep '^{"metric' > gpurun_out/bench/r04_bench_synth10m.json
 python - <<'PY'

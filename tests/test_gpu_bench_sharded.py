@@ -55,6 +55,20 @@ def test_single_rank_rccl_drives_every_collective_of_the_sharded_path(exchange):
     assert c["ranks_agree"] is True and c["same_workload_1gpu"]["results_identical_to_sharded"] is True
 
 
+def test_live_traffic_of_the_dominant_kernel_is_collected_by_the_bench_run_itself():
+    """`roofline.traffic` of the N = 1 line is measured by the run (two child runs of the same command under `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE`), not replayed from the committed profile: within a factor of the algorithmic bytes, source says so, and the timed value is
+    untouched by it (collected after the timed region)."""
+    env = dict(os.environ, PQT_BENCH_NO_PIPELINE="1")
+    env.pop("PQT_BENCH_NO_LIVE_TRAFFIC", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "synth1m", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-hbm-leg"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
+    assert r["traffic"] > 0 and 0.05 < r["traffic_ratio"] < 20, r
+
+
 def test_default_line_carries_the_hbm_roofline_leg():
     """`python bench.py` (N = 1): `value` is the SIFT1M-shape number and config.hbm_roofline_leg holds the configs[2] workload at both
     knob sets with the dominant kernel's roofline fraction (here with a small stand-in workload so the test stays short)."""
