@@ -143,6 +143,16 @@ int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples_host, uint64_
  * min(16, max_cluster), tuples ordered by sum_p sqrt(digit) (f32, ties by tuple index), at most 65536 rows.  Changes the
  * ORDER in which bins are enumerated, nothing else (bin ids, cut and rerank stay cpu_version). */
 int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_t rows);
+/* Optional mode: the CUDA library's 2-D anisotropic sequences of its 1B path, ProTree::prepare2DDistSequence(maxCluster)
+ * (pqt/ProTree.cu:50-126; test/test1B.cpp:941 passes 512) and their per-query use (pqt/PerturbationProTree.cu:2839-3100:
+ * computeSlopeIdx, generate2DBins, selectBinKernel2D2Parts, selectBinKernel2DFinal).  p = 4 only.  Builds the 10 cell orders
+ * (key x^0.8 + s*y^0.8, 65536 cells each); from then on every query picks ITS rows: parts (0,1) and (2,3) are merged into two
+ * 256-long pair lists through the order chosen by the slope of their sorted distances, the pair lists the same way, and row r of
+ * the query is the tuple of four part ranks behind cell r of that order (cells outside the lists name no bin).  Changes the SET of
+ * enumerated rows (at most min(65536, max_cluster^2), bound_bins <= 8192 as always), nothing else: bin ids, the exact sort of the
+ * rows by distance, the cut and the rerank stay cpu_version; the CUDA kernels' sorting inside 1024-row chunks, 2-vectors-per-bin
+ * cap and stop at k vectors are not reproduced.  Any other heuristic entry switches the mode off again. */
+int pqt_index_build_heuristic_2d(pqt_index* idx, uint32_t max_cluster);
 int pqt_index_get_heuristic(const pqt_index* idx, uint32_t* out_host, uint64_t rows);
 
 /* ---- bin store ----------------------------------------------------------------------------
@@ -298,6 +308,7 @@ int pqt_multi_set_option(pqt_multi* m, const char* name, int64_t value);
 int pqt_multi_set_codebooks(pqt_multi* m, const float* cb1_host, const float* cb2_host);   /* = pqt_index_set_codebooks */
 int pqt_multi_build_heuristic(pqt_multi* m, uint64_t rows);                                /* = pqt_index_build_heuristic */
 int pqt_multi_build_heuristic_cuda(pqt_multi* m, uint32_t max_cluster, uint64_t rows);     /* = pqt_index_build_heuristic_cuda, every shard gets the table */
+int pqt_multi_build_heuristic_2d(pqt_multi* m, uint32_t max_cluster);                        /* = pqt_index_build_heuristic_2d on every shard (each traverses all queries itself in this mode) */
 int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows);
 /* the WHOLE database as for pqt_index_set_bins (members of a bin in ascending id order = the reference's insertion order);
  * every shard keeps its id range.  n_total = number of vectors (0: the sum of the bin sizes). */

@@ -49,6 +49,10 @@ def _lib():
     L.pqo_heuristic_rows.argtypes = [C.c_void_p]
     L.pqo_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_ulonglong]
     L.pqo_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_ulonglong]
+    L.pqo_build_heuristic_2d.restype = C.c_int
+    L.pqo_build_heuristic_2d.argtypes = [C.c_void_p, C.c_uint]
+    L.pqo_get_heuristic_2d.argtypes = [C.c_void_p, u32p]
+    L.pqo_rows_2d.argtypes = [C.c_void_p, f32p, C.c_uint, u32p]
     L.pqo_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqo_get_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqo_get_coarse.argtypes = [C.c_void_p, f32p]
@@ -185,6 +189,24 @@ class Oracle:
     def set_heuristic(self, rows):
         rows = np.ascontiguousarray(rows, np.uint32)
         self.L.pqo_set_heuristic(self.h, _ptr(rows, u32p), rows.shape[0])
+
+    def build_heuristic_2d(self, max_cluster):
+        """Optional mode: the CUDA library's 2-D anisotropic sequences (ProTree.cu:50-126) and their per-query use
+        (PerturbationProTree.cu:2839-3100); p = 4.  Any other heuristic call switches it off again."""
+        if self.L.pqo_build_heuristic_2d(self.h, int(max_cluster)) != 0:
+            raise ValueError("2-D sequences need p = 4 and 2 <= max_cluster <= 4096")
+
+    def heuristic_2d(self):
+        out = np.zeros((10, 65536), np.uint32)
+        self.L.pqo_get_heuristic_2d(self.h, _ptr(out, u32p))
+        return out
+
+    def rows_2d(self, vec, rows):
+        """The rows one query enumerates in the 2-D mode: [rows][P] part ranks, digit 0 = 0xffffffff where the cell names no bin."""
+        v = np.ascontiguousarray(vec, np.float32).reshape(self.D)
+        out = np.zeros((rows, self.P), np.uint32)
+        self.L.pqo_rows_2d(self.h, _ptr(v, f32p), rows, _ptr(out, u32p))
+        return out
 
     def set_codebooks(self, cb1, cb2):
         cb1 = np.ascontiguousarray(cb1, np.float32).reshape(self.C1, self.D)

@@ -191,6 +191,7 @@ struct Oracle {
   // base `base`), sorted by squared norm with the unstable std::sort; only the first `keep` rows are
   // retained here (the reference keeps all of them but orderBins reads only the first boundBins).
   void prepareHeuristic(size_t keep) {
+    mode2d = false;
     const size_t M = maxMultiIndex;
     std::vector<float> norm(M);
     std::vector<uint> order(M);
@@ -213,6 +214,99 @@ struct Oracle {
       uint dec = order[h];
       uint p = 0;
       while (dec > 0) { heur[h * P + p] = dec % base; dec /= base; ++p; }
+    }
+  }
+
+  // ==== optional mode: the CUDA library's 2-D anisotropic sequences.  NOT cpu_version behaviour: it replaces the
+  // shared tuple table by per-query rows chosen the way the CUDA 1B path chooses its bins; everything after the choice of the rows
+  // (bin ids, distances, exact sort, cut, rerank) stays the cpu_version text above.  Restated from the CUDA sources, which cannot
+  // be run here (no CUDA): "parity unpinned" like the rest of the traversal.
+  bool mode2d = false;
+  uint seqDc = 0;
+  std::vector<uint> seq2d;  // [10][65536] cell numbers
+  float thr2d[9];
+  // ---- pqt/ProTree.cu:50-126 prepare2DDistSequence(_maxCluster); ProTree.hh:9-13 NUM_DISTSEQ 65536, NUM_ANISO_DIR 10, ANISO_BASE 1.2f
+  void prepare2DDistSequence(uint maxCluster) {
+    const uint NUM_DISTSEQ = 65536, NUM_ANISO_DIR = 10;
+    const float ANISO_BASE = 1.2f;
+    const uint nVec = maxCluster * maxCluster;                    // :55 pow(_maxCluster, 2)
+    const uint copyVec = nVec < NUM_DISTSEQ ? nVec : NUM_DISTSEQ;  // :57
+    seq2d.assign((size_t)NUM_DISTSEQ * NUM_ANISO_DIR, 0u);        // :113-114 zero fill
+    for (uint slope = 0; slope < NUM_ANISO_DIR; ++slope) {
+      const float s = (float)pow(0.9 * ANISO_BASE, (int)slope - (int)(NUM_ANISO_DIR / 2));  // :68 (double arithmetic, stored in a float)
+      std::vector<std::pair<float, uint> > dists;
+      for (uint i = 0; i < nVec; ++i) {
+        const float x = (float)(i % maxCluster);  // :76
+        const float y = (float)(i / maxCluster);  // :77
+        const float n = 0.8f;                     // :89
+        const float dist = std::pow(x, n) + s * std::pow(y, n);  // :91 (float overloads: the file is compiled as C++ with <cmath>)
+        dists.push_back(std::pair<float, uint>(dist, i));
+      }
+      std::sort(dists.begin(), dists.end());  // :105 (pairs: ties in the key fall back to the cell number, so the order is unique)
+      for (uint i = 0; i < copyVec; ++i) seq2d[(size_t)slope * NUM_DISTSEQ + i] = dists[i].second;  // :116-117
+    }
+    seqDc = maxCluster;
+    // slope classes: the CUDA text computes si = roundf(logf(slope) / logf(ANISO_BASE)) + NUM_ANISO_DIR / 2 clamped to [0, 9]
+    // (PerturbationProTree.cu:2851-2853).  roundf(t) + 5 >= j + 1  <=>  t >= j - 4.5  <=>  slope >= 1.2^(j - 4.5): the class is the number
+    // of these 9 boundaries at or below the slope.  Stated through the boundaries (runtime powf, like the engine) so that the
+    // class does not depend on which logf is linked; a NaN or negative slope falls into class 0 as the clamped expression does.
+    volatile float b = ANISO_BASE;
+    for (int j = 0; j < 9; ++j) thr2d[j] = powf(b, (float)j - 4.5f);
+    heurRows = copyVec;
+    heur.assign(P, 0);
+    mode2d = true;
+  }
+  // ---- pqt/PerturbationProTree.cu:2839-2858 computeSlopeIdx (sample positions passed in: sqrtf(2 N) and one below, see rows2D)
+  uint slopeIdx(const float* val0, const float* val1, uint s, uint sm) const {
+    const float slope = (val1[s] + val1[sm] - 2 * val1[0]) / (val0[s] + val0[sm] - 2 * val0[0]);  // :2847-2848
+    uint si = 0;
+    for (int j = 0; j < 9; ++j) if (slope >= thr2d[j]) ++si;
+    return si;
+  }
+  // ---- the per-query rows: selectBinKernel2D2Parts (:2914-3006, with generate2DBins :2888-2910) for the pairs of parts, then the
+  // row loop of selectBinKernel2DFinal (:3047-3075) over the two merged lists.  rows[h*P .. ] = the four part ranks of row h,
+  // or 0xffffffff in digit 0 when the cell names no bin (the CUDA kernels give such cells distance 99999999999 and bin 0).
+  void rows2D(const Ctx& c, size_t h_e, std::vector<uint>& rows) const {
+    const uint WC = W * C2;
+    const uint kMax = WC < 64 ? WC : 64;     // getBIGBins2D :3729 kMax = 64 (clamped to the list length here)
+    const uint nInter = 256;                 // :3735 nIntermediateBin
+    // computeSlopeIdx samples at sqrtf(2.f * N) and one below: N = nInter for the pairs (:2970), N = 1024 for the final merge (:3071)
+    uint s1 = (uint)sqrtf(2.f * nInter); if (s1 > kMax - 1) s1 = kMax - 1;
+    const uint s1m = s1 ? s1 - 1 : 0;
+    const uint s2 = (uint)sqrtf(2.f * 1024), s2m = s2 - 1;
+    struct Ent { float d; uint t, x, y; bool pad; };
+    std::vector<Ent> pair[2];
+    std::vector<float> ld[2];
+    for (uint j = 0; j < 2; ++j) {
+      std::vector<float> v0(kMax), v1(kMax);  // the sorted assignment values of parts 2j and 2j+1 (:2947-2962)
+      for (uint r = 0; r < kMax; ++r) {
+        v0[r] = c.segD2[(2 * j) * WC + c.segOrder[(2 * j) * WC + r]];
+        v1[r] = c.segD2[(2 * j + 1) * WC + c.segOrder[(2 * j + 1) * WC + r]];
+      }
+      const uint si = slopeIdx(v0.data(), v1.data(), s1, s1m);
+      pair[j].resize(nInter);
+      for (uint t = 0; t < nInter; ++t) {   // generate2DBins :2894-2907
+        const uint cell = seq2d[(size_t)si * 65536 + t];
+        const uint x = cell % seqDc, y = cell / seqDc;
+        Ent e; e.t = t; e.x = x; e.y = y;
+        if (x < kMax && y < kMax) { e.d = v0[x] + v1[y]; e.pad = false; }
+        else { e.d = 99999999999.f; e.pad = true; }
+        pair[j][t] = e;
+      }
+      // bitonic3 (:2987) orders by the distance; equal distances are taken in cell order here
+      std::sort(pair[j].begin(), pair[j].end(), [](const Ent& l, const Ent& r) { return l.d < r.d || (l.d == r.d && l.t < r.t); });
+      ld[j].resize(nInter);
+      for (uint t = 0; t < nInter; ++t) ld[j][t] = pair[j][t].d;
+    }
+    const uint si2 = slopeIdx(ld[0].data(), ld[1].data(), s2, s2m);
+    rows.assign(h_e * P, 0);
+    for (size_t h = 0; h < h_e; ++h) {
+      const uint cell = seq2d[(size_t)si2 * 65536 + h];  // :3079-3085 (chunk nIter, thread t: entry nIter * 1024 + t)
+      const uint x = cell % seqDc, y = cell / seqDc;
+      if (x < nInter && y < nInter && !pair[0][x].pad && !pair[1][y].pad) {
+        rows[h * P + 0] = pair[0][x].x; rows[h * P + 1] = pair[0][x].y;
+        rows[h * P + 2] = pair[1][y].x; rows[h * P + 3] = pair[1][y].y;
+      } else rows[h * P] = 0xffffffffu;
     }
   }
 
@@ -329,17 +423,21 @@ struct Oracle {
     if (h_e > heurRows) h_e = heurRows;  // callers keep heurRows >= boundBins
     binCand.clear(); binCand.reserve(h_e);
     seqOrder.clear(); seqOrder.reserve(h_e);
+    std::vector<uint> rowsQ;
+    if (mode2d) rows2D(c, h_e, rowsQ);  // optional mode: this query's own rows
+    const uint* tab = mode2d ? rowsQ.data() : heur.data();
     for (size_t h = 0; h < h_e; ++h) {
       uint globIdx = 0;
       float fine = 0;
+      if (mode2d && tab[h * P] == 0xffffffffu) continue;  // a cell without a bin
       for (uint p = 0; p < P; ++p) {
-        const uint idx = heur[h * P + p];
+        const uint idx = tab[h * P + p];
         const uint kkk = c.segOrder[p * WC + idx];
         fine += c.segD2[p * WC + kkk];
         globIdx += (c.segL1[p * WC + kkk] * C2 + c.segL2[p * WC + kkk]) * powers[p];
       }
       binCand.push_back({globIdx, fine});
-      seqOrder.push_back((uint)h);
+      seqOrder.push_back((uint)(binCand.size() - 1));
     }
     if (sortBins) {
       const std::pair<uint, float>* bc = binCand.data();
@@ -552,7 +650,23 @@ void pqo_get_heuristic(void* h, uint* out, unsigned long long rows) {
 }
 // replace the heuristic prefix (used to feed the oracle the very table the HIP index holds)
 void pqo_set_heuristic(void* h, const uint* rows, unsigned long long n) {
-  Oracle* o = (Oracle*)h; o->heur.assign(rows, rows + n * o->P); o->heurRows = n;
+  Oracle* o = (Oracle*)h; o->heur.assign(rows, rows + n * o->P); o->heurRows = n; o->mode2d = false;
+}
+// optional mode: the CUDA library's 2-D anisotropic sequences (p = 4); returns 0 on success
+int pqo_build_heuristic_2d(void* h, uint max_cluster) {
+  Oracle* o = (Oracle*)h;
+  if (o->P != 4 || max_cluster < 2 || max_cluster > 4096) return 1;
+  o->prepare2DDistSequence(max_cluster);
+  return 0;
+}
+// the 10 cell orders, [10][65536]
+void pqo_get_heuristic_2d(void* h, uint* out) { Oracle* o = (Oracle*)h; memcpy(out, o->seq2d.data(), o->seq2d.size() * sizeof(uint)); }
+// the rows one query enumerates in that mode (h_e rows of P digits, digit 0 = 0xffffffff: no bin)
+void pqo_rows_2d(void* h, const float* vec, uint h_e, uint* out) {
+  Oracle* o = (Oracle*)h; Ctx& c = o->ctx;
+  o->l1tables(c, vec); o->segmentInfo(c, vec);
+  std::vector<uint> rows; o->rows2D(c, h_e, rows);
+  memcpy(out, rows.data(), rows.size() * sizeof(uint));
 }
 void pqo_set_codebooks(void* h, const float* cb1, const float* cb2) {
   Oracle* o = (Oracle*)h;

@@ -43,13 +43,13 @@ class pqt_stats(C.Structure):
 EXPORTS = [
     "pqt_last_error", "pqt_device_count", "pqt_index_create", "pqt_index_destroy", "pqt_index_params", "pqt_index_create_view",
     "pqt_index_set_option", "pqt_debug_tstamps", "pqt_kmeans_assign", "pqt_debug_calibrate_gather", "pqt_rerank_exact",
-    "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_build_heuristic_cuda", "pqt_index_set_heuristic",
+    "pqt_index_set_codebooks", "pqt_index_get_coarse", "pqt_index_build_heuristic", "pqt_index_build_heuristic_cuda", "pqt_index_build_heuristic_2d", "pqt_index_set_heuristic",
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_compact_results", "pqt_index_device_bytes", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
     "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
     "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
-    "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
+    "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_build_heuristic_2d", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
     "pqt_multi_query_host",
 ]
 
@@ -85,6 +85,7 @@ def lib():
     L.pqt_index_get_coarse.argtypes = [C.c_void_p, f32p]
     L.pqt_index_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
     L.pqt_index_build_heuristic_cuda.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    L.pqt_index_build_heuristic_2d.argtypes = [C.c_void_p, C.c_uint32]
     L.pqt_index_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_index_get_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_index_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p]
@@ -132,6 +133,7 @@ def lib():
     L.pqt_multi_set_codebooks.argtypes = [C.c_void_p, f32p, f32p]
     L.pqt_multi_build_heuristic.argtypes = [C.c_void_p, C.c_uint64]
     L.pqt_multi_build_heuristic_cuda.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    L.pqt_multi_build_heuristic_2d.argtypes = [C.c_void_p, C.c_uint32]
     L.pqt_multi_set_heuristic.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_multi_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint64]
     L.pqt_multi_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64]
@@ -215,6 +217,10 @@ class PqtIndex:
     def build_heuristic_cuda(self, max_cluster, rows):
         """The CUDA library's prepareDistSequence order (sum of sqrt(digit), digits < min(16, max_cluster)) as the table."""
         _chk(self.L.pqt_index_build_heuristic_cuda(self.h, max_cluster, rows))
+
+    def build_heuristic_2d(self, max_cluster):
+        """The CUDA library's 2-D anisotropic sequences (prepare2DDistSequence + the 1B path's pairwise merges): per-query rows, p = 4."""
+        _chk(self.L.pqt_index_build_heuristic_2d(self.h, max_cluster))
 
     def set_heuristic(self, tuples):
         t = _np(tuples, np.uint32).reshape(-1, self.P)
@@ -391,6 +397,9 @@ class PqtMulti:
 
     def build_heuristic_cuda(self, max_cluster, rows):
         self._chk(self.L.pqt_multi_build_heuristic_cuda(self.h, max_cluster, rows))
+
+    def build_heuristic_2d(self, max_cluster):
+        self._chk(self.L.pqt_multi_build_heuristic_2d(self.h, max_cluster))
 
     def set_heuristic(self, tuples):
         t = _np(tuples, np.uint32).reshape(-1, self.P)

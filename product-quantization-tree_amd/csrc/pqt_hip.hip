@@ -456,17 +456,31 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
           hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                              idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                              idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap, (uint64_t)0);
         else
           hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lBins, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
                              idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, He, HeP2, Bv, d, idx->d_table, idx->d_lower,
                              idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
+                             stride, idx->d_ovList, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap, (uint64_t)0);
       }
     } else {
     hipLaunchKernelGGL(pqt_k_tables, dim3(nq), dim3(PQT_BLOCK), lTab, st, q_dev + (size_t)q0 * d.D, idx->d_cb1, idx->d_cb2, d,
                        idx->d_qL1virt + (size_t)q0 * d.LP * d.C1, idx->d_segD + (size_t)q0 * d.P * d.WC,
                        idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->ctr);
+    const uint16_t* heurArg = idx->d_heur8;
+    uint64_t heurStride = 0;
+    if (idx->heur2d) {
+      // 2-D anisotropic sequences: this chunk's queries get their own row tables from the sorted part lists
+      if ((uint64_t)nq * He > idx->heurQCap) {
+        if ((rc = devAlloc(&idx->d_heurQ, (size_t)qChunk * He))) return rc;
+        idx->heurQCap = (uint64_t)qChunk * He;
+      }
+      PqtRows2dArgs ra{idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_seq2d, idx->d_heurQ, idx->seq2dDc, d.WC, std::min<uint32_t>(64u, d.WC), He, nq, {0}};
+      for (int j = 0; j < 9; ++j) ra.thr[j] = idx->slopeThr[j];
+      hipLaunchKernelGGL(pqt_k_rows_2d, dim3((nq + 3) / 4), dim3(256), 0, st, ra);
+      heurArg = reinterpret_cast<const uint16_t*>(idx->d_heurQ);
+      heurStride = He;
+    }
     PQT_REC(EV_TABLES);
     // pass 1: small LDS arena (high occupancy); queries with more populated bins than it holds queue themselves for
     // pass 2, which runs the same kernel with a full-size arena on that (usually empty) list
@@ -478,14 +492,14 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       if (pass == 1 && cap1 >= He) break;
       if (idx->sharded)
         hipLaunchKernelGGL(pqt_k_bins<true>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                           idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
+                           idx->d_segBin + (size_t)q0 * d.P * d.WC, heurArg, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap, heurStride);
       else
         hipLaunchKernelGGL(pqt_k_bins<false>, dim3(nq), dim3(PQT_BLOCK), lds, st, idx->d_segD + (size_t)q0 * d.P * d.WC,
-                           idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_heur8, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
+                           idx->d_segBin + (size_t)q0 * d.P * d.WC, heurArg, He, cap, capP2, Bv, d, idx->d_table, idx->d_lower,
                            idx->tableBits, idx->d_cand, idx->d_candPos, idx->d_nCand + q0, idx->d_nLocal + q0, idx->d_nIncl + q0,
-                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap);
+                           stride, ql, idx->d_ovCount, idx->d_ovList, idx->d_ovCount, idx->ctr, schedCntArg, idx->d_schedList, idx->curSchedCap, heurStride);
     }
     }
     // wave-per-query rerank: workgroup-local dynamic schedule when a wavefront slot gets more than one query
@@ -720,12 +734,12 @@ void pqt_index_destroy(pqt_index* idx) {
   if (idx->evFork) (void)hipEventDestroy(idx->evFork);
   for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
   if (idx->isView) {  // the arrays of the index belong to the owner
-    idx->d_cb1 = idx->d_cb2 = idx->d_coarse = idx->d_cb1L = idx->d_cb2T = nullptr; idx->d_heur = idx->d_heur8 = nullptr; idx->d_heur4 = nullptr;
+    idx->d_cb1 = idx->d_cb2 = idx->d_coarse = idx->d_cb1L = idx->d_cb2T = nullptr; idx->d_heur = idx->d_heur8 = nullptr; idx->d_heur4 = nullptr; idx->d_seq2d = nullptr;
     idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_codesX = idx->d_filter = nullptr; idx->d_bias = nullptr;
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -855,6 +869,7 @@ int pqt_index_get_coarse(const pqt_index* idx, float* out) {
 static int uploadHeuristic(pqt_index* idx) {
   int rc = setDevice(idx);
   if (rc) return rc;
+  idx->heur2d = false;  // a shared table replaces the per-query 2-D rows (pqt_index_build_heuristic_2d sets the flag again after this call)
   const uint32_t P = idx->dp.P;
   std::vector<uint16_t> h16(idx->heurRows * P);
   for (size_t i = 0; i < h16.size(); ++i) {
@@ -948,6 +963,46 @@ int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_
     for (uint32_t p = 0; p < P; ++p) idx->heurHost[h * P + p] = (uint32_t)((dists[(size_t)h].second / denom[p]) % b);
   idx->heurRows = rows;
   return uploadHeuristic(idx);
+}
+
+// Optional mode ("next" row 8f-4 tail): the CUDA library's 2-D anisotropic sequences, ProTree::prepare2DDistSequence(maxCluster)
+// (pqt/ProTree.cu:50-126): for each of NUM_ANISO_DIR = 10 slopes s = (0.9 * 1.2f)^(slope - 5) (double power, rounded to f32) all
+// maxCluster^2 cells i (x = i % maxCluster, y = i / maxCluster) keyed x^0.8 + s * y^0.8 in f32 (powf), std::sort of (key, i)
+// pairs, the first NUM_DISTSEQ = 65536 cells kept (zero filled behind a shorter list).  The per-query use is pqt_k_rows_2d.
+int pqt_index_build_heuristic_2d(pqt_index* idx, uint32_t max_cluster) {
+  if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_build_heuristic_2d: a view handle shares the owner's index; load into the owner");
+  if (!idx) return fail(PQT_ERR_INVALID, "null argument");
+  if (idx->dp.P != 4) return fail(PQT_ERR_LIMIT, "the 2-D sequences merge parts (0,1) and (2,3): p = 4 only (pqt/PerturbationProTree.cu:2914-3100)");
+  if (max_cluster < 2 || max_cluster > 4096) return fail(PQT_ERR_INVALID, "max_cluster must be in [2, 4096] (test/test1B.cpp:941 passes 512)");
+  constexpr uint32_t kSeq = 65536, kDir = 10;
+  const uint32_t nVec = max_cluster * max_cluster;
+  std::vector<uint32_t> seq((size_t)kSeq * kDir, 0u);
+  std::vector<std::pair<float, uint32_t> > dists(nVec);
+  for (uint32_t slope = 0; slope < kDir; ++slope) {
+    const float s = (float)std::pow(0.9 * (double)1.2f, (double)((int)slope - (int)(kDir / 2)));
+    for (uint32_t i = 0; i < nVec; ++i) {
+      const float x = (float)(i % max_cluster), y = (float)(i / max_cluster);
+      const float n = 0.8f;
+      dists[i] = std::make_pair(powf(x, n) + s * powf(y, n), i);
+    }
+    std::sort(dists.begin(), dists.end());
+    const uint32_t keep = std::min<uint32_t>(nVec, kSeq);
+    for (uint32_t i = 0; i < keep; ++i) seq[(size_t)slope * kSeq + i] = dists[i].second;
+  }
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  // (queries check for a heuristic through d_heur / heurRows: one all-zero row stands in for the shared table)
+  idx->heurHost.assign(idx->dp.P, 0u);
+  idx->heurRows = 1;
+  if ((rc = uploadHeuristic(idx))) return rc;
+  if ((rc = devAlloc(&idx->d_seq2d, seq.size()))) return rc;
+  HIPCHK(hipMemcpy(idx->d_seq2d, seq.data(), seq.size() * 4, hipMemcpyHostToDevice));
+  idx->seq2dDc = max_cluster;
+  // slope index = number of boundaries 1.2^(j - 4.5), j = 0 .. 8, at or below the slope  (== roundf(log_1.2(slope)) + 5 clamped to [0, 9])
+  for (int j = 0; j < 9; ++j) idx->slopeThr[j] = powf(1.2f, (float)j - 4.5f);
+  idx->heurRows = std::min<uint64_t>(kSeq, nVec);
+  idx->heur2d = true;
+  return PQT_OK;
 }
 
 int pqt_index_set_heuristic(pqt_index* idx, const uint32_t* tuples, uint64_t rows) {
@@ -1137,20 +1192,21 @@ int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, 
 namespace {
 struct SharedWords {
   PqtDevParams dp; pqt_params prm;
-  const void* p[20]; uint64_t u[8]; uint32_t w[8]; float f[2]; int i[10]; bool b[12];
+  const void* p[20]; uint64_t u[8]; uint32_t w[8]; float f[12]; int i[10]; bool b[16];
 };
 void captureShared(const pqt_index* x, SharedWords& v) {
   memset(&v, 0, sizeof(v));
   v.dp = x->dp; v.prm = x->prm;
   const void* ps[] = {x->d_cb1, x->d_cb2, x->d_coarse, x->d_cb1L, x->d_cb2T, x->d_heur, x->d_heur8, x->d_heur4, x->d_table, x->d_lower, x->d_ids,
-                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter, x->d_codesX};
+                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter, x->d_codesX, x->d_seq2d};
   for (size_t j = 0; j < sizeof(ps) / sizeof(ps[0]); ++j) v.p[j] = ps[j];
   v.u[0] = x->heurRows; v.u[1] = x->maxMultiIndex; v.u[2] = x->nIds; v.u[3] = x->nTotal; v.u[4] = x->nCodes; v.u[5] = x->idBase; v.u[6] = x->scratchBudget;
-  v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg;
+  v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc;
   v.f[0] = x->coarseMax;
+  for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
   v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
-                     x->forceUnfused, x->useWgRerank, x->noShape};
+                     x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
 }
 void applyShared(pqt_index* t, const SharedWords& v) {
@@ -1158,14 +1214,15 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->d_cb1 = (float*)v.p[0]; t->d_cb2 = (float*)v.p[1]; t->d_coarse = (float*)v.p[2]; t->d_cb1L = (float*)v.p[3]; t->d_cb2T = (float*)v.p[4];
   t->d_heur = (uint16_t*)v.p[5]; t->d_heur8 = (uint16_t*)v.p[6]; t->d_heur4 = (uint32_t*)v.p[7];
   t->d_table = (PqtBinEntry*)v.p[8]; t->d_lower = (uint32_t*)v.p[9]; t->d_ids = (uint32_t*)v.p[10];
-  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15]; t->d_codesX = (uint32_t*)v.p[16];
+  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15]; t->d_codesX = (uint32_t*)v.p[16]; t->d_seq2d = (uint32_t*)v.p[17];
   t->codesOwned = false;
   t->heurRows = v.u[0]; t->maxMultiIndex = v.u[1]; t->nIds = v.u[2]; t->nTotal = v.u[3]; t->nCodes = v.u[4]; t->idBase = v.u[5]; t->scratchBudget = (size_t)v.u[6];
-  t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3];
+  t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4];
   t->coarseMax = v.f[0];
+  for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
   t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5];
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
-  t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11];
+  t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
 }
 

@@ -67,6 +67,9 @@ struct pqt_index {
   bool haveTree = false;
   // heuristic prefix (a3)
   std::vector<uint32_t> heurHost; uint64_t heurRows = 0; uint16_t* d_heur = nullptr; uint16_t* d_heur8 = nullptr; uint32_t* d_heur4 = nullptr;
+  // optional 2-D anisotropic traversal heuristic (pqt_index_build_heuristic_2d): the 10 cell orders [10][65536], their grid width,
+  // the slope boundaries, and the per-query row tables of the current chunk (scratch of this handle)
+  bool heur2d = false; uint32_t* d_seq2d = nullptr; uint32_t seq2dDc = 0; float slopeThr[9] = {0}; uint4* d_heurQ = nullptr; uint64_t heurQCap = 0;
   uint64_t maxMultiIndex = 0;
   // bin store (a5)
   PqtBinEntry* d_table = nullptr; uint32_t* d_lower = nullptr; uint32_t tableBits = 0;

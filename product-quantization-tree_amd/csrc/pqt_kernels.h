@@ -140,6 +140,85 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_tables(
 #endif  // PQT_MAIN_TU
 
 // ---------------------------------------------------------------------------------------------------
+// Optional traversal heuristic "2-D anisotropic sequences" (SURVEY 8f-4): WHICH rows a query enumerates, the way the CUDA
+// library's 1B path picks them (pqt/PerturbationProTree.cu: computeSlopeIdx :2839-2858, generate2DBins :2888-2910,
+// selectBinKernel2D2Parts :2914-3006, selectBinKernel2DFinal :3012-3100; tables: ProTree::prepare2DDistSequence,
+// pqt/ProTree.cu:50-126).  P = 4.  Parts (0,1) and (2,3) are merged first: with the sorted second-level distances v0, v1 of
+// the two parts (first kMax = min(64, W*C2) entries each) a slope (v1[22]+v1[21]-2 v1[0]) / (v0[22]+v0[21]-2 v0[0]) picks one
+// of 10 precomputed orders of the (x, y) grid (key x^0.8 + s y^0.8), whose first 256 cells -- those with x, y < kMax -- give
+// the pair list, sorted by v0[x] + v1[y].  The two pair lists are merged the same way (slope sampled at 45 / 44): row r of the
+// query is cell r of the chosen order over the 256 x 256 grid of pair-list ranks, i.e. the tuple of four part ranks
+// (pair0[x].x, pair0[x].y, pair1[y].x, pair1[y].y).  Cells that leave the lists, or land on padding, are rows WITHOUT a bin
+// (digit 0 = 0xffff; the CUDA kernel gives them distance 99999999999 and bin 0).
+// Only the SET of enumerated rows changes: pqt_k_bins then forms bin ids and distances from the tuples exactly as for the
+// shared table (cpu_version association and uint32 wrap), orders all rows by (distance, row) and applies the cpu cut -- the
+// CUDA kernel's order inside 1024-row chunks, its 2-vectors-per-bin cap and its stop at k vectors are NOT reproduced.
+// Differences from the CUDA text, on purpose: ties inside a pair list are ordered by cell number (bitonic3 leaves them in
+// network order); the slope index is found by comparing against the 9 boundaries 1.2^(j - 4.5) (computed once on the host)
+// instead of roundf(logf(slope) / logf(1.2)) + 5, so that device and checker agree bit for bit (a NaN / negative slope gives
+// index 0 as the clamped CUDA expression does); sample positions are clamped to the list length.
+// One wavefront per query, 4 per workgroup; rows[q][He] = 8 x u16 digits like the shared table.
+#ifdef PQT_MAIN_TU
+struct PqtRows2dArgs {
+  const float* segD; const uint32_t* seq; uint4* rows;
+  uint32_t dc, WC, kMax, He, nq;
+  float thr[9];
+};
+__global__ __launch_bounds__(256) void pqt_k_rows_2d(const PqtRows2dArgs A) {
+  __shared__ uint32_t sXY[4][2][256];
+  __shared__ float sDist[4][2][256];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * 4 + wave;
+  if (q >= A.nq) return;  // (no workgroup barrier below)
+  const float* sd = A.segD + (size_t)q * 4 * A.WC;
+  auto slopeIdx = [&](const float a1, const float b1, const float c1, const float a0, const float b0, const float c0) -> uint32_t {
+    const float slope = (a1 + b1 - 2.f * c1) / (a0 + b0 - 2.f * c0);
+    uint32_t si = 0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) si += (slope >= A.thr[j]) ? 1u : 0u;
+    return si;
+  };
+  const uint32_t s1 = A.kMax - 1 < 22u ? A.kMax - 1 : 22u, s1m = s1 ? s1 - 1 : 0u;
+  for (uint32_t j = 0; j < 2; ++j) {
+    const float* v0 = sd + (size_t)(2 * j) * A.WC;
+    const float* v1 = v0 + A.WC;
+    const uint32_t si = slopeIdx(v1[s1], v1[s1m], v1[0], v0[s1], v0[s1m], v0[0]);
+    const uint32_t* sq = A.seq + (size_t)si * 65536;
+    uint64_t key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t t = lane * 4 + r;
+      const uint32_t c = sq[t], x = c % A.dc, y = c / A.dc;
+      const bool in = x < A.kMax && y < A.kMax;
+      const float dist = in ? v0[in ? x : 0] + v1[in ? y : 0] : 99999999999.f;
+      key[r] = ((uint64_t)pqt_f2key(dist) << 32) | (t << 16) | (in ? (y << 8 | x) : 0xffffu);
+    }
+    pqt_wave_sort_u64<4>(key);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      sXY[wave][j][lane * 4 + r] = (uint32_t)key[r] & 0xffffu;
+      sDist[wave][j][lane * 4 + r] = pqt_key2f((uint32_t)(key[r] >> 32));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* l0 = sDist[wave][0];
+  const float* l1 = sDist[wave][1];
+  const uint32_t si2 = slopeIdx(l1[45], l1[44], l1[0], l0[45], l0[44], l0[0]);
+  const uint32_t* sq = A.seq + (size_t)si2 * 65536;
+  uint4* out = A.rows + (size_t)q * A.He;
+  for (uint32_t r = lane; r < A.He; r += 64) {
+    const uint32_t c = sq[r], x = c % A.dc, y = c / A.dc;
+    uint4 row = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    if (x < 256 && y < 256) {
+      const uint32_t a = sXY[wave][0][x], b = sXY[wave][1][y];
+      if (a != 0xffffu && b != 0xffffu) row = make_uint4((a & 0xffu) | ((a >> 8) << 16), (b & 0xffu) | ((b >> 8) << 16), 0u, 0u);
+    }
+    out[r] = row;
+  }
+}
+#endif  // PQT_MAIN_TU
+
+// ---------------------------------------------------------------------------------------------------
 // stage a4 + a5 + a6 (staged structure): bin enumeration, probe, exact ordering, cut and candidate gather.
 //   one workgroup per query.
 //   a4  for h < He: dist_h = sum_p segD[p][heur[h][p]] ; glob_h = sum_p segBin[p][..]*powers[p] (uint32 wrap)
@@ -165,10 +244,13 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
     uint32_t* __restrict__ nCand, uint32_t* __restrict__ nLocal, uint32_t* __restrict__ nIncl, uint64_t stride,
     const uint32_t* __restrict__ qlist, const uint32_t* __restrict__ qcount, uint32_t* __restrict__ ovList,
     uint32_t* __restrict__ ovCount, unsigned long long* __restrict__ counters,
-    uint32_t* __restrict__ schedCnt, unsigned long long* __restrict__ schedList, uint32_t schedCap /* rerank schedule 2: see PqtTravArgs */) {
+    uint32_t* __restrict__ schedCnt, unsigned long long* __restrict__ schedList, uint32_t schedCap /* rerank schedule 2: see PqtTravArgs */,
+    uint64_t heurStride /* 0: one table for all queries; otherwise rows per query of a per-query table (pqt_k_rows_2d), whose rows with
+                           digit 0 = 0xffff name no bin */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   if (qlist && blockIdx.x >= *qcount) return;
   const uint32_t q = qlist ? qlist[blockIdx.x] : blockIdx.x;
+  heur += (size_t)q * heurStride * 8;
   const uint32_t P = prm.P, WC = prm.WC;
   constexpr uint32_t RW = SHARDED ? 4 : 2;               // words per record
   uint64_t* sKey = (uint64_t*)smem_raw;                  // capP2
@@ -191,8 +273,11 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const uint32_t h = h0 + u * PQT_BLOCK; hv[u] = reinterpret_cast<const uint4*>(heur)[h < He ? h : h0]; }
     uint32_t glob[4]; float fine[4];
+    bool nobin[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      nobin[u] = (hv[u].x & 0xffffu) == 0xffffu;
+      if (nobin[u]) hv[u] = make_uint4(0u, 0u, 0u, 0u);
       const uint32_t dg[8] = {hv[u].x & 0xffffu, hv[u].x >> 16, hv[u].y & 0xffffu, hv[u].y >> 16, hv[u].z & 0xffffu, hv[u].z >> 16, hv[u].w & 0xffffu, hv[u].w >> 16};
       float f = 0.f; uint32_t g = 0;
 #pragma unroll
@@ -208,7 +293,7 @@ __global__ __launch_bounds__(PQT_BLOCK) void pqt_k_bins(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t h = h0 + u * PQT_BLOCK;
-      if (h < He && e[u].y) {
+      if (h < He && e[u].y && !nobin[u]) {
         const uint32_t ent = atomicAdd(&sMisc[3], 1u);
         if (ent < cap) {
           sRec[ent * RW] = e[u].y; sRec[ent * RW + 1] = e[u].z;

@@ -206,6 +206,14 @@ int pqt_multi_build_heuristic_cuda(pqt_multi* m, uint32_t max_cluster, uint64_t 
   return broadcastHeuristic(m, rows);
 }
 
+int pqt_multi_build_heuristic_2d(pqt_multi* m, uint32_t max_cluster) {
+  if (!m) return mfail(PQT_ERR_INVALID, "null argument");
+  // (the 10 cell orders are cheap to build: every shard builds its own; the per-query rows need the staged traversal, so the
+  // query-sharded traversal marks every query as overflowed and each shard traverses the whole batch itself)
+  for (int s = 0; s < m->n; ++s) MPQT(pqt_index_build_heuristic_2d(m->sh[s], max_cluster));
+  return PQT_OK;
+}
+
 int pqt_multi_set_heuristic(pqt_multi* m, const uint32_t* tuples_host, uint64_t rows) {
   if (!m) return mfail(PQT_ERR_INVALID, "null argument");
   for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_heuristic(m->sh[s], tuples_host, rows));

@@ -7,7 +7,7 @@ int planTraversal(pqt_index* idx, uint32_t He, TravPlan& tp) {
   const PqtDevParams& d = idx->dp;
   int rc;
   // fused traversal (wave per query) when the bin list fits the in-register sorter
-  tp.fused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused;
+  tp.fused = (He <= 4096) && (d.WC <= 256) && !idx->forceUnfused && !idx->heur2d;  // (2-D sequences: per-query row tables, staged kernels)
   tp.wide = tp.fused && He > 512;  // rows enumerated in blocks of 512, populated ones listed (<= 512), overflow -> pqt_k_bins
   const size_t travR0 = (std::max<size_t>(tp.wide ? 2 * 512 * 8 : 512 * 8 + (idx->sharded ? 512 * 4 : 0), 4 * (size_t)(d.LP * d.C1 + d.P * d.WC + d.D)) + 15) & ~(size_t)15;
   tp.perWave = (uint32_t)(travR0 + ((4 * (size_t)(d.P * d.C1 + d.P * d.W + 2 * d.P * d.WC) + 15) & ~(size_t)15));

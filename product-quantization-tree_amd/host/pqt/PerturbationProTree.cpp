@@ -71,6 +71,10 @@ void ProTree::prepareDistSequence(int _maxCluster, int _groupParts) {
   if (pqt_index_build_heuristic_cuda(handle(), (uint32_t)_maxCluster, 65536) != PQT_OK) throw std::runtime_error(pqt_last_error());
 }
 
+void ProTree::prepare2DDistSequence(int _maxCluster) {
+  if (pqt_index_build_heuristic_2d(handle(), (uint32_t)_maxCluster) != PQT_OK) throw std::runtime_error(pqt_last_error());
+}
+
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
     : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_resCnt(nullptr), d_offsets(nullptr), d_packIdx(nullptr), d_packDist(nullptr),
       h_stageIdx(nullptr), h_stageDist(nullptr), h_stageCap(0), h_offsets(nullptr), h_stageCntCap(0), d_copyStream(nullptr), d_evIdx(nullptr), d_evDist(nullptr), d_pool(nullptr),
@@ -180,6 +184,13 @@ void PerturbationProTree::prepareDistSequence(int _maxCluster, int _groupParts) 
   if (_groupParts != (int)d_p) throw std::runtime_error("prepareDistSequence: groupParts must equal p");
   if (d_multi) { if (pqt_multi_build_heuristic_cuda(d_multi, (uint32_t)_maxCluster, 65536) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
   else ProTree::prepareDistSequence(_maxCluster, _groupParts);
+  d_heurRows = 65536;
+}
+
+// the 2-D anisotropic sequences of the 1B path (ProTree.cu:50-126, test/test1B.cpp:941): per-query rows; at most 65536 cells per order
+void PerturbationProTree::prepare2DDistSequence(int _maxCluster) {
+  if (d_multi) { if (pqt_multi_build_heuristic_2d(d_multi, (uint32_t)_maxCluster) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
+  else ProTree::prepare2DDistSequence(_maxCluster);
   d_heurRows = 65536;
 }
 

@@ -64,6 +64,10 @@ class ProTree : public ProQuantization {
   /** the CUDA library's own heuristic with its signature (ProTree.hh:66, ProTree.cu:128-207): sum-of-sqrt order over digits
    *  < min(16, _maxCluster); _groupParts must be p.  Optional mode: changes the enumeration order only. */
   void prepareDistSequence(int _maxCluster, int _groupParts);
+  /** the 1B path's 2-D anisotropic sequences with the reference's signature (ProTree.hh:69, ProTree.cu:50-126; test/test1B.cpp:941
+   *  calls it with 512): 10 orders of the _maxCluster^2 grid; queries then pick their rows through the pairwise merges of
+   *  PerturbationProTree.cu:2914-3100 (pqt_index_build_heuristic_2d).  p = 4.  Optional mode: changes which rows are enumerated. */
+  void prepare2DDistSequence(int _maxCluster);
 
  protected:
   virtual pqt_index* handle() = 0;
@@ -89,6 +93,7 @@ class PerturbationProTree : public ProTree {
   /** shadows ProTree's: with several devices every shard gets the table */
   void prepareDistSequence(uint _rows);
   void prepareDistSequence(int _maxCluster, int _groupParts);
+  void prepare2DDistSequence(int _maxCluster);
   /** W of treequantizer<..,W,..> / k1 of queryKNN (PerturbationProTree.cu:8187); call before reading a tree */
   void setW(uint _w) { d_w = _w; }
   /** query bounds of treequantizer::query(boundVectors, boundBins, ..) (cpu_version/tools/query.cpp:42) */

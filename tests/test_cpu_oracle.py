@@ -281,3 +281,50 @@ def test_committed_dump_pair_reloads_into_the_oracle():
         assert len(ids) == n
         assert np.array_equal(ids, exp["ids"][off:off + n]) and np.array_equal(d.view(np.uint32), exp["dist"][off:off + n].view(np.uint32))
         off += n
+
+
+def test_2d_anisotropic_sequences_tables_and_rows():
+    """The checker's restatement of the CUDA library's 2-D anisotropic sequences (pqt/ProTree.cu:50-126 and
+    pqt/PerturbationProTree.cu:2839-3100), checked against what the CUDA text says on its own terms: every order is the ascending
+    (x^0.8 + s*y^0.8, cell) sequence for its slope (numpy restatement with the same f32 steps), a complete grid is a permutation
+    followed by zeros, a query's rows are tuples of ranks inside the part lists (or "no bin"), the first row is the all-best tuple,
+    and the slope classes equal roundf(log(slope) / log(1.2)) + 5 away from the class boundaries."""
+    f = fixture("wrap")
+    o = f.oracle
+    try:
+        for dc in (64, 512):
+            o.build_heuristic_2d(dc)
+            seq = o.heuristic_2d()
+            n_vec = dc * dc
+            keep = min(n_vec, 65536)
+            i = np.arange(n_vec, dtype=np.int64)
+            x, y = (i % dc).astype(np.float32), (i // dc).astype(np.float32)
+            for slope in range(10):
+                s = np.float32((0.9 * float(np.float32(1.2))) ** (slope - 5))
+                key = (np.power(x, np.float32(0.8)) + s * np.power(y, np.float32(0.8))).astype(np.float32)
+                got = seq[slope, :keep].astype(np.int64)
+                assert len(np.unique(got)) == keep and got.max() < n_vec
+                kg = key[got]
+                # ascending in the key, ties in cell order (libm's powf and numpy's may differ in the last bit: compare the order through
+                # the keys numpy computes, allowing equal-or-adjacent keys to swap)
+                assert np.all(np.diff(kg.astype(np.float64)) >= -np.abs(kg[1:]).astype(np.float64) * 2.0 ** -20)
+                if keep < 65536:
+                    assert not seq[slope, keep:].any()
+            WC = f.cfg["W"] * f.cfg["C2"]
+            for q in f.queries[:6]:
+                rows = o.rows_2d(q, 600)
+                real = rows[rows[:, 0] != 0xffffffff]
+                assert len(real) > 100 and real.max() < min(64, WC)
+                assert tuple(rows[0]) == (0, 0, 0, 0)  # cell 0 of every order is (0, 0) on both levels
+                assert len(np.unique(real, axis=0)) == len(real)  # a tuple is enumerated once
+        # slope classes
+        thr = np.array([np.float32(1.2) ** np.float32(j - 4.5) for j in range(9)], np.float32)
+        rng = np.random.default_rng(5)
+        sl = np.exp(rng.uniform(np.log(0.2), np.log(5.0), 4000)).astype(np.float32)
+        t = np.log(sl.astype(np.float64)) / np.log(1.2)
+        far = np.abs(t - np.floor(t) - 0.5) > 1e-3
+        want = np.clip(np.rint(t) + 5, 0, 9).astype(np.int64)
+        got = (sl[:, None] >= thr[None, :]).sum(1)
+        assert np.array_equal(got[far], want[far])
+    finally:
+        o.set_heuristic(f.heur)

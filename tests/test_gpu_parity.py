@@ -100,7 +100,7 @@ def test_candidates_and_full_sorted_list(pair):
     kfull = 8192  # > 4096 -> full-sort path; larger than any candidate list of these fixtures
     ids, dist, cnt = idx.query(f.queries, Bv, Bb, kfull)
     st = idx.stats()
-    dbg = idx.debug_read(qn)
+    dbg = idx.debug_read(qn, segs=False)  # (the segment lists stay on chip in the fused traversal)
     any_ties = st["ties_l1"] or st["ties_l2"] or st["ties_bins"]
     total = 0
     for qi, q in enumerate(f.queries):
@@ -799,6 +799,48 @@ def test_cuda_style_heuristic_mode(name):
             kk = min(50, len(s_ids))
             assert int(cnt[qi]) == len(s_ids)
             assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])) and np.array_equal(ids[qi, :kk], s_ids[:kk])
+    finally:
+        f.oracle.set_heuristic(f.heur)
+        f.oracle.set_sort_mode(0)
+        idx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dc,knobs", [
+    ("cfg2_small", 512, (800, 500, 50)),    # the grid width test/test1B.cpp:941 passes; 64 entries per part list
+    ("cfg2_small", 64, (300, 1500, 100)),   # complete 64 x 64 orders (4096 cells, zero filled behind), 1500 rows
+    ("cfg3_small", 512, (2000, 400, 100)),  # W = 1, C2 = 64; MODE 2 rerank behind it
+    ("wrap", 512, (500, 300, 64)),          # 32 entries per part list (sample positions inside), aliased bin ids
+])
+def test_2d_anisotropic_sequences_mode(name, dc, knobs):
+    """Optional mode (SURVEY 8f-4 tail): the CUDA 1B path's 2-D anisotropic sequences (pqt/ProTree.cu:50-126) and their per-query use
+    (pqt/PerturbationProTree.cu:2839-3100) as the choice of the enumerated rows -- pqt_index_build_heuristic_2d + pqt_k_rows_2d against the
+    checker's restatement (oracle.build_heuristic_2d): candidate counts, distances and ids of every query; everything behind the rows is
+    cpu_version on both sides.  Switching back to a shared table restores the default results."""
+    f = fixture(name)
+    Bv, Bb, k = knobs
+    idx = f.hip_index()
+    try:
+        base_ids, base_dist, base_cnt = idx.query(f.queries, Bv, min(Bb, f.heur_rows), k)
+        idx.build_heuristic_2d(dc)
+        f.oracle.build_heuristic_2d(dc)
+        f.oracle.set_sort_mode(1)
+        ids, dist, cnt = idx.query(f.queries, Bv, Bb, k)
+        assert "traverse=staged" in idx.last_path()
+        differs = 0
+        for qi, q in enumerate(f.queries):
+            rows = f.oracle.rows_2d(q, Bb)
+            real = rows[rows[:, 0] != 0xffffffff]
+            assert len(real) > 0 and int(real.max()) < f.cfg["W"] * f.cfg["C2"]
+            s_ids, s_d = f.oracle.query(q, Bv, Bb)
+            kk = min(k, len(s_ids))
+            assert int(cnt[qi]) == len(s_ids), "candidate count differs q=%d: %d vs %d" % (qi, int(cnt[qi]), len(s_ids))
+            assert np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])) and np.array_equal(ids[qi, :kk], s_ids[:kk]), "results differ q=%d" % qi
+            differs += int(cnt[qi]) != int(base_cnt[qi])
+        assert differs > 0  # (the mode does change what is enumerated)
+        idx.set_heuristic(f.heur)
+        ids2, dist2, cnt2 = idx.query(f.queries, Bv, min(Bb, f.heur_rows), k)
+        assert np.array_equal(ids2, base_ids) and np.array_equal(bits(dist2), bits(base_dist)) and np.array_equal(cnt2, base_cnt)
     finally:
         f.oracle.set_heuristic(f.heur)
         f.oracle.set_sort_mode(0)
