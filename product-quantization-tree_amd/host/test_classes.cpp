@@ -84,6 +84,25 @@ int main(int argc, char** argv) {
       try { (void)tm.getDBIdx(); } catch (const std::runtime_error&) { refused = true; }
       if (!refused) throw std::runtime_error("getDBIdx with several devices did not refuse");
       std::cout << "multi ok " << tm.getNDevices() << std::endl;
+      // p = 4: the 1B path's 2-D anisotropic sequences with the reference's call (test/test1B.cpp:941 prepare2DDistSequence(512)) on both
+      // objects: identical results, written to <out>.2d for the caller's comparison with the checker; the default table is set again after
+      if (p == 4) {
+        t.prepare2DDistSequence(512);
+        tm.prepare2DDistSequence(512);
+        float* qd3 = nullptr;
+        if (hipMalloc((void**)&qd3, q.size() * 4) != hipSuccess || hipMemcpy(qd3, q.data(), q.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+          throw std::runtime_error("upload failed");
+        std::vector<uint> ai, bi; std::vector<float> ad, bd2;
+        t.queryKNN(ai, ad, qd3, nq, 16);
+        tm.queryKNN(bi, bd2, qd3, nq, 16);
+        (void)hipFree(qd3);
+        if (ai != bi || memcmp(ad.data(), bd2.data(), ad.size() * 4) != 0) throw std::runtime_error("two-shard queryKNN differs under the 2-D sequences");
+        std::ofstream f2((out + ".2d").c_str(), std::ios::binary);
+        f2.write((const char*)ai.data(), ai.size() * 4);
+        f2.write((const char*)ad.data(), ad.size() * 4);
+        t.prepareDistSequence((uint)bb);
+        std::cout << "2d ok" << std::endl;
+      }
     }
     // optional: <base.raw f32> <n> <hashsize> -- the device-pointer overloads and the reference's device getters
     if (argc >= 15) {

@@ -152,6 +152,37 @@ def test_class_surface_loadtree_loadbins_query(tmp_path):
         assert np.array_equal(ri[i, :kk], tops[i][0]) and np.array_equal(rd[i, :kk], tops[i][1].view(np.uint32))
 
 
+def test_class_prepare2DDistSequence_single_and_two_shards(tmp_path):
+    """The class method with the reference's signature (ProTree.hh:69; test/test1B.cpp:941 calls prepare2DDistSequence(512)) on a p = 4
+    index: queryKNN under the 2-D anisotropic sequences equals the checker's restatement, and one object over two range shards returns the
+    same bytes as the single-device object (test_classes compares them itself)."""
+    if not os.path.exists(os.path.join(HOST, "test_classes")):
+        subprocess.check_call(["make", "-C", HOST])
+    f = fixture("cfg2_small")
+    c = f.cfg
+    os.chdir(tmp_path)
+    f.oracle.save_tree("o.tree")
+    f.oracle.save_bins("o.bins")
+    nq, bv, bb = 10, 800, 500
+    f.queries[:nq].astype(np.float32).tofile("q.raw")
+    out = subprocess.run([os.path.join(HOST, "test_classes"), str(c["D"]), str(c["P"]), str(c["LP"]), str(c["W"]), "o.tree", "o.bins",
+                          "q.raw", str(nq), str(bv), str(bb), "res.bin"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "2d ok" in out.stdout and "multi ok 2" in out.stdout
+    raw = np.fromfile("res.bin.2d", np.uint32)
+    ri, rd = raw[:nq * 16].reshape(nq, 16), raw[nq * 16:].reshape(nq, 16)
+    f.oracle.build_heuristic_2d(512)
+    f.oracle.set_sort_mode(1)
+    try:
+        for i in range(nq):
+            ids, d = f.oracle.query(f.queries[i], bv, bb)
+            kk = min(16, len(ids))
+            assert kk > 0 and np.array_equal(ri[i, :kk], ids[:kk]) and np.array_equal(rd[i, :kk], d[:kk].view(np.uint32))
+    finally:
+        f.oracle.set_heuristic(f.heur)
+        f.oracle.set_sort_mode(0)
+
+
 def test_committed_dump_pair_loads_and_reproduces_expected_lists(tmp_path):
     """tests/golden/dump_small.{tree,bins}: an index dump pair in the reference's on-disk formats (written by the oracle's
     saveTree/saveBins; a pair written by a real reference build can be dropped in at the same paths).  Loaded through the
