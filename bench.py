@@ -1031,6 +1031,14 @@ def main():
             idx.set_option("fused", 1)
             leg["launch_structure"] = "staged kernels (tables, bins, rerank -> candDist in HBM, select)"
             out["config"]["knobs_4096_4096_k4096_staged"] = leg
+            if w["P"] == 4:
+                # optional mode: the CUDA 1B path's 2-D anisotropic sequences choose the enumerated rows (per-query row tables:
+                # the traversal runs as staged kernels, the rerank is the headline's), at the headline knobs
+                idx.build_heuristic_2d(512)
+                leg, _, _ = side_leg(args.bv, args.bb, k)
+                leg["launch_structure"] = "staged traversal: tables, per-query rows (pqt_k_rows_2d), bins; fused rerank/select"
+                out["config"]["heuristic_2d_512"] = leg
+                idx.build_heuristic(4096)
             idx.query_dev(queries, args.bv, args.bb, k, out_idx, out_dist, out_cnt, stream=stream)  # restore the headline outputs
             torch.cuda.synchronize(dev)
         except Exception as e:
