@@ -355,7 +355,9 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms);
  * Two more modes check the cross-lane primitives themselves (n is ignored): 6 = the lane exchanges of the sorting networks,
  * out_host[i * 64 + lane] = 0x9e3779b9 * (partner + 1) with partner = lane ^ (1 << i), i = 0..5 (DPP moves, gfx950 row / half swaps), i = 6: partner = lane + 1 (63: itself),
  * i = 7: the 64 keys (0x9e3779b9 * (lane + 1)) | 1 sorted by the u32 network;
- * 7 = inclusive wave scan of v(lane) = (lane * 2654435761 mod 2^32) >> 24 in out_host[0..63] (out_host must hold 513 words). */
+ * 7 = inclusive wave scan of v(lane) = (lane * 2654435761 mod 2^32) >> 24 in out_host[0..63] (out_host must hold 513 words);
+ * 8 = the four-lists-at-once row network of the traversal's part sorts (pqt_row_sort64_u32): out_host[64 p + e] = e-th smallest of the 64
+ * keys (0x9e3779b9 * (64 p + j + 1)) | 1, j = 0..63, for each of the four 16-lane rows p. */
 int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host);
 int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* Which kernels the last pqt_query* call launched, as text (tests assert the path taken, not only the result):

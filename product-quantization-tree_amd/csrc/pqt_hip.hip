@@ -1610,9 +1610,10 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms) {
 }
 
 int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host) {
-  if (!out_host || mode > 7) return fail(PQT_ERR_INVALID, "mode 0..7, out_host[n + 1]");
+  if (!out_host || mode > 8) return fail(PQT_ERR_INVALID, "mode 0..8, out_host[n + 1]");
   if (mode == 6) n = 512;  // six exchanges, the lane + 1 move and a 64-key u32 sort x 64 lanes
   if (mode == 7) n = 64;
+  if (mode == 8) n = 256;  // four 64-key row sorts
   const bool p2 = (n >= 64 && (n & (n - 1)) == 0) || mode == 6;
   if (!p2 || n > 8192 || (mode == 0 && n > 2048) || (mode == 2 && n != 512 && n != 1024) || (mode == 5 && n < 256))
     return fail(PQT_ERR_INVALID, "n: a power of two, 64..8192 (wave sort <= 2048, wave select 512 | 1024, block scan >= 256)");

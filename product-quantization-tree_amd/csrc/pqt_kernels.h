@@ -2118,7 +2118,51 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
   __builtin_amdgcn_wave_barrier();
   PQT_TS(3);
   ties = 0;
+  bool rowSorted = false;
+#ifndef PQT_NO_ROW_SORT
+  if constexpr (SHAPE != 0) {
+    // compile-time shapes (P = 4 lists of W*C2 = 64 entries): the four part lists are sorted TOGETHER, list p by the 16-lane row p of the
+    // wavefront with 4 entries per lane (pqt_row_sort64_u32: 178 instructions for all four, the one-entry-per-lane network below takes 161
+    // per list), on the same 32-bit keys -- distance key with its low 6 bits replaced by the entry's position.  That order is the exact
+    // (distance, position) order unless two NEIGHBOURS of a sorted list agree in the upper 26 bits of their distance keys (two second-level
+    // distances within 2^-17 of each other, relatively); a query where that happens anywhere takes the path below, which settles such
+    // pairs exactly.  Lists enter and leave in 16-byte LDS accesses: entry e of list p sits at word 64 p + e = 4 lane + r.
+    static_assert(SHAPE == 0 || (PqtShape<SHAPE>::P == 4 && PqtShape<SHAPE>::W * PqtShape<SHAPE>::C2 == 64), "row sort: 4 lists of 64");
+    const uint32_t pr = lane >> 4, l16 = lane & 15u;
+    const float4 dv = reinterpret_cast<const float4*>(sD2)[lane];
+    uint32_t k[4] = {(pqt_f2key(dv.x) & ~63u) | (4u * l16), (pqt_f2key(dv.y) & ~63u) | (4u * l16 + 1u),
+                     (pqt_f2key(dv.z) & ~63u) | (4u * l16 + 2u), (pqt_f2key(dv.w) & ~63u) | (4u * l16 + 3u)};
+    pqt_row_sort64_u32(k);
+    // neighbours with equal upper 26 bits (the successor of a lane's last entry is the next lane's first; the last lane of a row has none)
+    const uint32_t nx0 = pqt_lane_down1_u32(k[0]);
+    const bool close = ((k[0] ^ k[1]) < 64u) || ((k[1] ^ k[2]) < 64u) || ((k[2] ^ k[3]) < 64u) || (l16 != 15u && (k[3] ^ nx0) < 64u);
+    if (__builtin_expect(__ballot(close) == 0ull, 1)) {
+      rowSorted = true;
+      const float* dRow = sD2 + 64u * pr;
+      const uint32_t pos[4] = {k[0] & 63u, k[1] & 63u, k[2] & 63u, k[3] & 63u};
+      const float4 dOut = make_float4(dRow[pos[0]], dRow[pos[1]], dRow[pos[2]], dRow[pos[3]]);
+      // bin part of an entry = (cell * C2 + second-level index) * (C1 C2)^p in uint32 wrap-around arithmetic; (C1 C2)^p is a power of two
+      // here, or 0 once p * log2(C1 C2) reaches 32
+      constexpr uint32_t shCC = (uint32_t)__builtin_ctz(SH::C1 * SH::C2);
+      const uint32_t sh = pr * shCC, shMask = sh < 32u ? 0xffffffffu : 0u;
+      uint32_t cellC2[2];
+      cellC2[0] = sOrd[pr * SH::W] * SH::C2;
+      cellC2[1] = SH::W > 1 ? sOrd[pr * SH::W + (SH::W > 1 ? 1u : 0u)] * SH::C2 : 0u;
+      uint32_t part[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[r] = (SH::W > 1 && (pos[r] >> shC2) ? cellC2[1] : cellC2[0]) + (pos[r] & (SH::C2 - 1u));
+      reinterpret_cast<float4*>(sSegD)[lane] = dOut;
+      reinterpret_cast<uint4*>(sSegB)[lane] = make_uint4((part[0] << (sh & 31u)) & shMask, (part[1] << (sh & 31u)) & shMask,
+                                                         (part[2] << (sh & 31u)) & shMask, (part[3] << (sh & 31u)) & shMask);
+      if (He > 512) {  // wide enumeration: keep the lists for the overflow hand-over to pqt_k_bins
+        reinterpret_cast<float4*>(segDOut + (size_t)q * (SH::P * 64u))[lane] = dOut;
+        reinterpret_cast<uint4*>(segBOut + (size_t)q * (SH::P * 64u))[lane] = make_uint4(part[0], part[1], part[2], part[3]);
+      }
+    }
+  }
+#endif
   constexpr int PM = (4 / WCR) < 1 ? 1 : (4 / WCR);  // parts sorted together (register budget: PM * WCR keys)
+  if (!rowSorted)
   for (uint32_t p0 = 0; p0 < P; p0 += PM) {
     // several parts at once: their sorting networks are independent dependency chains the scheduler interleaves
     uint64_t key[PM][WCR];
@@ -3906,6 +3950,15 @@ __global__ __launch_bounds__(256) void pqt_k_debug_sortscan(uint32_t mode, uint3
     out[3 * 64 + tid] = pqt_lane_xor_u32<8>(v); out[4 * 64 + tid] = pqt_lane_xor_u32<16>(v); out[5 * 64 + tid] = pqt_lane_xor_u32<32>(v);
     out[6 * 64 + tid] = pqt_lane_down1_u32(v);  // value of lane + 1 (lane 63: its own)
     { uint32_t t[1] = {(0x9e3779b9u * (tid + 1u)) | 1u}; pqt_wave_sort_u32<1>(t); out[7 * 64 + tid] = t[0]; }  // the u32 network on 64 distinct keys
+  } else if (mode == 8) {
+    // four 64-key row sorts in one pass (pqt_row_sort64_u32): row p sorts the distinct keys hash(64 p + e) | 1, e = 4 (lane & 15) + r
+    if (tid >= 64) return;
+    uint32_t k[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) k[r] = (0x9e3779b9u * (4u * tid + (uint32_t)r + 1u)) | 1u;
+    pqt_row_sort64_u32(k);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[4 * tid + r] = k[r];
   } else if (mode == 7) {
     // inclusive wave scan of irregular values (v = (lane * 2654435761) >> 24), first wavefront
     if (tid >= 64) return;

@@ -280,3 +280,59 @@ template <int R>
 __device__ __forceinline__ void pqt_wave_sort_u32(uint32_t (&key)[R]) {
   pqt_sort_level32<R, 2>(key, (int)(threadIdx.x & 63));
 }
+
+// ---- FOUR independent 64-key sorts in one pass, one per 16-lane row: unique u32 keys, 4 per lane, blocked layout (element e of a row's
+// list = (lane & 15) * 4 + r); on return lane l of a row holds its sorted elements [4 l, 4 l + 4).  The network is the bitonic sorter in
+// its direction-free form -- the first stage of every merge level compares element i with its MIRROR in the block (i ^ (K - 1)), all
+// later stages i with i ^ J, and the smaller key always goes to the smaller index -- so the 11 stages whose partner lives in the same lane
+// are a plain v_min / v_max pair per compare-exchange, and the 10 cross-lane stages are one DPP-fused v_min, one DPP-fused v_max and one
+// select per key: lane ^ 1, ^ 2, ^ 3 are quad permutes, the mirrors of 8 and 16 lanes are row_half_mirror / row_mirror, lane ^ 4 is the
+// one exchange that takes two moves.  178 instructions for the four sorts together (four passes of the 64-key one-key-per-lane network
+// above: 644), and the lists enter and leave as 16-byte LDS accesses.
+template <int CTRL>
+__device__ __forceinline__ uint32_t pqt_dpp_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ void pqt_cx_u32(uint32_t& a, uint32_t& b) {
+  const uint32_t mn = a < b ? a : b, mx = a < b ? b : a;
+  a = mn; b = mx;
+}
+// compare-exchange with the lane named by the DPP control CTRL; MIRROR: the partner's registers in reverse order (a mirror stage);
+// low = this lane holds the smaller index of every pair
+template <int CTRL, bool MIRROR>
+__device__ __forceinline__ void pqt_row_stage_u32(uint32_t (&k)[4], const bool low) {
+  uint32_t o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = pqt_dpp_u32<CTRL>(k[MIRROR ? 3 - r : r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint32_t mn = k[r] < o[r] ? k[r] : o[r], mx = k[r] < o[r] ? o[r] : k[r];
+    k[r] = low ? mn : mx;
+  }
+}
+__device__ __forceinline__ void pqt_row_sort64_u32(uint32_t (&k)[4]) {
+  const uint32_t l = threadIdx.x & 15u;
+  const bool low1 = !(l & 1u), low2 = !(l & 2u), low4 = !(l & 4u), low8 = !(l & 8u);
+  constexpr int X1 = 0xB1 /* quad_perm [1,0,3,2] */, X2 = 0x4E /* [2,3,0,1] */, X3 = 0x1B /* [3,2,1,0] */, X7 = 0x141 /* row_half_mirror */,
+                X15 = 0x140 /* row_mirror */;
+#define PQT_ROW_TAIL() do { pqt_cx_u32(k[0], k[2]); pqt_cx_u32(k[1], k[3]); pqt_cx_u32(k[0], k[1]); pqt_cx_u32(k[2], k[3]); } while (0)
+  pqt_cx_u32(k[0], k[1]); pqt_cx_u32(k[2], k[3]);                                                                  // K = 2
+  pqt_cx_u32(k[0], k[3]); pqt_cx_u32(k[1], k[2]); pqt_cx_u32(k[0], k[1]); pqt_cx_u32(k[2], k[3]);                  // K = 4
+  pqt_row_stage_u32<X1, true>(k, low1); PQT_ROW_TAIL();                                                            // K = 8
+  pqt_row_stage_u32<X3, true>(k, low2); pqt_row_stage_u32<X1, false>(k, low1); PQT_ROW_TAIL();                     // K = 16
+  pqt_row_stage_u32<X7, true>(k, low4); pqt_row_stage_u32<X2, false>(k, low2); pqt_row_stage_u32<X1, false>(k, low1); PQT_ROW_TAIL();  // K = 32
+  pqt_row_stage_u32<X15, true>(k, low8);                                                                           // K = 64
+  {
+    uint32_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t dn = pqt_dpp_u32<0x114>(k[r]);                                                    // row_shr:4  lane i <- i - 4
+      o[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)dn, (int)k[r], 0x104, 0xf, 0x5, false);        // row_shl:4 into lanes 0-3, 8-11: i <- i + 4
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t mn = k[r] < o[r] ? k[r] : o[r], mx = k[r] < o[r] ? o[r] : k[r];
+      k[r] = low4 ? mn : mx;
+    }
+  }
+  pqt_row_stage_u32<X2, false>(k, low2); pqt_row_stage_u32<X1, false>(k, low1); PQT_ROW_TAIL();
+#undef PQT_ROW_TAIL
+}

@@ -1504,6 +1504,10 @@ def test_cross_lane_primitives_exchange_and_scan():
     assert np.array_equal(got[7 * 64:8 * 64], np.sort(vals | np.uint32(1))), "pqt_wave_sort_u32"
     v = ((lane * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(24)
     assert np.array_equal(pkg.debug_sort_scan(7, 64)[:64], np.cumsum(v).astype(np.uint32))
+    # the traversal's part sorts: four 64-key lists sorted at once, one per 16-lane row, 4 keys per lane
+    e = np.arange(256, dtype=np.uint64)
+    keys = (((np.uint64(0x9e3779b9) * (e + np.uint64(1))) & np.uint64(0xffffffff)).astype(np.uint32) | np.uint32(1)).reshape(4, 64)
+    assert np.array_equal(pkg.debug_sort_scan(8, 256)[:256].reshape(4, 64), np.sort(keys, axis=1)), "pqt_row_sort64_u32"
 
 
 @pytest.mark.parametrize("name", ["cfg2_small", "cfg2_dense", "ties", "wrap"])
