@@ -438,18 +438,33 @@ def build_workload(ctx, args, wl_name, mode, want_gt=True, codebooks=None):
                 chunked=w.get("chunk", n) < n, mode=mode, qn=qn)
 
 
-def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fresh=False):
+def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fresh=False, single_pipeline=False):
     """W warm-up steps, then exactly `steps` timed steps of the hot path between barriers (+ device synchronisation); the
     per-kernel HIP events ride on every period-th call.  Returns the timing, the stage means and the outputs.
     Range-sharded mode: pipeline = 2 (default, --pipeline) runs every step as two half batches in flight (sharding.py:
     sharded_query_pipelined -- half B's kernels under half A's collectives), 1 as one batch; the collectives of the event-carrying
-    steps are bracketed by HIP events (exchange_ms)."""
+    steps are bracketed by HIP events (exchange_ms).
+    One GPU (single / replica), single_pipeline=True and --pipeline >= 2: two WHOLE batches in flight as well -- consecutive steps
+    alternate between the index and a view of it (pqt_index_create_view: own scratch, same loaded index), each on its own stream with
+    its own result arrays, so one batch's traversal runs under the other batch's rerank (the two launches of a batch depend on each
+    other; the launches of different batches do not).  Every step is still one complete batch; all of them are complete at the closing
+    barrier."""
     idx, queries, qn, dev, mode = W["idx"], W["queries"], W["qn"], ctx.dev, W["mode"]
     out_idx = torch.empty((qn, k), dtype=torch.int32, device=dev)
     out_dist = torch.empty((qn, k), dtype=torch.float32, device=dev)
     out_cnt = torch.empty(qn, dtype=torch.int32, device=dev)
     sbuf = engine = timer = view = None
-    pipeline = (args.pipeline if pipeline is None else pipeline) if (mode == "shard_db" and qn >= 2) else 1
+    two_single = bool(single_pipeline and mode != "shard_db" and (args.pipeline if pipeline is None else pipeline) >= 2)
+    pipeline = (args.pipeline if pipeline is None else pipeline) if (mode == "shard_db" and qn >= 2) else (2 if two_single else 1)
+    slots = None
+    if two_single:
+        if "view" not in W:
+            W["view"] = idx.view()
+        view = W["view"]
+        if "slot_stream" not in W:
+            W["slot_stream"] = torch.cuda.Stream(dev)
+        slots = [(idx, ctx.stream, (out_idx, out_dist, out_cnt)),
+                 (view, W["slot_stream"].cuda_stream, (torch.empty_like(out_idx), torch.empty_like(out_dist), torch.empty_like(out_cnt)))]
     if mode == "shard_db":
         timer = ctx.sharding.ExchangeTimer(cuda=True)
         engine = ctx.sharding.PqtShardEngine(idx)
@@ -477,6 +492,11 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fre
     def step():
         if mode != "shard_db":
             qq = queries if qlist is None else qlist[calls[0] % len(qlist)]
+            if slots is not None:
+                h_, s_, o_ = slots[calls[0] & 1]
+                calls[0] += 1
+                h_.query_dev(qq, bv, bb, k, o_[0], o_[1], o_[2], stream=s_)
+                return
             calls[0] += 1
             idx.query_dev(qq, bv, bb, k, out_idx, out_dist, out_cnt, stream=ctx.stream)
             return
@@ -497,6 +517,8 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fre
     timed_in_region = [i for i in range(steps) if (warmup + i) % period == 0]
     if not timed_in_region:
         period, timed_in_region = 1, list(range(steps))
+    # (two batches in flight on one device: each handle sees every other step and carries the events on every period-th of ITS calls, so
+    # one step in `period` carries them as before)
     idx.set_option("stage_timing", period)
     if view is not None:
         view.set_option("stage_timing", period)
@@ -519,7 +541,17 @@ def time_path(ctx, args, W, bv, bb, k, steps, warmup, period, pipeline=None, fre
     st = idx.stats()
     stage = dict(zip(STAGES, hist.mean(0).tolist())) if hist.shape[0] else dict.fromkeys(STAGES, 0.0)
     path = idx.last_path()
-    if view is not None:
+    if two_single:
+        # both slots answered the same batch (or, with fresh batches, their own): the view's kernels count like the index's
+        nh_ = max(1, min(len(timed_in_region) // 2, 32))
+        hist = idx.stage_ms_history(nh_)
+        h2 = view.stage_ms_history(nh_)
+        if h2.shape[0] and hist.shape[0]:
+            both = np.concatenate([hist, h2], 0)
+            stage = dict(zip(STAGES, both.mean(0).tolist()))
+        path += " | two batches in flight on one device (index + view, two streams)"
+        view.set_option("stage_timing", 0)
+    elif view is not None:
         if pipeline >= 3:
             # two half batches: a kernel's time per step is the sum over the halves (they overlap in time); statistics likewise
             h2 = view.stage_ms_history(min(len(timed_in_region), 32))
@@ -574,7 +606,7 @@ def live_traffic(args, wl_name, bv, bb, k, kernel, fetch_factor):
     opts = list(args.option)
     if not any(o.startswith("overlap=") for o in opts):
         opts.append("overlap=0")  # every call in one piece: all dispatches of the kernel are full-size launches
-    child = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-gt", "--no-hbm-leg", "--no-live-traffic", "--steps", "3", "--warmup", "2",
+    child = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-gt", "--no-hbm-leg", "--no-live-traffic", "--pipeline", "1", "--steps", "3", "--warmup", "2",
              "--workload", wl_name, "--bv", str(bv), "--bb", str(bb), "--k", str(k), "--iso-noise", str(args.iso_noise), "--lat-noise", str(args.lat_noise),
              "--centers", str(args.centers), "--center-scale", str(args.center_scale), "--query-mode", args.query_mode]
     for o in opts:
@@ -729,13 +761,18 @@ def make_line(ctx, args, W, R):
                    # range-sharded run: mean device time of each collective of a step (HIP events on the issuing stream around the call, on the
                    # steps that also carry the per-kernel events; with two half batches in flight: per half-batch call), this rank and all ranks
                    "pipeline": {1: "one batch at a time", 2: "two whole batches in flight (consecutive steps alternate between the index and a view of it on two streams: one batch's collectives pass under the other's kernels)",
-                                3: "two half batches in flight (half B's kernels run under half A's collectives)"}[R["pipeline"]] if mode == "shard_db" else None,
+                                3: "two half batches in flight (half B's kernels run under half A's collectives)"}[R["pipeline"]] if mode == "shard_db" else
+                               {1: "one batch at a time on one stream",
+                                2: "two whole batches in flight (consecutive steps alternate between the index and a view of it on two streams: one batch's traversal "
+                                   "runs under the other batch's rerank; every step is one complete batch, all complete at the closing barrier; "
+                                   "config.one_batch_at_a_time = the same steps issued one after the other)"}[R["pipeline"]],
                    "exchange_ms": R["exchange_ms"],
                    "per_rank_stage_ms": R["per_rank"],
                    "collective_backend": ({"nccl": "rccl"}.get(ctx.backend, ctx.backend) if ctx.collectives else None), "collective_world_size": world,
                    "options": args.option,
-                   "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call; the events cost ~10 us per call)"
-                                    % (R["n_timed"], R["steps"], {1: "", 2: "2nd"}.get(R["period"], "%dth" % R["period"])),
+                   "kernel_timing": "per-kernel start/stop HIP events on %d of the %d timed steps (every %s call%s; the events cost ~10 us per call)"
+                                    % (R["n_timed"], R["steps"], {1: "", 2: "2nd"}.get(R["period"], "%dth" % R["period"]),
+                                       " of each of the two handles" if (mode != "shard_db" and R["pipeline"] == 2) else ""),
                    "kernel_path": R["path"],
                    "global_batch": R["units"],
                    "recall@1": r1, "recall@10": r10, "recall@100": r100, "mean_candidates": ncand_mean,
@@ -894,7 +931,7 @@ def main():
     ap.add_argument("--traversal", default=None, choices=["sharded", "replicated"],
                     help="range-sharded run: traversal sharded by queries with one all-gather of the per-query bin lists (default) or replicated on every rank")
     ap.add_argument("--pipeline", type=int, default=2, choices=[1, 2, 3],
-                    help="range-sharded run: 2 = two whole batches in flight (consecutive steps alternate between two streams / handles: the collectives of one "
+                    help="2 (default) = two whole batches in flight -- on ONE GPU as well: consecutive steps alternate between the index and a view of it on two streams, the line carries the one-batch-at-a-time figures as config.one_batch_at_a_time; range-sharded run: 2 = two whole batches in flight (consecutive steps alternate between two streams / handles: the collectives of one "
                          "batch pass under the kernels of the other), 1 = one batch at a time, 3 = every step split into two half batches in flight; the line "
                          "carries the one-batch-at-a-time step time as config.pipeline_ab (or the two-batches figure when run with --pipeline 1)")
     ap.add_argument("--no-ref1", action="store_true", help="range-sharded run: skip the single-GPU timing of the same database on rank 0")
@@ -931,9 +968,11 @@ def main():
     wl_name = args.workload or ("sift1m" if mode != "shard_db" else head_wl)
     W = build_workload(ctx, args, wl_name, mode)
     w, n, qn, idx, meta, queries, k = W["w"], W["n"], W["qn"], W["idx"], W["meta"], W["queries"], args.k
-    R = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period)
+    R = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period, single_pipeline=mode != "shard_db")
     out_idx, out_dist, out_cnt, gt, stream = R["out_idx"], R["out_dist"], R["out_cnt"], W["gt"], ctx.stream
     st = R["st"]
+    if os.environ.get("PQT_PRINT_STATS"):  # per-stage tie counters and totals of the last batch (development aid)
+        log("[stats]", {k_: int(v_) for k_, v_ in st.items() if isinstance(v_, (int, np.integer))})
     if os.environ.get("PQT_TSTAMP"):
         import ctypes
         ts = np.zeros((qn, 24), np.uint64)
@@ -965,6 +1004,23 @@ def main():
         barrier(ctx)
 
     out = make_line(ctx, args, W, R)
+
+    # ---- one device, two batches in flight: the same steps one batch at a time on one stream (each kernel alone on the device: the
+    # per-kernel durations and roofline fractions without the overlap), beside the line's own figures
+    if mode != "shard_db" and R["pipeline"] == 2:
+        try:
+            R1 = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, min(args.warmup, 3), args.timing_period, pipeline=1)
+            roof1, _ = roofline_block(ctx, args, W, R1, live=False)
+            out["config"]["one_batch_at_a_time"] = {
+                "queries_per_sec": R1["qps"], "ms_per_step": R1["ms_per_step"], "stage_ms": R1["stage"],
+                "results_identical": bool(torch.equal(R1["out_idx"], out_idx) and torch.equal(R1["out_dist"], out_dist) and torch.equal(R1["out_cnt"], out_cnt)),
+                "what": "the %d timed steps issued one batch at a time on one stream (the form of `value` up to round 3 and of --pipeline 1)" % R1["steps"]}
+            out["roofline"]["one_batch_at_a_time"] = {"kernel": roof1["kernel"], "avg_launch_ms": roof1["avg_launch_ms"], "achieved": roof1["achieved"],
+                                                      "frac": roof1["frac"], "other_kernels": roof1["other_kernels"]}
+            out["roofline"]["overlap_note"] = ("avg_launch_ms / achieved / frac above are measured over the timed region, where the launches of two batches share the "
+                                               "device (a kernel's own duration stretches while throughput rises); roofline.one_batch_at_a_time = the same kernels alone on the device")
+        except Exception as e:
+            out["config"]["one_batch_at_a_time"] = {"error": repr(e)[:300]}
 
     # optional "next" row 8f-4 (not part of the timed path): exact re-rank of the k results against the raw uint8 vectors
     exact = None

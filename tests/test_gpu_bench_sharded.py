@@ -61,10 +61,12 @@ def test_live_traffic_of_the_dominant_kernel_is_collected_by_the_bench_run_itsel
     untouched by it (collected after the timed region)."""
     env = dict(os.environ, PQT_BENCH_NO_PIPELINE="1")
     env.pop("PQT_BENCH_NO_LIVE_TRAFFIC", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "synth1m", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-hbm-leg"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "synth1m", "--steps", "4", "--warmup", "1", "--no-cpu", "--no-hbm-leg", "--pipeline", "1"],
                          capture_output=True, text=True, cwd=ROOT, timeout=1200, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["pipeline"].startswith("one batch at a time") and "one_batch_at_a_time" not in d["config"]  # --pipeline 1: the line IS that figure
+    r = d["roofline"]
     assert r["traffic_source"].startswith("measured in this run"), r["traffic_source"]
     assert r["traffic"] > 0 and 0.05 < r["traffic_ratio"] < 20, r
 
@@ -77,6 +79,11 @@ def test_default_line_carries_the_hbm_roofline_leg():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["workload_name"] == "sift1m"
+    # default: two whole batches in flight on the one device; the same steps one batch at a time ride along, results identical
+    assert "two whole batches in flight" in d["config"]["pipeline"] and "two batches in flight" in d["config"]["kernel_path"]
+    one = d["config"]["one_batch_at_a_time"]
+    assert "error" not in one and one["results_identical"] is True and one["queries_per_sec"] > 0
+    assert d["roofline"]["one_batch_at_a_time"]["avg_launch_ms"] > 0 and d["roofline"]["one_batch_at_a_time"]["kernel"] == d["roofline"]["kernel"]
     assert d["roofline"]["traffic_source"] is None or "committed profile" in d["roofline"]["traffic_source"]
     assert d["roofline"]["measured_stream_GBps"] > 1000
     leg = d["config"]["hbm_roofline_leg"]
