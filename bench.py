@@ -1007,7 +1007,7 @@ def main():
 
     # ---- one device, two batches in flight: the same steps one batch at a time on one stream (each kernel alone on the device: the
     # per-kernel durations and roofline fractions without the overlap), beside the line's own figures
-    if mode != "shard_db" and R["pipeline"] == 2:
+    if mode != "shard_db" and R["pipeline"] == 2 and not os.environ.get("PQT_BENCH_NO_PIPELINE"):  # (that variable: headline launches only, for kernel statistics)
         try:
             R1 = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, min(args.warmup, 3), args.timing_period, pipeline=1)
             roof1, _ = roofline_block(ctx, args, W, R1, live=False)

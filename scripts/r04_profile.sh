@@ -8,7 +8,9 @@
 tag=$1; ff=$2; wl=$3; bv=$4; bb=$5; k=$6; shift 6
 # overlap=0: every call in one piece, so that the kernel statistics average full-size launches only (the library's default splits an
 # untimed SIFT1M-shape batch into two half-size launches per kernel; bench.py's own per-kernel numbers come from the one-piece timed calls)
-args="--workload $wl --bv $bv --bb $bb --k $k --option overlap=0 $@"
+# --pipeline 1: one batch at a time, every kernel alone on the device (the per-kernel durations behind roofline.one_batch_at_a_time; the
+# default line's two batches in flight are profiled by scripts/r04_profile_inflight.sh)
+args="--workload $wl --bv $bv --bb $bb --k $k --option overlap=0 --pipeline 1 $@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PQT_BENCH_NO_PIPELINE=1   # only the headline launches in the kernel statistics (no half-batch two-stream leg)
 mkdir -p gpurun_out/prof
