@@ -75,7 +75,7 @@ def test_default_line_carries_the_hbm_roofline_leg():
     """`python bench.py` (N = 1): `value` is the SIFT1M-shape number and config.hbm_roofline_leg holds the configs[2] workload at both
     knob sets with the dominant kernel's roofline fraction (here with a small stand-in workload so the test stays short)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu", "--hbm-workload", "synth1m"],
-                         capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, PQT_BENCH_NO_PIPELINE="1"))
+                         capture_output=True, text=True, cwd=ROOT, timeout=900, env={k_: v_ for k_, v_ in os.environ.items() if k_ != "PQT_BENCH_NO_PIPELINE"})
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["workload_name"] == "sift1m"
