@@ -44,7 +44,10 @@ constexpr int kFusedWaves = PQT_RS_NW;
 // k > 128 short-list kernels (pqt_k_rerank_sort_small): wavefronts per workgroup of the first pass (lists <= 1024) and of the second (<= 2048)
 constexpr int kSmallWaves = 12;
 constexpr int kMidWaves = 8;
-constexpr int kXcWaves = 16;
+#ifndef PQT_XC_WAVES
+#define PQT_XC_WAVES 16
+#endif
+constexpr int kXcWaves = PQT_XC_WAVES;
 constexpr int kXcSlots = 384;
 constexpr int kCtrRing = 4;
 constexpr int kPoolRing = 4;  // blocks of 16 draw counters + 8 x 64 registration counts behind the statistics ring (rerank schedule 2)

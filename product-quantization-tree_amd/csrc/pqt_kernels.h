@@ -1560,7 +1560,9 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
           int MODE = 0, bool RUNS = false, bool XC = false /* A.codes = the X-code copy of the store, see pqt_rs_query */,
           int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */>
-__global__ __launch_bounds__(NW * 64) void pqt_k_rerank_select(const PqtRsArgs A) {
+// (the X-code kernel keeps its 128-VGPR budget whatever NW is: with fewer than 16 wavefronts the registers it leaves belong to the other
+// batch's traversal wavefronts when two batches are in flight)
+__global__ __launch_bounds__(NW * 64, XC ? 4 : 1) void pqt_k_rerank_select(const PqtRsArgs A) {
   const float* __restrict__ coarse = A.coarse; const uint32_t* __restrict__ nLocal = A.nLocal; const uint32_t qn = A.qn;
   const PqtDevParams& prm = A.prm; const uint32_t dbg = A.dbg; const uint32_t dynamic = A.dynamic; unsigned long long* __restrict__ zero8 = A.zero8;
   constexpr uint32_t LP = LPV * 4;
