@@ -1015,10 +1015,25 @@ def main():
                 "queries_per_sec": R1["qps"], "ms_per_step": R1["ms_per_step"], "stage_ms": R1["stage"],
                 "results_identical": bool(torch.equal(R1["out_idx"], out_idx) and torch.equal(R1["out_dist"], out_dist) and torch.equal(R1["out_cnt"], out_cnt)),
                 "what": "the %d timed steps issued one batch at a time on one stream (the form of `value` up to round 3 and of --pipeline 1)" % R1["steps"]}
-            out["roofline"]["one_batch_at_a_time"] = {"kernel": roof1["kernel"], "avg_launch_ms": roof1["avg_launch_ms"], "achieved": roof1["achieved"],
-                                                      "frac": roof1["frac"], "other_kernels": roof1["other_kernels"]}
-            out["roofline"]["overlap_note"] = ("avg_launch_ms / achieved / frac above are measured over the timed region, where the launches of two batches share the "
-                                               "device (a kernel's own duration stretches while throughput rises); roofline.one_batch_at_a_time = the same kernels alone on the device")
+            # `roofline` prices the dominant KERNEL: its launch alone on the device (this leg's timed region: the same K steps, same barriers, HIP events on the
+            # launch stream).  Under the two batches in flight of `value` a launch shares the device with the other batch's launch and its own duration
+            # stretches while the device does more per unit of time: those figures stay in the line as roofline.in_flight, and the whole step's rate is
+            # config.path_GBps / path_frac_of_hbm_peak (algorithmic bytes of both launches over ms_per_step of `value`).
+            rf = out["roofline"]
+            in_flight = {"kernel": rf["kernel"], "avg_launch_ms": rf["avg_launch_ms"], "achieved": rf["achieved"], "frac": rf["frac"], "other_kernels": rf["other_kernels"],
+                         "timing": rf["timing"],
+                         "what": "the same launches inside the timed region of `value` (two whole batches in flight: every launch shares the device with the other batch's)"}
+            if roof1["kernel"] == rf["kernel"]:
+                for key_ in ("avg_launch_ms", "achieved", "frac", "other_kernels"):
+                    rf[key_] = roof1[key_]
+                if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
+                    rf["traffic_ratio"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+                rf["timing"] = ("the kernel ALONE on the device: mean of its own duration over the %d of the %d steps of config.one_batch_at_a_time that carry events (the timed steps "
+                                "issued one batch at a time, same barriers; start/stop HIP events attached to the dispatch on the launch stream); "
+                                "roofline.in_flight = the same launches inside the timed region of `value`, where they overlap the other batch's" % (R1["n_timed"], R1["steps"]))
+                rf["in_flight"] = in_flight
+            else:
+                rf["one_batch_at_a_time"] = {"kernel": roof1["kernel"], "avg_launch_ms": roof1["avg_launch_ms"], "achieved": roof1["achieved"], "frac": roof1["frac"]}
         except Exception as e:
             out["config"]["one_batch_at_a_time"] = {"error": repr(e)[:300]}
 
