@@ -1020,20 +1020,25 @@ def main():
             # stretches while the device does more per unit of time: those figures stay in the line as roofline.in_flight, and the whole step's rate is
             # config.path_GBps / path_frac_of_hbm_peak (algorithmic bytes of both launches over ms_per_step of `value`).
             rf = out["roofline"]
-            in_flight = {"kernel": rf["kernel"], "avg_launch_ms": rf["avg_launch_ms"], "achieved": rf["achieved"], "frac": rf["frac"], "other_kernels": rf["other_kernels"],
-                         "timing": rf["timing"],
-                         "what": "the same launches inside the timed region of `value` (two whole batches in flight: every launch shares the device with the other batch's)"}
-            if roof1["kernel"] == rf["kernel"]:
-                for key_ in ("avg_launch_ms", "achieved", "frac", "other_kernels"):
+            # the same kernel's figures inside the timed region of `value` (it may be the other one of the two there)
+            flt = {rf["kernel"]: {"avg_launch_ms": rf["avg_launch_ms"], "achieved": rf["achieved"], "frac": rf["frac"]}}
+            for n_, v_ in rf["other_kernels"].items():
+                flt[n_] = {"avg_launch_ms": v_["avg_launch_ms"], "achieved": v_["GBps"], "frac": v_["frac"]}
+            mine = flt.get(roof1["kernel"], {})
+            in_flight = dict(kernel=roof1["kernel"], **mine, all_kernels=flt, timing=rf["timing"],
+                             what="the same launches inside the timed region of `value` (two whole batches in flight: every launch shares the device with the other batch's)")
+            if roof1["kernel"] != rf["kernel"]:  # (the live counters were collected for the other kernel: the committed profile's figure of this one, if any)
+                for key_ in ("traffic", "traffic_source", "traffic_committed_profile"):
                     rf[key_] = roof1[key_]
-                if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
-                    rf["traffic_ratio"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
-                rf["timing"] = ("the kernel ALONE on the device: mean of its own duration over the %d of the %d steps of config.one_batch_at_a_time that carry events (the timed steps "
-                                "issued one batch at a time, same barriers; start/stop HIP events attached to the dispatch on the launch stream); "
-                                "roofline.in_flight = the same launches inside the timed region of `value`, where they overlap the other batch's" % (R1["n_timed"], R1["steps"]))
-                rf["in_flight"] = in_flight
-            else:
-                rf["one_batch_at_a_time"] = {"kernel": roof1["kernel"], "avg_launch_ms": roof1["avg_launch_ms"], "achieved": roof1["achieved"], "frac": roof1["frac"]}
+            for key_ in ("kernel", "avg_launch_ms", "achieved", "frac", "other_kernels", "algorithmic_bytes_per_launch", "intermediate_bytes"):
+                rf[key_] = roof1[key_]
+            rf["traffic_ratio"] = None
+            if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch"):
+                rf["traffic_ratio"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+            rf["timing"] = ("the kernel ALONE on the device: mean of its own duration over the %d of the %d steps of config.one_batch_at_a_time that carry events (the timed steps "
+                            "issued one batch at a time, same barriers; start/stop HIP events attached to the dispatch on the launch stream); "
+                            "roofline.in_flight = the same launches inside the timed region of `value`, where they overlap the other batch's" % (R1["n_timed"], R1["steps"]))
+            rf["in_flight"] = in_flight
         except Exception as e:
             out["config"]["one_batch_at_a_time"] = {"error": repr(e)[:300]}
 

@@ -85,7 +85,7 @@ def test_default_line_carries_the_hbm_roofline_leg():
     assert "error" not in one and one["results_identical"] is True and one["queries_per_sec"] > 0
     # `roofline` prices the kernel alone on the device (the one-batch-at-a-time steps); the overlapped launches of `value` ride along
     fl = d["roofline"]["in_flight"]
-    assert fl["kernel"] == d["roofline"]["kernel"] and fl["avg_launch_ms"] >= 0.9 * d["roofline"]["avg_launch_ms"] > 0
+    assert fl["kernel"] == d["roofline"]["kernel"] and fl["avg_launch_ms"] > 0 and d["roofline"]["avg_launch_ms"] > 0 and len(fl["all_kernels"]) == 2
     assert d["roofline"]["avg_launch_ms"] in one["stage_ms"].values()
     assert d["roofline"]["traffic_source"] is None or "committed profile" in d["roofline"]["traffic_source"]
     assert d["roofline"]["measured_stream_GBps"] > 1000
