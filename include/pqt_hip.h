@@ -113,6 +113,9 @@ int pqt_index_create_view(pqt_index* owner, pqt_index** out);
  * call (1 = every call, the default; 0 = never); they cost about 5 us per kernel launch.
  * "order_all_rows" = 1 makes the fused traversal order all enumerated rows instead of only the populated ones (the
  * fallback it takes by itself when more than 128 rows are populated); results are identical.
+ * "exact_part_sorts" = 1 sends every query's second-level part lists through the one-list-at-a-time sort that settles near-ties of
+ * the distances exactly (compile-time shapes: normally only a query in whose row-parallel sort two neighbours agree in the upper 26
+ * bits of their distance keys takes it); results are identical (test switch).
  * "debug_bits" = ablation switches of the fused kernels (measurement only: results are WRONG for non-zero values;
  * scripts/ablate*.sh, PQT_DBG).
  * "enumerate_beyond_wrap" = 1: enumerable heuristic rows = the true (W*C2)^P, not the reference's uint32 product (which wraps to 0 at

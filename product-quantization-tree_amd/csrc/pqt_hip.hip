@@ -424,7 +424,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                         idx->d_segD + (size_t)q0 * d.P * d.WC, idx->d_segBin + (size_t)q0 * d.P * d.WC, idx->d_ovList, idx->d_ovCount,
                         (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                         emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
-                        countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 1u,
+                        countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 3u,
                         schedCntArg, idx->d_schedList, idx->curSchedCap, nullptr, nullptr, nullptr, 0u};
       if (binsIn) {
         // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
@@ -796,6 +796,9 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "balance") == 0) { idx->balance = value < 0 ? -1 : (value >= 2 ? 2 : (int)value); return PQT_OK; }  // rerank schedule: -1 automatic, 0 static, 1 workgroup-local, 2 global pools
   if (strcmp(name, "debug_bits") == 0) { idx->dbg = (uint32_t)value; return PQT_OK; }  // ablation switches (PQT_DBG), wrong results
   if (strcmp(name, "order_all_rows") == 0) { idx->dbg = value ? (idx->dbg | 32u) : (idx->dbg & ~32u); return PQT_OK; }
+  // test switch: the traversal's part lists always through the one-list-at-a-time code that settles near-ties of the second-level distances
+  // exactly (compile-time shapes: normally only the queries whose row-parallel sort meets such a pair take it); results unchanged
+  if (strcmp(name, "exact_part_sorts") == 0) { idx->dbg = value ? (idx->dbg | 64u) : (idx->dbg & ~64u); return PQT_OK; }
   // "enumerate_beyond_wrap" = 1: the number of enumerable heuristic rows is the true (W*C2)^P instead of the reference's uint32 product
   // (treequantizer.hpp:40-41), which wraps to 0 at BASELINE configs[4] (64^8 = 2^48) and makes its orderBins enumerate nothing.  NO
   // reference counterpart: a throughput-only mode for that shape, used with a supplied prefix (pqt_index_set_heuristic).  Bin ids keep
@@ -1361,7 +1364,7 @@ int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t 
                             idx->d_candPos, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, 0, idx->d_counters + 8 * kCtrRing /* spare statistics block */, nullptr,
                             idx->d_segD, idx->d_segBin, idx->d_ovList, idx->d_ovCount,
                             (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
-                            nullptr, nullptr, nullptr, 0u, nullptr, (idx->dbg >> 5) & 1u,
+                            nullptr, nullptr, nullptr, 0u, nullptr, (idx->dbg >> 5) & 3u,
                             nullptr, nullptr, 0u, nullptr, nullptr, out_bins_dev, cap};
     launchFusedTraversal(idx, targs, tp, qn, st, nullptr, nullptr);
   }

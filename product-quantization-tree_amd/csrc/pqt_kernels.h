@@ -1848,7 +1848,7 @@ struct PqtTravArgs {
   unsigned long long* runs; uint32_t* runGpos; uint32_t* nRuns;  // bin runs for the rerank (see PqtRsArgs), or null
   uint32_t runCap;  // at most this many runs are handed over (more: the plain candidate list is written)
   uint32_t* outCount;  // the caller's per-query candidate count, written here directly (saves a copy on the stream), or null
-  uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones
+  uint32_t tdbg;  // test bits: 1 = order all rows, not just the populated ones; 2 = part lists by the one-list-at-a-time code (option exact_part_sorts)
   // rerank schedule 2: the query registers itself in the list of (XCD pool q % 8, size class of its local candidate count):
   // schedCnt[pool * 64 + class] entries so far, schedList[(pool * 64 + class) * schedCap + i] = i-th query; or null
   uint32_t* schedCnt; unsigned long long* schedList /* query | local candidates << 32 */; uint32_t schedCap;
@@ -2138,7 +2138,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
     // neighbours with equal upper 26 bits (the successor of a lane's last entry is the next lane's first; the last lane of a row has none)
     const uint32_t nx0 = pqt_lane_down1_u32(k[0]);
     const bool close = ((k[0] ^ k[1]) < 64u) || ((k[1] ^ k[2]) < 64u) || ((k[2] ^ k[3]) < 64u) || (l16 != 15u && (k[3] ^ nx0) < 64u);
-    if (__builtin_expect(__ballot(close) == 0ull, 1)) {
+    if (__builtin_expect(__ballot(close) == 0ull && !(tdbg & 2u), 1)) {
       rowSorted = true;
       const float* dRow = sD2 + 64u * pr;
       const uint32_t pos[4] = {k[0] & 63u, k[1] & 63u, k[2] & 63u, k[3] & 63u};

@@ -1510,6 +1510,34 @@ def test_cross_lane_primitives_exchange_and_scan():
     assert np.array_equal(pkg.debug_sort_scan(8, 256)[:256].reshape(4, 64), np.sort(keys, axis=1)), "pqt_row_sort64_u32"
 
 
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg2_dense", "cfg3_small"])
+def test_row_parallel_part_sorts_equal_the_one_list_at_a_time_sorts(name):
+    """Compile-time shapes: the four second-level part lists of a query are sorted together, one per 16-lane row (pqt_row_sort64_u32, keys
+    = distance key with the position in its low 6 bits); a query in which two neighbours of a sorted list agree in the upper 26 bits takes
+    the one-list-at-a-time code that settles such pairs exactly.  Option exact_part_sorts = 1 sends EVERY query through that code: the
+    result lists must be the same bit for bit, and the checker's."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        Bv, Bb = BV_BB[name]
+        f.oracle.set_sort_mode(1)
+        got = {}
+        for ex in (0, 1):
+            idx.set_option("exact_part_sorts", ex)
+            got[ex] = idx.query(f.queries, Bv, Bb, 128)
+            assert "-shape" in idx.last_path(), idx.last_path()
+        assert all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got[0], got[1])), name
+        ids, dist, cnt = got[1]
+        for qi, q in enumerate(f.queries):
+            s_ids, s_d = f.oracle.query(q, Bv, Bb)
+            kk = min(128, len(s_ids))
+            assert int(cnt[qi]) == len(s_ids) and np.array_equal(ids[qi, :kk], s_ids[:kk]) and np.array_equal(bits(dist[qi, :kk]), bits(s_d[:kk])), (name, qi)
+    finally:
+        idx.set_option("exact_part_sorts", 0)
+        f.oracle.set_sort_mode(0)
+        idx.close()
+
+
 @pytest.mark.parametrize("name", ["cfg2_small", "cfg2_dense", "ties", "wrap"])
 def test_xcode_rows_and_the_one_pass_selection_change_no_bit(name):
     """The exact rerank with the LDS coarse table at C1 = 32 reads the X-code copy of the line store (coarse offset precomputed in the
