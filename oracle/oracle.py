@@ -122,6 +122,26 @@ def ref_helper():
     return L
 
 
+def ref_format(cpu_version=False):
+    """The genuine file-format layer of the reference (oracle/_ref): convert/filehelper.hpp + utils/filereader.hpp, or with
+    cpu_version=True cpu_version/filehelper.hpp.  None if not built.  Every function returns 0, or 1 when the reference threw."""
+    so = os.path.join(_HERE, "_ref", "libref_format_cpu.so" if cpu_version else "libref_format.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    up = C.POINTER(C.c_uint)
+    for t in ("u8", "f32", "i32"):
+        getattr(L, "reffmt_write_" + t).argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_void_p, C.c_uint, C.c_uint]
+        getattr(L, "reffmt_read_" + t).argtypes = [C.c_char_p, up, up, C.c_void_p, C.c_uint, C.c_uint]
+        getattr(L, "reffmt_jegou_header_" + t).argtypes = [C.c_char_p, up, up]
+        getattr(L, "reffmt_jegou_" + t).argtypes = [C.c_char_p, C.c_void_p, up, up]
+        if not cpu_version:
+            getattr(L, "reffmt_filereader_" + t).argtypes = [C.c_char_p, C.c_void_p, up, up, C.c_size_t, C.c_size_t]
+    L.reffmt_header.argtypes = [C.c_char_p, up, up]
+    L.reffmt_jegou_batch_u8.argtypes = [C.c_char_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
+    return L
+
+
 def ref_triangle():
     """The genuine pqt/triangle.cuh host functions (oracle/_ref), or None if not built/loadable."""
     so = os.path.join(_HERE, "_ref", "libref_triangle.so")

@@ -60,7 +60,7 @@ def build(force=False):
                                            "pqt_multi.cpp", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
-        subprocess.check_call(["make", "-j5", "-C", CSRC, "libpqt_hip.so"])
+        subprocess.check_call(["make", "-j6", "-C", CSRC, "libpqt_hip.so"])
     return LIB_PATH
 
 

@@ -350,6 +350,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     idx->runsCap = (uint64_t)qChunk * PQT_RUNCAP;
   }
   idx->curRuns = emitRuns;
+  // shared-row pass in front of the filtered selection (configs[2]/[3] shape with bin runs): on by default where the line store is far
+  // beyond the caches (the pass costs six small launches per chunk)
+  const bool sharedPass = runsBig && useFilter && sharedRowsShape(idx) && !idx->d_tstamp && !(idx->dbg & 0xffffu) &&
+                          (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30)));
   // X-code rows for the exact rerank with the LDS table at C1 = 32 (SIFT1M shape): a second copy of the line store with cheaper
   // address arithmetic (pqt_rs_query XC); not for stores beyond 16 GiB (the copy doubles their footprint) and not with bin runs
   bool xcode = idx->useXCode != 0 && fused && !useBias && !wgG && coarseLds && d.C1 == 32 && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !emitRuns &&
@@ -523,6 +527,11 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         nextZeroed = true;
         const float* v = idx->d_qL1virt + (size_t)q0 * d.LP * d.C1;
         const uint32_t* nl = idx->d_nLocal + q0;
+        if (sharedPass) {
+          // rows of a bin read once for all the queries (and all the visits of a query) that include it: pqt_shared_rows.h
+          if ((rc = launchSharedRows(idx, st, v, nl, stride, nq, idx->lev0))) return rc;
+          rc = launchSharedSelect(idx, grid, lRunsBig, st, v, nl, stride, k, nq, oI, oD, oP);
+        } else
         rc = launchRSBiasAny(idx, biasNW, useFilter, grid, biasNW == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP);
         if (rc) return rc;
         idx->poolDirty = false;  // the launch consumes this chunk's registrations and zeroes the next block
@@ -636,6 +645,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->lastSegKept = !travFused || travWide;  // the fused traversal keeps the sorted part lists on chip unless He > 512
   idx->lastFilter = useFilter || usedSmallFirst;  // (pqt_stats.filter_fallbacks then counts the queries the short-list kernel handed to the block-wide one)
   idx->lastRuns = emitRuns;
+  idx->lastShared = sharedPass;
   {
     // which kernels ran (pqt_get_last_path): tests assert the path, not only the result
     std::string tp = !travFused ? "traverse=staged" : (travWide ? "traverse=fused-wide" : "traverse=fused");
@@ -647,7 +657,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     std::string rp;
     if (fused) {
-      if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "");
+      if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "") + (sharedPass ? "-shared" : "");
       else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
       else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "") + ((xcode && !usedOneLaunch) ? "-xcode" : "");
     } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + (usedSmallFirst ? (usedMid ? "+small-lists+mid-lists" : "+small-lists") : "");
@@ -739,7 +749,7 @@ void pqt_index_destroy(pqt_index* idx) {
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -783,6 +793,8 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // the prefetched list costs nothing: rerank+select 0.155 -> 0.170 ms.  Net loss, so the default stays 0.
   // 0: the exact rerank with the LDS table reads the plain bin-ordered store instead of its X-code copy (same results; A/B and tests)
   if (strcmp(name, "xcode") == 0) { idx->useXCode = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  // shared-row pass of the filtered rerank (pqt_shared_rows.h): -1 automatic (line stores of 1 GiB and more), 0 off, 1 on where the shape allows
+  if (strcmp(name, "shared_rows") == 0) { idx->sharedRows = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
@@ -1207,7 +1219,7 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc;
   v.f[0] = x->coarseMax;
   for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1223,7 +1235,7 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4];
   t->coarseMax = v.f[0];
   for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5];
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6];
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)

@@ -886,6 +886,10 @@ struct PqtRsArgs {
   // ... the traversal's registration lists (see PqtTravArgs): pool x is drawn class by class, largest first
   const uint32_t* schedCnt; const unsigned long long* schedList; uint32_t schedCap;
   uint32_t padDone;  // k > 128 kernels: the padding behind the results is written elsewhere (pqt_k_pad_rows)
+  // PRE (shared-row pass, pqt_shared_rows.h): the filter distances d1 of the candidates were written by pqt_k_sr_adc -- once per
+  // distinct (bin, query) pair, the rows of a bin read once for all the queries of the batch that include it -- into
+  // preDist[q * stride + visiting position]; preOk[q] != 0 marks the queries it covered (the others evaluate their rows here)
+  const float* preDist; const uint32_t* preOk;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -914,7 +918,8 @@ struct PqtRsArgs {
 //   u16 * 2^-13 is exact, so the FMA rounds like the separate multiply and add), and two CANDIDATES are evaluated per packed
 //   instruction (the running sums of both in one packed add) -- every candidate's own sequence of roundings is unchanged: same bits.
 // NSLOT: 8-byte key slots of the wavefront (best list + pending buffer): 512 by default, 384 in the 16-wavefront configuration
-template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND>
+template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND,
+          bool PRE = false /* MODE 2 + RUNS: the filter distances come from A.preDist (see PqtRsArgs) */>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
                                              unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
@@ -959,6 +964,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     }
   }
   const bool useRuns = kRuns && mRuns != 0xffffffffu;
+  bool usePre = false;
+  if constexpr (PRE) { static_assert(MODE == 2 && RUNS, "precomputed filter distances: MODE 2 with bin runs"); usePre = useRuns && A.preOk[q] != 0u; }
+  const float* const preRow = PRE ? A.preDist + (size_t)q * stride : nullptr;
+  (void)preRow;
   uint32_t* const sRunG = reinterpret_cast<uint32_t*>(sRuns + A.runCap);
   // runs `lane` and `64 + lane` also live in registers: a batch of 64 consecutive candidates spans a handful of runs, which
   // are broadcast one after the other (v_readlane with a uniform index) -- no search, no LDS latency on the row path
@@ -1191,16 +1200,27 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     if (base < n) {
       if (tstamp) ts0 = __builtin_readcyclecounter();
       uint32_t id[U];
+      float accPre[U];
+      (void)accPre;
+      if constexpr (PRE) {
+        if (usePre) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) { const uint32_t j = base + u * 64 + lane; accPre[u] = preRow[j < n ? j : n - 1]; }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t j = base + u * 64 + lane;
         id[u] = idNext[u];  // position in the bin-ordered line store (requested one batch ago)
-        if constexpr (kRuns) { if (useRuns) { const uint32_t p0 = expand64(base + u * 64); id[u] = j < n ? p0 : 0u; } }
+        if constexpr (kRuns) { if (useRuns && !usePre) { const uint32_t p0 = expand64(base + u * 64); id[u] = j < n ? p0 : 0u; } }
         if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
       }
       uint4 rows[U][LPV];
       float rbias[U];
       (void)rbias;
+      if (PRE && usePre) {
+        // nothing to fetch: the distances are in accPre
+      } else
       if constexpr (MODE != 0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1316,6 +1336,8 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         float acc = 0.f;
         if constexpr (XC) acc = accX[u];
         else
+        if (PRE && usePre) acc = accPre[u];
+        else
         if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
           uint32_t x = 0;
 #pragma unroll
@@ -1368,7 +1390,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             }
           }
         }
-        if constexpr (MODE != 0) acc = acc + rbias[u];
+        if constexpr (MODE != 0) { if (!(PRE && usePre)) acc = acc + rbias[u]; }
         // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
         if (kPhase1 && phase1) {
           if (valid) sK32[j] = pqt_f2key(acc);
@@ -1559,7 +1581,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
           int MODE = 0, bool RUNS = false, bool XC = false /* A.codes = the X-code copy of the store, see pqt_rs_query */,
-          int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */>
+          int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */, bool PRE = false /* filter distances from A.preDist, see pqt_rs_query */>
 // (the X-code kernel keeps its 128-VGPR budget whatever NW is: with fewer than 16 wavefronts the registers it leaves belong to the other
 // batch's traversal wavefronts when two batches are in flight)
 __global__ __launch_bounds__(NW * 64, XC ? 4 : 1) void pqt_k_rerank_select(const PqtRsArgs A) {
@@ -1780,7 +1802,7 @@ __global__ __launch_bounds__(NW * 64, XC ? 4 : 1) void pqt_k_rerank_select(const
   while (q != 0xffffffffu) {
     uint32_t nN = 0, qN = 0xffffffffu;
     if (dynamic != 2) qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS, XC, NSLOT>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS, XC, NSLOT, PRE>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
     if (dynamic == 2) { qN = nextQuery(nN); if (dbg & 2) nN = 0; }
     q = qN;
     n = nN;

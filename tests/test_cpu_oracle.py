@@ -328,3 +328,91 @@ def test_2d_anisotropic_sequences_tables_and_rows():
         assert np.array_equal(got[far], want[far])
     finally:
         o.set_heuristic(f.heur)
+
+
+def test_format_layer_against_the_reference_compiled_fixture(tmp_path):
+    """f2 pinned by the reference's OWN code: tests/golden/ref_formats.npz holds what convert/filehelper.hpp,
+    utils/filereader.hpp and cpu_version/filehelper.hpp -- compiled from /root/reference as oracle/_ref/libref_format{,_cpu}.so by
+    tests/golden/make_golden.py -- wrote and read for seeded arrays.  (1) The host layer's converters produce the reference writer's bytes
+    for bvecs -> .umem and ivecs -> .imem.  (2) The host layer's reader (utils/filereader.hpp, the one tool_query / tool_createdb use) returns
+    what the reference's FileReader<float | uint8_t | int> returned, whole files and (num, offset) windows.  (3) fvecs: the reference's
+    converter stores the FLOAT payload (convert_fvecs.cpp:14,61) although its readers take one BYTE per value (the fixture's
+    filereader_f32_of_float_payload is not the data); the host layer's converter follows the READER side: uint8 payload, = the reference
+    writer's bytes for the uint8-cast values, and reads back as the values."""
+    import subprocess
+    z = np.load(os.path.join(G, "ref_formats.npz"))
+    host = os.path.join(os.path.dirname(G), "..", "product-quantization-tree_amd", "host")
+    for t in ("convert_fvecs", "convert_bvecs", "convert_ivecs", "read_mem"):
+        subprocess.check_call(["make", "-C", host, t], stdout=subprocess.DEVNULL)
+    # both copies of the reference's format code agree with each other
+    for nm in ("umem_bytes", "imem_bytes", "fmem_bytes", "jegou_f32", "jegou_u8", "jegou_i32", "jegou_batch_u8_start9_num6", "read_u8_len640_off384"):
+        assert np.array_equal(z[nm], z["cpu_" + nm]), nm
+    # the reference's TEXMEX readers return the arrays the files were made from
+    assert np.array_equal(z["jegou_f32"], z["f32"]) and np.array_equal(z["jegou_u8"], z["u8"]) and np.array_equal(z["jegou_i32"], z["i32"])
+    assert np.array_equal(z["jegou_batch_u8_start9_num6"], z["u8"][9:15])
+    assert tuple(z["jegou_header_u8"]) == z["u8"].shape and tuple(z["jegou_header_f32"]) == z["f32"].shape and tuple(z["jegou_header_i32"]) == z["i32"].shape
+    # (1) converters against the reference writer's bytes
+    for nm in ("fvecs", "bvecs", "ivecs"):
+        (tmp_path / ("a." + nm)).write_bytes(z[nm + "_bytes"].tobytes())
+    for tool, flag, outflag, want in (("convert_bvecs", "bvecs", "umem", z["umem_bytes"]), ("convert_ivecs", "ivecs", "imem", z["imem_bytes"])):
+        out = tmp_path / ("o_" + flag + "." + outflag)
+        subprocess.check_call([os.path.join(host, tool), "--" + flag, str(tmp_path / ("a." + flag)), "--" + outflag, str(out), "--chunkSize", "7"], stdout=subprocess.DEVNULL)
+        assert np.array_equal(np.frombuffer(out.read_bytes(), np.uint8), want), tool
+    # (2) the host reader on the REFERENCE-written files
+    (tmp_path / "ref.umem").write_bytes(z["umem_bytes"].tobytes())
+    (tmp_path / "ref.imem").write_bytes(z["imem_bytes"].tobytes())
+
+    def read_mem(path, as_, dt, num=None, off=0):
+        out = tmp_path / "raw.bin"
+        cmd = [os.path.join(host, "read_mem"), "--in", str(path), "--as", as_, "--out", str(out)]
+        if num is not None:
+            cmd += ["--num", str(num), "--offset", str(off)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        return tuple(int(x) for x in r.stdout.split()), np.frombuffer(out.read_bytes(), dt)
+
+    nd, v = read_mem(tmp_path / "ref.umem", "f32", np.float32)
+    assert nd == tuple(z["filereader_f32_of_umem_nd"]) and np.array_equal(v.reshape(nd), z["filereader_f32_of_umem"])
+    _, v = read_mem(tmp_path / "ref.umem", "f32", np.float32, 4, 11)
+    assert np.array_equal(v.reshape(4, -1), z["filereader_f32_of_umem_num4_off11"])
+    _, v = read_mem(tmp_path / "ref.umem", "u8", np.uint8)
+    assert np.array_equal(v.reshape(nd), z["filereader_u8_of_umem"])
+    # read<uint8_t>(len, element offset) of the reference = the same window of the payload
+    assert np.array_equal(z["read_u8_len640_off384"], z["u8"].reshape(-1)[384:384 + 640])
+    nd, v = read_mem(tmp_path / "ref.imem", "i32", np.int32)
+    assert nd == tuple(z["filereader_i32_of_imem_nd"]) and np.array_equal(v.reshape(nd), z["filereader_i32_of_imem"])
+    _, v = read_mem(tmp_path / "ref.imem", "i32", np.int32, 5, 7)
+    assert np.array_equal(v.reshape(5, -1), z["filereader_i32_of_imem_num5_off7"])
+    assert np.array_equal(z["read_i32_len200_off700"], z["i32"].reshape(-1)[700:900])
+    r = subprocess.run([os.path.join(host, "read_mem"), "--in", str(tmp_path / "missing.umem"), "--as", "f32", "--out", str(tmp_path / "x")], capture_output=True)
+    assert r.returncode == 3  # std::runtime_error like the reference's reader (the fixture generator asserts the reference throws)
+    # (3) fvecs
+    assert not np.array_equal(z["filereader_f32_of_float_payload"], z["f32"])  # the reference's converter/reader pair does not round-trip
+    out = tmp_path / "o_fvecs.umem"
+    subprocess.check_call([os.path.join(host, "convert_fvecs"), "--fvecs", str(tmp_path / "a.fvecs"), "--umem", str(out)], stdout=subprocess.DEVNULL)
+    raw = np.frombuffer(out.read_bytes(), np.uint8)
+    hdr = ("%d\n%d\n" % z["f32"].shape).encode().ljust(20, b"\0")
+    assert raw[:20].tobytes() == hdr and raw[:20].tobytes() == z["fmem_bytes"][:20].tobytes()  # the reference writer's header for this shape
+    assert np.array_equal(raw[20:], z["f32"].astype(np.uint8).reshape(-1))
+    nd, v = read_mem(out, "f32", np.float32)
+    assert nd == z["f32"].shape and np.array_equal(v.reshape(nd), z["f32"])
+
+
+def test_reference_format_libraries_still_match_the_fixture():
+    """Where /root/reference is present (the authoring container) the format fixture is re-derived from the compiled reference and compared
+    with the committed one: the fixture cannot drift from the code it claims to come from.  Skipped on the GPU box."""
+    from oracle import ref_format
+    if not os.path.isdir("/root/reference/convert") or ref_format() is None:
+        pytest.skip("reference sources not present here")
+    import ctypes as C
+    z = np.load(os.path.join(G, "ref_formats.npz"))
+    F = ref_format()
+    import tempfile
+    p = os.path.join(tempfile.mkdtemp(), "a.umem").encode()
+    u8 = np.ascontiguousarray(z["u8"])
+    assert F.reffmt_write_u8(p, u8.shape[0], u8.shape[1], u8.ctypes.data, u8.size, 0) == 0
+    assert np.array_equal(np.frombuffer(open(p, "rb").read(), np.uint8), z["umem_bytes"])
+    n_, d_ = C.c_uint(), C.c_uint()
+    r = np.zeros(u8.shape, np.float32)
+    assert F.reffmt_filereader_f32(p, r.ctypes.data, C.byref(n_), C.byref(d_), u8.shape[0], 0) == 0
+    assert np.array_equal(r, z["filereader_f32_of_umem"])

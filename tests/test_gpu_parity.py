@@ -1570,3 +1570,92 @@ def test_xcode_rows_and_the_one_pass_selection_change_no_bit(name):
     finally:
         f.oracle.set_sort_mode(0)
         idx.close()
+
+
+@pytest.mark.parametrize("knobs", [(400, 500), (5000, 500), (10 ** 6, 512), (3000, 64), (1, 500)])
+def test_shared_row_pass_changes_no_bit(knobs):
+    """BASELINE configs[2]/[3] shape: the rows of a bin read once for all the queries -- and all the visits of one query: the bin id drops
+    part 3 at this shape, (C1*C2)^3 wraps to 0 in uint32 (treequantizer.hpp:45-49,572), so a query visits the same bin once per aliased
+    tuple -- that include it (pqt_shared_rows.h, option "shared_rows"; automatic only for line stores of 1 GiB and more).  Same ids, distance
+    bits and counts as the wave-per-query filter kernel and as the checker; range shards as well; the queries whose run list does not fit
+    the hand-over (64 runs) evaluate their rows in the selection kernel."""
+    import torch
+    bv, bb = knobs
+    f = fixture("cfg3_small")
+    idx = f.hip_index()
+    n = f.oracle.num_vectors
+    shards = [f.hip_index(shard=(0, n // 3)), f.hip_index(shard=(n // 3, n))]
+    try:
+        k = 100
+        a = idx.query(f.queries, bv, bb, k)
+        assert "-shared" not in idx.last_path()
+        idx.set_option("shared_rows", 1)
+        b = idx.query(f.queries, bv, bb, k)
+        assert "rerank=mode2-nw12-runs-shared" in idx.last_path(), idx.last_path()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        # the checker (duplicates of an aliased bin appear once per visit, in visiting order)
+        f.oracle.set_sort_mode(1)
+        dup = 0
+        for qi, q in enumerate(f.queries):
+            s_ids, s_d = f.oracle.query(q, bv, bb)
+            kk = min(k, len(s_ids))
+            assert int(b[2][qi]) == len(s_ids)
+            assert np.array_equal(b[0][qi, :kk], s_ids[:kk]) and np.array_equal(bits(b[1][qi, :kk]), bits(s_d[:kk])), qi
+            dup += len(s_ids) - len(np.unique(s_ids))
+        if bv >= 3000 and bb >= 500:
+            assert dup > 0, "fixture no longer visits a bin twice"
+        # range shards with the pass, merged
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        I = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Dd = torch.empty((2, qn, k), dtype=torch.float32, device="cuda")
+        Pp = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Cc = torch.empty((2, qn), dtype=torch.int32, device="cuda")
+        for s, sh in enumerate(shards):
+            sh.set_option("shared_rows", 1)
+            sh.query_shard_dev(q, bv, bb, k, I[s], Dd[s], Pp[s], Cc[s], sync=True)
+            assert "-shared" in sh.last_path(), sh.last_path()
+        oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)
+        assert np.array_equal(oI.cpu().numpy().view(np.uint32), a[0]) and np.array_equal(bits(oD.cpu().numpy()), bits(a[1]))
+        # a view of the index (second batch in flight) runs the pass on its own scratch
+        v = idx.view()
+        try:
+            c = v.query(f.queries[::-1].copy(), bv, bb, k)
+            assert "-shared" in v.last_path()
+            assert np.array_equal(c[0], a[0][::-1]) and np.array_equal(bits(c[1]), bits(a[1][::-1]))
+        finally:
+            v.close()
+    finally:
+        f.oracle.set_sort_mode(0)
+        idx.close()
+        for sh in shards:
+            sh.close()
+
+
+def test_shared_row_pass_keeps_the_tie_cluster_fallback():
+    """The band overflow of the filter (hundreds of exactly tied candidates around the k-th distance) still sends the query to the plain
+    exact kernel when the distances come from the shared-row pass."""
+    from common import Fixture
+
+    def clustered(n, D, seed):
+        protos = np.random.default_rng(777).integers(0, 256, (20, D)).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        x = protos[rng.integers(0, 20, n)]
+        noisy = rng.random(n) < 0.5
+        x[noisy] = np.clip(np.rint(x[noisy] + rng.normal(0, 25, (int(noisy.sum()), D))), 0, 255)
+        return x.astype(np.float32)
+
+    f = Fixture(D=64, P=2, C1=64, C2=4, W=2, LP=32, n_base=12000, n_query=8, seed=68, heur_rows=64, train=3000, data=clustered)
+    idx = f.hip_index()
+    try:
+        a = idx.query(f.queries, 10 ** 6, 64, 100)
+        fa = idx.stats()["filter_fallbacks"]
+        idx.set_option("shared_rows", 1)
+        b = idx.query(f.queries, 10 ** 6, 64, 100)
+        assert "-shared" in idx.last_path()
+        assert idx.stats()["filter_fallbacks"] == fa and fa > 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    finally:
+        idx.close()
