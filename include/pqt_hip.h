@@ -152,7 +152,7 @@ int pqt_index_build_heuristic_cuda(pqt_index* idx, uint32_t max_cluster, uint64_
  * (key x^0.8 + s*y^0.8, 65536 cells each); from then on every query picks ITS rows: parts (0,1) and (2,3) are merged into two
  * 256-long pair lists through the order chosen by the slope of their sorted distances, the pair lists the same way, and row r of
  * the query is the tuple of four part ranks behind cell r of that order (cells outside the lists name no bin).  Changes the SET of
- * enumerated rows (at most min(65536, max_cluster^2), bound_bins <= 8192 as always), nothing else: bin ids, the exact sort of the
+ * enumerated rows (at most min(65536, max_cluster^2), bound_bins <= 8192 as always; 16 <= max_cluster <= 4096), nothing else: bin ids, the exact sort of the
  * rows by distance, the cut and the rerank stay cpu_version; the CUDA kernels' sorting inside 1024-row chunks, 2-vectors-per-bin
  * cap and stop at k vectors are not reproduced.  Any other heuristic entry switches the mode off again. */
 int pqt_index_build_heuristic_2d(pqt_index* idx, uint32_t max_cluster);

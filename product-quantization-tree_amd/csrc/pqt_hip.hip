@@ -350,17 +350,26 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     idx->runsCap = (uint64_t)qChunk * PQT_RUNCAP;
   }
   idx->curRuns = emitRuns;
-  // shared-row pass in front of the filtered selection (configs[2]/[3] shape with bin runs): on by default where the line store is far
-  // beyond the caches (the pass costs six small launches per chunk)
-  const bool sharedPass = runsBig && useFilter && sharedRowsShape(idx) && !idx->d_tstamp && !(idx->dbg & 0xffffu) &&
-                          (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30)));
+  // shared-row pass in front of the filtered selection (configs[2]/[3] shape with bin runs).  Automatic choice: where the line store is far
+  // beyond the caches (the pass costs six small launches per chunk) AND the vector bound reaches past the first long bin of a query -- the
+  // pass wins by the visits of one query to the same (aliased) bin and by bins shared between queries; with bound_vectors below half the
+  // largest bin a query takes ~1.3 bins, hardly any twice (measured at 100 M: 3.27 against 4.98 ms per batch at (20000, 500), 2.97 against
+  // 2.88 at (4096, 4096): DESIGN.md section 4)
+  const bool sharedPass = runsBig && useFilter && sharedRowsShape(idx) && !(idx->dbg & 0xffffu) &&
+                          (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30) && (uint64_t)Bv * 2 >= idx->maxBin));
   // X-code rows for the exact rerank with the LDS table at C1 = 32 (SIFT1M shape): a second copy of the line store with cheaper
   // address arithmetic (pqt_rs_query XC); not for stores beyond 16 GiB (the copy doubles their footprint) and not with bin runs
   bool xcode = idx->useXCode != 0 && fused && !useBias && !wgG && coarseLds && d.C1 == 32 && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !emitRuns &&
                      (size_t)idx->nIds * d.LP * 4 <= ((size_t)16 << 30);
   const size_t lFusedX = coarseBytes + (size_t)kXcWaves * ((size_t)kXcSlots * 8 + (size_t)d.LP * d.C1 * 4) + 16 + 3 * PQT_RS_LIST * 4;
   const bool xcodeFits = lFusedX <= kMaxLds;
-  if (xcode && xcodeFits && (rc = ensureXCode(idx, 5))) return rc;
+  if (xcode && xcodeFits && (rc = ensureXCode(idx, 5))) {
+    // automatic mode: a second copy of the line store that cannot be had (out of memory; a view whose owner has not built it yet) is not
+    // an error -- the plain bin-ordered rows serve the same kernel family; "xcode" = 1 keeps the failure visible
+    if (idx->useXCode > 0) return rc;
+    (void)hipGetLastError();
+    xcode = false;
+  }
   xcode = xcode && xcodeFits;
   idx->curXCode = xcode;
   // 128 < k <= 4096 (queryKNN(.., 4096) of the reference front-end): workgroup-per-query fused rerank+select, distances on chip
@@ -530,6 +539,10 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
         if (sharedPass) {
           // rows of a bin read once for all the queries (and all the visits of a query) that include it: pqt_shared_rows.h
           if ((rc = launchSharedRows(idx, st, v, nl, stride, nq, idx->lev0))) return rc;
+          if (idx->lev1) {  // timed call: stage "rerank_select" ends with pqt_k_sr_adc, the selection over its distances is stage "select"
+            idx->lev1 = idx->evRing[idx->ringPos][c][EV_SELECT];
+            idx->evMask[idx->ringPos][c] |= 1u << EV_SELECT;
+          }
           rc = launchSharedSelect(idx, grid, lRunsBig, st, v, nl, stride, k, nq, oI, oD, oP);
         } else
         rc = launchRSBiasAny(idx, biasNW, useFilter, grid, biasNW == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP);
@@ -988,7 +1001,9 @@ int pqt_index_build_heuristic_2d(pqt_index* idx, uint32_t max_cluster) {
   if (idx && idx->isView) return fail(PQT_ERR_INVALID, "pqt_index_build_heuristic_2d: a view handle shares the owner's index; load into the owner");
   if (!idx) return fail(PQT_ERR_INVALID, "null argument");
   if (idx->dp.P != 4) return fail(PQT_ERR_LIMIT, "the 2-D sequences merge parts (0,1) and (2,3): p = 4 only (pqt/PerturbationProTree.cu:2914-3100)");
-  if (max_cluster < 2 || max_cluster > 4096) return fail(PQT_ERR_INVALID, "max_cluster must be in [2, 4096] (test/test1B.cpp:941 passes 512)");
+  // (pqt_k_rows_2d reads the first 256 cells of an order and its slope samples at positions 44 / 45: a grid below 16 x 16 would put the
+  // zero-filled tail -- cell (0, 0), the minimum -- on top of both pair lists)
+  if (max_cluster < 16 || max_cluster > 4096) return fail(PQT_ERR_INVALID, "max_cluster must be in [16, 4096] (test/test1B.cpp:941 passes 512)");
   constexpr uint32_t kSeq = 65536, kDir = 10;
   const uint32_t nVec = max_cluster * max_cluster;
   std::vector<uint32_t> seq((size_t)kSeq * kDir, 0u);

@@ -97,7 +97,7 @@ struct pqt_index {
   uint32_t curDynamic = 0; unsigned long long* curZero8 = nullptr; uint32_t* curPool = nullptr; uint32_t* curPoolNext = nullptr; uint32_t poolPos = 0; unsigned long long* d_schedList = nullptr; uint64_t schedCapQ = 0; uint32_t curSchedCap = 0;  // rerank schedule and next statistics block of the current chunk
   // shared-row pass of the filtered rerank (pqt_shared_rows.h; scratch of this handle): per-batch bin table, pair records, block sums, items
   uint32_t* d_srTable = nullptr; uint64_t srTableCap = 0; uint32_t* d_srPairs = nullptr; uint64_t srPairCap = 0; uint32_t* d_srBlocks = nullptr; uint64_t srBlockCap = 0;
-  unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; const uint32_t* curPreOk = nullptr;
+  unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; const uint32_t* curPreOk = nullptr; const float* curPreQmax = nullptr;
   int sharedRows = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastShared = false;
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
@@ -177,6 +177,8 @@ int launchBigK(pqt_index* idx, bool cl, size_t lBig, uint32_t nq, hipStream_t st
 // ---- pqt_shared_launch.hip: shared-row pass (pqt_shared_rows.h) in front of the filtered selection, and that selection reading its distances
 bool sharedRowsShape(const pqt_index* idx);
 int launchSharedRows(pqt_index* idx, hipStream_t st, const float* qL1virt, const uint32_t* nLocal, uint64_t stride, uint32_t nq, hipEvent_t ev0);
+// the queries a filtered selection handed back (fbList): exact distances by whole workgroups + the exact selection over them
+int launchHandedBack(pqt_index* idx, hipStream_t st, const PqtRsArgs& rargs);
 int launchSharedSelect(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
                        uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP);
 

@@ -889,7 +889,7 @@ struct PqtRsArgs {
   // PRE (shared-row pass, pqt_shared_rows.h): the filter distances d1 of the candidates were written by pqt_k_sr_adc -- once per
   // distinct (bin, query) pair, the rows of a bin read once for all the queries of the batch that include it -- into
   // preDist[q * stride + visiting position]; preOk[q] != 0 marks the queries it covered (the others evaluate their rows here)
-  const float* preDist; const uint32_t* preOk;
+  const float* preDist; const uint32_t* preOk; const float* preQmax /* [q] largest entry of the query's L1virt table (pqt_k_sr_visits) */;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -919,7 +919,8 @@ struct PqtRsArgs {
 //   instruction (the running sums of both in one packed add) -- every candidate's own sequence of roundings is unchanged: same bits.
 // NSLOT: 8-byte key slots of the wavefront (best list + pending buffer): 512 by default, 384 in the 16-wavefront configuration
 template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND,
-          bool PRE = false /* MODE 2 + RUNS: the filter distances come from A.preDist (see PqtRsArgs) */>
+          bool PRE = false /* MODE 2 + RUNS, selection only (pqt_k_sr_select): the filter distances come from A.preDist (see PqtRsArgs), sVirt is the
+                                  query's table in GLOBAL memory (read by the band re-evaluation only), no row is fetched in the batch loop */>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
                                              unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
@@ -963,11 +964,35 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       if (A.runCap > 64) rr1 = A.runs[(size_t)q * PQT_RUNCAP + 64 + lane];
     }
   }
+  if constexpr (PRE) {
+    static_assert((MODE == 2 || MODE == 0) && RUNS && !COARSE_LDS && !XC, "precomputed distances: filter distances (MODE 2) or exact ones (MODE 0), bin-runs variant");
+    if constexpr (MODE == 2) {
+      // a query the shared-row pass did not cover (its runs did not fit the hand-over, or its bins the pass's table) goes where the
+      // queries with an overflowing near-tie band go: exact distances by a whole workgroup, then the MODE 0 selection (pqt_k_sr_exact_list)
+      if (n && A.preOk[q] == 0u) {
+        if (lane == 0) A.fbList[atomicAdd(A.fbCount, 1u)] = q;
+        return;
+      }
+    }
+  }
   const bool useRuns = kRuns && mRuns != 0xffffffffu;
-  bool usePre = false;
-  if constexpr (PRE) { static_assert(MODE == 2 && RUNS, "precomputed filter distances: MODE 2 with bin runs"); usePre = useRuns && A.preOk[q] != 0u; }
+  constexpr bool usePre = PRE;
   const float* const preRow = PRE ? A.preDist + (size_t)q * stride : nullptr;
   (void)preRow;
+  // PRE: a batch costs ~50 instructions here, so its distances must be on their way long before they are used: a queue of PRE_DEPTH
+  // batches (one register per 64 candidates each) instead of one request and one exposed round trip per batch
+  constexpr int PRE_DEPTH = PRE ? 8 : 1;
+  float preQ[PRE_DEPTH][UREQ];
+  (void)preQ;
+  if constexpr (PRE) {
+    if (usePre) {
+#pragma unroll
+      for (int dq = 0; dq < PRE_DEPTH; ++dq) {
+#pragma unroll
+        for (int u = 0; u < UREQ; ++u) { const uint32_t j = (uint32_t)(dq * UREQ + u) * 64u + lane; preQ[dq][u] = n ? preRow[j < n ? j : n - 1] : 0.f; }
+      }
+    }
+  }
   uint32_t* const sRunG = reinterpret_cast<uint32_t*>(sRuns + A.runCap);
   // runs `lane` and `64 + lane` also live in registers: a batch of 64 consecutive candidates spans a handful of runs, which
   // are broadcast one after the other (v_readlane with a uniform index) -- no search, no LDS latency on the row path
@@ -1010,9 +1035,12 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 #pragma unroll
   for (int u = 0; u < UREQ; ++u) {
     const uint32_t j = u * 64 + lane;
-    idNext[u] = (n && !useRuns) ? cid[j < n ? j : n - 1] : 0u;
+    idNext[u] = (!PRE && n && !useRuns) ? cid[j < n ? j : n - 1] : 0u;  // (PRE: positions are needed for the results only)
   }
   float qmax = 0.f;  // MODE 2: largest entry of the query's L1virt table
+  if constexpr (PRE) {
+    if constexpr (MODE == 2) qmax = A.preQmax[q];  // (no LDS copy of the table: sVirt points at it in global memory)
+  } else
   if constexpr (C1M >= 2) {
     // compile-time shape: the whole table is requested before the first piece is stored (the run-time loop below compiled to one
     // load + s_waitcnt per 1 KB: 8 serialised round trips per query at the configs[2] shape, ~14 k clocks of set-up)
@@ -1046,7 +1074,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   constexpr uint32_t SLOTS = NSLOT;
   static_assert(BESTN + 64u * UREQ <= SLOTS, "a batch of appended keys must fit behind the best list");
   const uint32_t kSel = MODE == 2 ? BESTN : k;
-  if constexpr (MODE == 2) {
+  if constexpr (MODE == 2 && !PRE) {
     if constexpr (C1M < 2) { for (uint32_t t = lane; t < LP * C1; t += 64) { const float v = sVirt[t]; qmax = v > qmax ? v : qmax; } }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(qmax, d, 64); qmax = o > qmax ? o : qmax; }
@@ -1204,21 +1232,32 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       (void)accPre;
       if constexpr (PRE) {
         if (usePre) {
+          // head of the request queue (asked for PRE_DEPTH batches ago), the queue moves up, the batch PRE_DEPTH ahead is requested
 #pragma unroll
-          for (int u = 0; u < U; ++u) { const uint32_t j = base + u * 64 + lane; accPre[u] = preRow[j < n ? j : n - 1]; }
+          for (int u = 0; u < U; ++u) accPre[u] = preQ[0][u];
+#pragma unroll
+          for (int dq = 0; dq + 1 < PRE_DEPTH; ++dq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) preQ[dq][u] = preQ[dq + 1][u];
+          }
+          // (requested unconditionally, clamped to the list: with a conditional request the compiler cannot count the requests in flight
+          // and waits for ALL of them at every use -- the queue would hide nothing)
+          const uint32_t ahead = base + (uint32_t)PRE_DEPTH * 64u * U;
+#pragma unroll
+          for (int u = 0; u < U; ++u) { const uint32_t j = ahead + u * 64 + lane; preQ[PRE_DEPTH - 1][u] = preRow[j < n ? j : n - 1]; }
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t j = base + u * 64 + lane;
         id[u] = idNext[u];  // position in the bin-ordered line store (requested one batch ago)
-        if constexpr (kRuns) { if (useRuns && !usePre) { const uint32_t p0 = expand64(base + u * 64); id[u] = j < n ? p0 : 0u; } }
+        if constexpr (kRuns && !PRE) { if (useRuns) { const uint32_t p0 = expand64(base + u * 64); id[u] = j < n ? p0 : 0u; } }
         if (dbg & 16) id[u] = (j & 1023u);  // debug: cache-resident rows (results wrong)
       }
       uint4 rows[U][LPV];
       float rbias[U];
       (void)rbias;
-      if (PRE && usePre) {
+      if constexpr (PRE) {
         // nothing to fetch: the distances are in accPre
       } else
       if constexpr (MODE != 0) {
@@ -1275,12 +1314,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         for (int v = 0; v < LPV; ++v) rows[u][v] = row4[(dbg & 1024) ? 0 : v];  // debug bit 1024: one 16-byte piece per row (results wrong)
       }
       }
+      if constexpr (!PRE) {
       if (!useRuns && base + 64 * U < n) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const uint32_t j = base + 64 * U + u * 64 + lane;
           idNext[u] = cid[j < n ? j : n - 1];
         }
+      }
       }
       if (tstamp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_readcyclecounter(); tsLoad += t - ts0; ts0 = t; }
       float accX[U];
@@ -1335,8 +1376,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
         const bool valid = j < n;
         float acc = 0.f;
         if constexpr (XC) acc = accX[u];
-        else
-        if (PRE && usePre) acc = accPre[u];
+        else if constexpr (PRE) acc = accPre[u];
         else
         if (dbg & 8) {  // debug: no ADC arithmetic, the rows are still fetched and consumed (results wrong)
           uint32_t x = 0;
@@ -1390,7 +1430,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
             }
           }
         }
-        if constexpr (MODE != 0) { if (!(PRE && usePre)) acc = acc + rbias[u]; }
+        if constexpr (MODE != 0 && !PRE) acc = acc + rbias[u];
         // visiting position is the tie-break; sharded lists keep j as the low word (positions are monotone in j)
         if (kPhase1 && phase1) {
           if (valid) sK32[j] = pqt_f2key(acc);
@@ -1581,7 +1621,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
 
 template <int NW, int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M /* 0: any C1, 1: power of two, >= 2: C1 == 1 << C1M at compile time */,
           int MODE = 0, bool RUNS = false, bool XC = false /* A.codes = the X-code copy of the store, see pqt_rs_query */,
-          int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */, bool PRE = false /* filter distances from A.preDist, see pqt_rs_query */>
+          int NSLOT = PQT_RS_BEST + PQT_RS_PEND /* key slots per wavefront */>
 // (the X-code kernel keeps its 128-VGPR budget whatever NW is: with fewer than 16 wavefronts the registers it leaves belong to the other
 // batch's traversal wavefronts when two batches are in flight)
 __global__ __launch_bounds__(NW * 64, XC ? 4 : 1) void pqt_k_rerank_select(const PqtRsArgs A) {
@@ -1802,7 +1842,7 @@ __global__ __launch_bounds__(NW * 64, XC ? 4 : 1) void pqt_k_rerank_select(const
   while (q != 0xffffffffu) {
     uint32_t nN = 0, qN = 0xffffffffu;
     if (dynamic != 2) qN = nextQuery(nN);
-    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS, XC, NSLOT, PRE>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
+    pqt_rs_query<LPV, UREQ, COARSE_LDS, SHARDED, C1M, MODE, RUNS, XC, NSLOT>(A, q, n, sKeys, sVirt, cz, qN, nN, slot, tiesAcc, sRuns);
     if (dynamic == 2) { qN = nextQuery(nN); if (dbg & 2) nN = 0; }
     q = qN;
     n = nN;

@@ -118,6 +118,11 @@ int launchRSBias(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, cons
   const PqtRsArgs rargs = rsArgsFilter(idx, qL1virt, nLocal, stride, k, nq, oI, oD, oP);
   if (MODE == 2) HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
   hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, idx->lev0, idx->lev1, 0u, rargs);
+  if (MODE == 2 && kRunsVariant && c1 == 64 && idx->candCap) {
+    // queries whose near-tie band overflowed the wave's list (normally none, a few per FRESH batch at configs[2]): exact distances by whole
+    // workgroups, then the exact selection over them (pqt_shared_launch.hip) -- not one wavefront per 23 k-candidate query
+    if ((rc = launchHandedBack(idx, st, rargs))) return rc;
+  } else
   if (MODE == 2) {
     // queries whose near-tie band overflowed the wave's list (normally none): plain exact kernel on that list
     constexpr int LNW = 4;

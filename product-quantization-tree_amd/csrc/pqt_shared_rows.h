@@ -27,19 +27,33 @@
 #pragma once
 #include "pqt_kernels.h"
 
+#ifndef PQT_SR_ABL
+#define PQT_SR_ABL 0   // development ablations of pqt_k_sr_adc (results wrong): 1 no stores, 2 no table look-ups, 4 cache-resident rows, 8 one visit only
+#endif
 #ifndef PQT_SR_TILE
 #define PQT_SR_TILE 2048u   // rows per item
 #endif
 
+#ifndef PQT_SR_OCC
+#define PQT_SR_OCC 4   // wavefronts per SIMD pqt_k_sr_adc is compiled for (register budget 512 / PQT_SR_OCC)
+#endif
+#ifndef PQT_SR_DB
+#define PQT_SR_DB 1    // 1: two register sets of rows (next batch in flight under the current one's arithmetic), 0: one
+#endif
+#ifndef PQT_SR_QC
+#define PQT_SR_QC 8   // queries of a bin evaluated per item against one copy of the rows (their L1virt tables side by side in LDS: 8 KB each)
+#endif
+
 struct PqtSrArgs {
   const unsigned long long* runs; const uint32_t* nRuns; const uint32_t* nLocal; uint32_t qn;
-  uint32_t* keys; uint32_t* cnt; uint32_t* len; uint32_t* base; uint32_t slotBits;  // per-batch bin table: 2^slotBits slots (keys, cnt zeroed / 0xff-filled per batch)
+  uint32_t* keys; uint32_t* cnt; uint32_t* len; uint32_t* base; uint32_t* lbase; uint32_t slotBits;  // per-batch bin table: 2^slotBits slots (keys 0xff-filled, cnt zeroed per batch)
   uint32_t* pairSlot; uint32_t* pairIdx;   // [qn][64]: table slot of the pair run r of query q is the canonical visit of (0xffffffff: none), its rank among the bin's queries
-  uint32_t* preOk;                         // [qn]
-  uint32_t* blockSum; uint32_t nBlocks;    // per 1024 slots: items of the block, then (after _scan2) their exclusive prefix
+  uint32_t* preOk; float* qmax;            // [qn] covered by the pass; largest entry of the query's L1virt table (the selection's error bound)
+  uint32_t* blockSum; uint32_t nBlocks;    // [nBlocks][2] per 1024 slots: items / list entries of the block, then (after _scan2) their exclusive prefixes
   uint32_t* total;                         // [0] items of the batch
-  unsigned long long* items; uint64_t itemCap;  // query | run << 32 | tile << 40
-  const uint4* codesGrp4; uint64_t nIds; const float* bias; const float* qL1virt; float* dist; uint64_t stride;
+  unsigned long long* items; uint64_t itemCap;  // slot | tile << 32 | chunk << 48
+  unsigned long long* binList; uint64_t listCap;  // the queries of a bin, side by side: query | run << 32
+  const uint4* codesGrp4; uint64_t nIds; const float* bias; const float* qL1virt; float* dist; uint64_t stride; uint32_t tableFloats /* LP * C1 */;
 };
 
 // 1. one wavefront per query
@@ -74,112 +88,140 @@ __global__ __launch_bounds__(256) void pqt_k_sr_visits(const PqtSrArgs A) {
   const bool ok = listed && __ballot(failed) == 0ull;
   A.pairSlot[(size_t)q * 64 + lane] = slot;
   A.pairIdx[(size_t)q * 64 + lane] = rank;
-  if (lane == 0) A.preOk[q] = ok ? 1u : 0u;
+  // largest entry of the query's table (pqt_rs_query MODE 2 takes it from its LDS copy; the selection kernel of this pass keeps none)
+  float qmax = 0.f;
+  {
+    const uint32_t nv = A.tableFloats / 4;
+    const float4* src4 = reinterpret_cast<const float4*>(A.qL1virt + (size_t)q * A.tableFloats);
+    for (uint32_t t = lane; t < nv; t += 64) {
+      const float4 v = src4[t];
+      const float m01 = v.x > v.y ? v.x : v.y, m23 = v.z > v.w ? v.z : v.w, mm = m01 > m23 ? m01 : m23;
+      qmax = mm > qmax ? mm : qmax;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { const float o = __shfl_xor(qmax, d, 64); qmax = o > qmax ? o : qmax; }
+  }
+  if (lane == 0) { A.preOk[q] = ok ? 1u : 0u; A.qmax[q] = qmax; }
 }
 
-// 2a. items per table slot, exclusive scan inside blocks of 1024 slots
+// 2a. items and list entries per table slot, exclusive scans inside blocks of 1024 slots
 __global__ __launch_bounds__(1024) void pqt_k_sr_scan(const PqtSrArgs A) {
-  __shared__ uint32_t sWave[16];
+  __shared__ uint32_t sWave[2][16];
   const uint32_t slot = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t c = A.cnt[slot];
-  const uint32_t need = c ? c * ((A.len[slot] + PQT_SR_TILE - 1u) / PQT_SR_TILE) : 0u;
-  const uint32_t incl = pqt_wave_incl_scan(need);
-  if (lane == 63) sWave[wave] = incl;
+  const uint32_t need = c ? ((c + PQT_SR_QC - 1u) / PQT_SR_QC) * ((A.len[slot] + PQT_SR_TILE - 1u) / PQT_SR_TILE) : 0u;
+  const uint32_t incl = pqt_wave_incl_scan(need), inclL = pqt_wave_incl_scan(c);
+  if (lane == 63) { sWave[0][wave] = incl; sWave[1][wave] = inclL; }
   __syncthreads();
-  uint32_t off = 0;
-  for (uint32_t w = 0; w < wave; ++w) off += sWave[w];
+  uint32_t off = 0, offL = 0;
+  for (uint32_t w = 0; w < wave; ++w) { off += sWave[0][w]; offL += sWave[1][w]; }
   A.base[slot] = off + incl - need;
-  if (threadIdx.x == 1023) A.blockSum[blockIdx.x] = off + incl;
+  A.lbase[slot] = offL + inclL - c;
+  if (threadIdx.x == 1023) { A.blockSum[2 * blockIdx.x] = off + incl; A.blockSum[2 * blockIdx.x + 1] = offL + inclL; }
 }
-// 2b. exclusive scan of the block sums (one workgroup), total
+// 2b. exclusive scans of the block sums (one workgroup), total
 __global__ __launch_bounds__(1024) void pqt_k_sr_scan2(const PqtSrArgs A) {
-  __shared__ uint32_t sWave[16];
+  __shared__ uint32_t sWave[2][16];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t per = (A.nBlocks + 1023u) / 1024u;
-  uint32_t sum = 0;
-  for (uint32_t i = 0; i < per; ++i) { const uint32_t b = threadIdx.x * per + i; if (b < A.nBlocks) sum += A.blockSum[b]; }
-  const uint32_t incl = pqt_wave_incl_scan(sum);
-  if (lane == 63) sWave[wave] = incl;
+  uint32_t sum = 0, sumL = 0;
+  for (uint32_t i = 0; i < per; ++i) { const uint32_t b = threadIdx.x * per + i; if (b < A.nBlocks) { sum += A.blockSum[2 * b]; sumL += A.blockSum[2 * b + 1]; } }
+  const uint32_t incl = pqt_wave_incl_scan(sum), inclL = pqt_wave_incl_scan(sumL);
+  if (lane == 63) { sWave[0][wave] = incl; sWave[1][wave] = inclL; }
   __syncthreads();
-  uint32_t off = 0;
-  for (uint32_t w = 0; w < wave; ++w) off += sWave[w];
-  uint32_t run = off + incl - sum;
+  uint32_t off = 0, offL = 0;
+  for (uint32_t w = 0; w < wave; ++w) { off += sWave[0][w]; offL += sWave[1][w]; }
+  uint32_t run = off + incl - sum, runL = offL + inclL - sumL;
   for (uint32_t i = 0; i < per; ++i) {
     const uint32_t b = threadIdx.x * per + i;
-    if (b < A.nBlocks) { const uint32_t v = A.blockSum[b]; A.blockSum[b] = run; run += v; }
+    if (b < A.nBlocks) { const uint32_t v = A.blockSum[2 * b], vL = A.blockSum[2 * b + 1]; A.blockSum[2 * b] = run; A.blockSum[2 * b + 1] = runL; run += v; runL += vL; }
   }
   if (threadIdx.x == 1023) A.total[0] = off + incl;
 }
 
-// 3. one thread per (query, run): the items of a canonical visit
+// 3. one thread per (query, run): a canonical visit enters its bin's query list; the first query of every chunk of PQT_SR_QC writes the chunk's items
 __global__ __launch_bounds__(256) void pqt_k_sr_items(const PqtSrArgs A) {
   const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (uint64_t)A.qn * 64) return;
   const uint32_t slot = A.pairSlot[t];
   if (slot == 0xffffffffu) return;
   const uint32_t q = (uint32_t)(t >> 6), r = (uint32_t)(t & 63u);
-  // (a query whose other pairs did not fit the table still owns the slots it got: its items are written and evaluated, the selection
-  // kernel ignores them -- no holes in the item list)
+  // (a query whose other pairs did not fit the table still owns the slots it got: it is listed and evaluated, the selection kernel
+  // ignores what was written for it -- no holes in the lists)
   const uint32_t c = A.cnt[slot], rank = A.pairIdx[t];
+  const uint64_t lo = (uint64_t)A.lbase[slot] + A.blockSum[2 * (slot >> 10) + 1] + rank;
+  if (lo < A.listCap) A.binList[lo] = (unsigned long long)q | ((unsigned long long)r << 32);
+  if (rank % PQT_SR_QC) return;
+  const uint32_t chunks = (c + PQT_SR_QC - 1u) / PQT_SR_QC, chunk = rank / PQT_SR_QC;
   const uint32_t tiles = (A.len[slot] + PQT_SR_TILE - 1u) / PQT_SR_TILE;
-  const uint64_t b = (uint64_t)A.base[slot] + A.blockSum[slot >> 10];
+  const uint64_t b = (uint64_t)A.base[slot] + A.blockSum[2 * (slot >> 10)];
   for (uint32_t ti = 0; ti < tiles; ++ti) {
-    const uint64_t o = b + (uint64_t)ti * c + rank;
-    if (o < A.itemCap) A.items[o] = (unsigned long long)q | ((unsigned long long)r << 32) | ((unsigned long long)ti << 40);
+    const uint64_t o = b + (uint64_t)ti * chunks + chunk;
+    if (o < A.itemCap) A.items[o] = (unsigned long long)slot | ((unsigned long long)ti << 32) | ((unsigned long long)chunk << 48);
   }
 }
 
-// 4. filter distances of one tile of one bin for one query, by one wavefront
-template <int NW, int LPV, int C1M, int U>
-__global__ __launch_bounds__(NW * 64) void pqt_k_sr_adc(const PqtSrArgs A) {
+// 4. filter distances of one tile of one bin for up to PQT_SR_QC of its queries, by one workgroup: every row is read ONCE (a wavefront holds
+// 64 of them in registers while it walks the queries' tables)
+template <int NW, int LPV, int C1M>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_OCC, PQT_SR_OCC))) void pqt_k_sr_adc(const PqtSrArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M;
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M, QC = PQT_SR_QC;
+  constexpr uint32_t TB = LP * C1 * 4;  // bytes of one table
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float* const sVirt = reinterpret_cast<float*>(smem_raw) + (size_t)wave * LP * C1;
+  uint32_t* const sJ0 = reinterpret_cast<uint32_t*>(smem_raw + (size_t)QC * TB);  // [QC][64] first visiting positions of the query's visits of this bin
+  uint32_t* const sNv = sJ0 + QC * 64;                                               // [QC] their number
+  uint32_t* const sQ = sNv + QC;                                                     // [QC] the query
   uint64_t total = A.total[0];
   if (total > A.itemCap) total = A.itemCap;
-  for (uint64_t i = (uint64_t)blockIdx.x * NW + wave; i < total; i += (uint64_t)gridDim.x * NW) {
+  for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
     const unsigned long long it = A.items[i];
-    const uint32_t q = (uint32_t)it, r = (uint32_t)(it >> 32) & 0xffu, ti = (uint32_t)(it >> 40);
-    const uint32_t m = A.nRuns[q], n = A.nLocal[q];
-    const unsigned long long rr = lane < m ? A.runs[(size_t)q * PQT_RUNCAP + lane] : ~0ull;
-    // the query's table, requested whole before the first piece is stored
-    constexpr uint32_t NV = LP * C1 / 4, IT = (NV + 63) / 64;
-    {
+    const uint32_t slot = (uint32_t)it, ti = (uint32_t)(it >> 32) & 0xffffu, chunk = (uint32_t)(it >> 48);
+    const uint32_t sr = A.keys[slot], lenr = A.len[slot], c = A.cnt[slot];
+    const uint64_t lo = (uint64_t)A.lbase[slot] + A.blockSum[2 * (slot >> 10) + 1] + (uint64_t)chunk * QC;
+    const uint32_t nq = c - chunk * QC < QC ? c - chunk * QC : QC;
+    __syncthreads();  // the previous item's tables are no longer read
+    // the queries' tables, side by side
+    for (uint32_t e = wave; e < nq; e += NW) {
+      const unsigned long long ent = A.binList[lo + e];
+      const uint32_t q = (uint32_t)ent;
       const float4* src4 = reinterpret_cast<const float4*>(A.qL1virt + (size_t)q * LP * C1);
-      float4* dst4 = reinterpret_cast<float4*>(sVirt);
+      float4* dst4 = reinterpret_cast<float4*>(smem_raw + (size_t)e * TB);
+      constexpr uint32_t NV = LP * C1 / 4, IT = (NV + 63) / 64;
       float4 tmp[IT];
 #pragma unroll
       for (uint32_t x = 0; x < IT; ++x) { const uint32_t t = lane + 64 * x; tmp[x] = src4[t < NV ? t : 0]; }
+      // every visit of this bin by the query (the listed run is the first): first visiting positions, compacted
+      const uint32_t m = A.nRuns[q];
+      const unsigned long long rr = lane < m ? A.runs[(size_t)q * PQT_RUNCAP + lane] : ~0ull;
+      const bool vis = lane < m && (uint32_t)(rr >> 32) == sr;
+      uint32_t nv;
+      const uint32_t rk = pqt_ballot_rank(vis, &nv);
+      if (vis) sJ0[e * 64 + rk] = (uint32_t)rr;
+      if (lane == 0) { sNv[e] = nv; sQ[e] = q; }
 #pragma unroll
       for (uint32_t x = 0; x < IT; ++x) { const uint32_t t = lane + 64 * x; if (t < NV) dst4[t] = tmp[x]; }
     }
-    const uint32_t j0 = (uint32_t)rr, s = (uint32_t)(rr >> 32);
-    const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)r), j0r = (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)r);
-    const uint32_t jn = r + 1 < m ? (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(r + 1)) : n;
-    const uint32_t lenr = jn - j0r;
-    const unsigned long long visits = __ballot(lane < m && s == sr);  // every visit of this bin by the query (run r is the first)
+    __syncthreads();
     const uint32_t row0 = ti * PQT_SR_TILE, row1 = lenr < row0 + PQT_SR_TILE ? lenr : row0 + PQT_SR_TILE;
-    float* const drow = A.dist + (size_t)q * A.stride;
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t b = row0; b < row1; b += 64 * U) {
-      uint4 rows[U][LPV];
-      float rbias[U];
+    // the rows of this wavefront's next batch are requested before the current one is evaluated (two register sets, alternating).
+    // (Without the scheduling barriers the compiler sinks the requests between the terms of the other set to save registers.)
+    auto request = [&](uint4 (&rows)[LPV], float& rbias, const uint32_t b) {
+      const uint32_t o = b + lane;
+      size_t pos = (size_t)sr + (o < row1 ? o : row1 - 1u);
+      if (PQT_SR_ABL & 4) pos &= 4095u;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t o = b + u * 64 + lane;
-        const size_t pos = (size_t)sr + (o < row1 ? o : row1 - 1u);
-#pragma unroll
-        for (int v = 0; v < LPV; ++v) rows[u][v] = A.codesGrp4[(size_t)v * A.nIds + pos];
-        rbias[u] = A.bias[pos];
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t o = b + u * 64 + lane;
+      for (int v = 0; v < LPV; ++v) rows[v] = A.codesGrp4[(size_t)v * A.nIds + pos];
+      rbias = A.bias[pos];
+    };
+    auto evaluate = [&](const uint4 (&rows)[LPV], const float rbias, const uint32_t b) {
+      const uint32_t o = b + lane;
+      for (uint32_t e = 0; e < nq; ++e) {
+        const float* const sVirt = reinterpret_cast<const float*>(smem_raw + (size_t)e * TB);
         float acc = 0.f;
 #pragma unroll
         for (int v = 0; v < LPV; ++v) {
-          const uint32_t w[4] = {rows[u][v].x, rows[u][v].y, rows[u][v].z, rows[u][v].w};
+          const uint32_t w[4] = {rows[v].x, rows[v].y, rows[v].z, rows[v].w};
 #pragma unroll
           for (int x = 0; x < 4; x += 2) {  // the instruction sequence of pqt_rs_query MODE 2 (same association: same bits)
             pqt_f2 sb2, sa2, lam2;
@@ -189,8 +231,10 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_sr_adc(const PqtSrArgs A) {
               const uint32_t ww = w[x + h];
               const uint32_t Aa = ww & 0xffu, Bb = (ww >> 8) & 0xffu;
               lam2[h] = (float)(ww >> 16);
+              if (PQT_SR_ABL & 2) { sb2[h] = __uint_as_float(Aa); sa2[h] = __uint_as_float(Bb); } else {
               sb2[h] = sVirt[(p << C1M) + Aa];
               sa2[h] = sVirt[(p << C1M) + Bb];
+              }
             }
             const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
             lam2 = lam2 * kScale + kOff;
@@ -199,16 +243,151 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_sr_adc(const PqtSrArgs A) {
             acc = acc + d2[1];
           }
         }
-        acc = acc + rbias[u];
-        unsigned long long vm = visits;
-        while (vm) {  // uniform: one (coalesced) store per visit of the bin
-          const uint32_t d = (uint32_t)__builtin_ctzll(vm);
-          vm &= vm - 1ull;
-          const uint32_t jd = (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)d);
+        acc = acc + rbias;
+        float* const drow = A.dist + (size_t)sQ[e] * A.stride;
+        const uint32_t nv = (PQT_SR_ABL & 8) ? 1u : sNv[e];
+        if (PQT_SR_ABL & 1) { if (acc == 12345.678f) drow[o] = acc; }
+        else
+        for (uint32_t vi = 0; vi < nv; ++vi) {  // uniform: one (coalesced) store per visit of the bin
+          const uint32_t jd = sJ0[e * 64 + vi];
           if (o < row1) drow[jd + o] = acc;
         }
       }
+    };
+    const uint32_t first = row0 + wave * 64;
+#if PQT_SR_DB
+    uint4 rowsA[LPV], rowsB[LPV];
+    float biasA = 0.f, biasB = 0.f;
+    if (first < row1) request(rowsA, biasA, first);
+    for (uint32_t b = first; b < row1; b += 2 * NW * 64) {
+      const bool haveB = b + NW * 64 < row1;
+      if (haveB) request(rowsB, biasB, b + NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(rowsA, biasA, b);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!haveB) break;
+      if (b + 2 * NW * 64 < row1) request(rowsA, biasA, b + 2 * NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(rowsB, biasB, b + NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_wave_barrier();  // the next item overwrites the table
+#else
+    uint4 rowsA[LPV];
+    float biasA = 0.f;
+    for (uint32_t b = first; b < row1; b += NW * 64) {
+      request(rowsA, biasA, b);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(rowsA, biasA, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
+  }
+}
+
+// 5. selection: one wavefront per query over the distances of step 4 (pqt_rs_query PRE): no row is read before the band re-evaluation, the
+// query's table stays in global memory (the band reads ~k entries of it), so a wavefront needs its key slots and run list only -- 5 KB of LDS
+// instead of 12.5 KB, and none of the row registers of the evaluating kernel.
+// LIST: the queries of A.qlist (those the first selection handed back: not covered by the pass, or a near-tie band beyond its 256 slots),
+// MODE 0 over the EXACT distances pqt_k_sr_exact_list wrote for them.
+template <int NW, int LPV, int UREQ, bool SHARDED, int C1M, bool LIST>
+__global__ __launch_bounds__(NW * 64) void pqt_k_sr_select(const PqtRsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M;
+  constexpr int NSLOT = PQT_RS_BEST + PQT_RS_PEND;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t* const sKeys = reinterpret_cast<uint64_t*>(smem_raw) + (size_t)wave * NSLOT;
+  unsigned long long* const sRuns = reinterpret_cast<unsigned long long*>(smem_raw + (size_t)NW * NSLOT * 8) + (size_t)wave * (A.runCap + A.runCap / 2);
+  if constexpr (!LIST) {
+    // (what the evaluating kernel does for the next call: statistics block and the schedule's registration block zeroed)
+    if (blockIdx.x == 0 && threadIdx.x < 8 && A.zero8) A.zero8[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && A.poolNext) for (uint32_t t = threadIdx.x; t < 16u + 8u * PQT_SCHED_CLASSES; t += NW * 64) A.poolNext[t] = 0;
+  }
+  uint32_t tiesAcc = 0;
+  const uint32_t slot = blockIdx.x * NW + wave;
+  const uint32_t cnt = LIST ? *A.qcount : A.qn;
+  for (uint32_t e = slot; e < cnt; e += gridDim.x * NW) {
+    const uint32_t q = LIST ? A.qlist[e] : e;
+    uint32_t nN = 0;
+    float* const tableG = const_cast<float*>(A.qL1virt) + (size_t)q * LP * C1;
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, LIST ? 0 : 2, true, false, NSLOT, true>(A, q, A.nLocal[q], sKeys, tableG, A.coarse, 0xffffffffu, nN, slot, tiesAcc, sRuns);
+    __builtin_amdgcn_wave_barrier();
+  }
+  pqt_count_ties(&A.counters[3], tiesAcc);
+}
+
+// 6. the queries the selection handed back: EXACT distances (the reference's association, term by term, p ascending: the sequence of the
+// band re-evaluation in pqt_rs_query) of all their candidates by one workgroup per query -- a wavefront alone needs ~1 ms for the 23 k
+// candidates of a configs[2] query (the plain exact list kernel: that latency, once per batch, was most of what a fresh batch lost).
+// Positions come from the query's runs, or from its plain candidate list when the traversal wrote one.
+template <int NW, int LPV, int C1M>
+__global__ __launch_bounds__(NW * 64) void pqt_k_sr_exact_list(const PqtRsArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M;
+  float* const sVirt = reinterpret_cast<float*>(smem_raw);
+  unsigned long long* const sRun = reinterpret_cast<unsigned long long*>(smem_raw + (size_t)LP * C1 * 4);  // PQT_RUNCAP entries
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t cnt = *A.qcount;
+  // an item = XT candidates of one listed query: the handful of queries spread over the whole device
+  constexpr uint32_t XT = 2048;
+  const uint32_t maxTiles = (uint32_t)((A.stride + XT - 1) / XT);
+  for (uint64_t it = blockIdx.x; it < (uint64_t)cnt * maxTiles; it += gridDim.x) {
+    const uint32_t e = (uint32_t)(it / maxTiles), tile = (uint32_t)(it % maxTiles);
+    const uint32_t q = A.qlist[e];
+    const uint32_t n = A.nLocal[q];
+    if (tile * XT >= n) continue;  // (uniform)
+    const uint32_t jEnd = n < (tile + 1) * XT ? n : (tile + 1) * XT;
+    const uint32_t m = A.nRuns ? A.nRuns[q] : 0xffffffffu;
+    const bool listed = m != 0xffffffffu;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < LP * C1 / 4; t += NW * 64) reinterpret_cast<float4*>(sVirt)[t] = reinterpret_cast<const float4*>(A.qL1virt + (size_t)q * LP * C1)[t];
+    if (listed) for (uint32_t t = threadIdx.x; t < m; t += NW * 64) sRun[t] = A.runs[(size_t)q * PQT_RUNCAP + t];
+    __syncthreads();
+    const uint32_t* cid = A.cand + (size_t)q * A.stride;
+    float* const drow = const_cast<float*>(A.preDist) + (size_t)q * A.stride;
+    for (uint32_t j0 = tile * XT + wave * 64; j0 < jEnd; j0 += NW * 64) {
+      const uint32_t j = j0 + lane;
+      const bool act = j < jEnd;
+      uint32_t posj = 0;
+      if (act) {
+        if (listed) {
+          uint32_t lo = 0;  // last run whose first visiting position is <= j
+#pragma unroll
+          for (uint32_t s2 = PQT_RUNCAP / 2; s2 >= 1; s2 >>= 1) { const uint32_t mid = lo + s2; if (mid < m && (uint32_t)sRun[mid] <= j) lo = mid; }
+          const unsigned long long rr = sRun[lo];
+          posj = (uint32_t)(rr >> 32) + (j - (uint32_t)rr);
+        } else posj = cid[j];
+      }
+      const uint4* row4 = reinterpret_cast<const uint4*>(A.codes + (size_t)posj * LP);
+      uint4 rv[LPV];
+#pragma unroll
+      for (int v = 0; v < LPV; ++v) rv[v] = row4[v];
+      float scv[LP];
+#pragma unroll
+      for (int v = 0; v < LPV; ++v) {
+        const uint32_t w[4] = {rv[v].x, rv[v].y, rv[v].z, rv[v].w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const uint32_t p = v * 4 + x;
+          const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+          scv[p] = A.coarse[((((p << C1M) + Aa) << C1M) + Bb)];
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // all LP gathers in flight before the first use (see the band re-evaluation of pqt_rs_query)
+      float acc = 0.f;
+#pragma unroll
+      for (int v = 0; v < LPV; ++v) {
+        const uint32_t w[4] = {rv[v].x, rv[v].y, rv[v].z, rv[v].w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const uint32_t p = v * 4 + x;
+          const uint32_t Aa = w[x] & 0xffu, Bb = (w[x] >> 8) & 0xffu;
+          const float lam = __builtin_fmaf((float)(w[x] >> 16), 8.f / 65536.f, -4.f);
+          const float sb = sVirt[(p << C1M) + Aa], sa = sVirt[(p << C1M) + Bb];
+          acc = acc + pqt_extract_distance(sa, sb, scv[p], lam);
+        }
+      }
+      if (act) drow[j] = acc;
+    }
   }
 }

@@ -15,7 +15,9 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 namespace pqt {
 
@@ -76,32 +78,42 @@ void ProTree::prepare2DDistSequence(int _maxCluster) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_resIdx(nullptr), d_resDist(nullptr), d_resCap(0), d_resCnt(nullptr), d_offsets(nullptr), d_packIdx(nullptr), d_packDist(nullptr),
-      h_stageIdx(nullptr), h_stageDist(nullptr), h_stageCap(0), h_offsets(nullptr), h_stageCntCap(0), d_copyStream(nullptr), d_evIdx(nullptr), d_evDist(nullptr), d_pool(nullptr),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_issued(0), d_collected(0), d_keepPadding(true), d_padIdx(nullptr), d_padDist(nullptr), d_padQN(0), d_padNVec(0),
+      d_legacyCopy(getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr),
+      d_packMin(getenv("PQT_FRONTEND_PACK_MIN_BYTES") ? (size_t)atoll(getenv("PQT_FRONTEND_PACK_MIN_BYTES")) : ((size_t)8 << 20)),
+      d_poolThreads(getenv("PQT_FRONTEND_THREADS") ? std::max(1, atoi(getenv("PQT_FRONTEND_THREADS"))) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()))),
+      d_pool(nullptr),
       d_lastTiming(), d_hashPrefix(nullptr),
       d_hashCounts(nullptr), d_hashSizeHeld(0), d_lineById(nullptr), d_lineByIdValid(false), d_device(0), d_w(2), d_lineParts(16), d_boundVectors(20000),
       d_boundBins(500), d_heurRows(0), d_N(0) {}
 
+void PerturbationProTree::releaseSlot(KnnSlot& s) {
+  if (s.d_resIdx) (void)hipFree(s.d_resIdx);
+  if (s.d_resDist) (void)hipFree(s.d_resDist);
+  if (s.d_resCnt) (void)hipFree(s.d_resCnt);
+  if (s.h_stageIdx) (void)hipHostFree(s.h_stageIdx);
+  if (s.h_stageDist) (void)hipHostFree(s.h_stageDist);
+  if (s.h_offsets) (void)hipHostFree(s.h_offsets);
+  if (s.d_offsets) (void)hipFree(s.d_offsets);
+  if (s.d_packIdx) (void)hipFree(s.d_packIdx);
+  if (s.d_packDist) (void)hipFree(s.d_packDist);
+  if (s.evOff) (void)hipEventDestroy(s.evOff);
+  if (s.evIdx) (void)hipEventDestroy(s.evIdx);
+  if (s.evDist) (void)hipEventDestroy(s.evDist);
+  if (s.stream) (void)hipStreamDestroy(s.stream);
+  pqt_index* keep = s.h;
+  s = KnnSlot();
+  s.h = keep;  // (the view of slot 1 dies with its owner: pqt_index_destroy of the index)
+}
+
 void PerturbationProTree::releaseDeviceScratch() {
-  if (d_resIdx) (void)hipFree(d_resIdx);
-  if (d_resDist) (void)hipFree(d_resDist);
-  if (d_resCnt) (void)hipFree(d_resCnt);
-  if (h_stageIdx) (void)hipHostFree(h_stageIdx);
-  if (h_stageDist) (void)hipHostFree(h_stageDist);
-  if (h_offsets) (void)hipHostFree(h_offsets);
-  if (d_offsets) (void)hipFree(d_offsets);
-  if (d_packIdx) (void)hipFree(d_packIdx);
-  if (d_packDist) (void)hipFree(d_packDist);
-  h_offsets = nullptr; d_offsets = nullptr; d_packIdx = nullptr; d_packDist = nullptr;
-  if (d_evIdx) (void)hipEventDestroy(d_evIdx);
-  if (d_evDist) (void)hipEventDestroy(d_evDist);
-  if (d_copyStream) (void)hipStreamDestroy(d_copyStream);
-  d_resCnt = nullptr; h_stageIdx = nullptr; h_stageDist = nullptr; h_stageCap = 0; h_stageCntCap = 0;
-  d_copyStream = nullptr; d_evIdx = d_evDist = nullptr;
+  for (KnnSlot& s : d_slots) releaseSlot(s);
+  d_issued = d_collected = 0;
+  d_padIdx = nullptr;
   if (d_hashPrefix) (void)hipFree(d_hashPrefix);
   if (d_hashCounts) (void)hipFree(d_hashCounts);
   if (d_lineById) (void)hipFree(d_lineById);
-  d_resIdx = nullptr; d_resDist = nullptr; d_resCap = 0; d_hashPrefix = d_hashCounts = nullptr; d_hashSizeHeld = 0;
+  d_hashPrefix = d_hashCounts = nullptr; d_hashSizeHeld = 0;
   d_lineById = nullptr; d_lineByIdValid = false;
 }
 
@@ -114,46 +126,44 @@ PerturbationProTree::~PerturbationProTree() {
 }
 
 // result buffers of queryKNN live as long as the object and only grow (the reference allocates and frees all scratch per
-// batch, PerturbationProTree.cu:8201-8238,8315-8321 -- the overhead SURVEY App. C lists first)
-void PerturbationProTree::ensureResultBuffers(size_t _n) {
-  if (_n <= d_resCap) return;
-  if (d_resIdx) (void)hipFree(d_resIdx);
-  if (d_resDist) (void)hipFree(d_resDist);
-  d_resIdx = nullptr; d_resDist = nullptr; d_resCap = 0;
-  if (hipMalloc((void**)&d_resIdx, _n * 4) != hipSuccess || hipMalloc((void**)&d_resDist, _n * 4) != hipSuccess)
-    throw std::runtime_error("device allocation failed");
-  d_resCap = _n;
-}
-
-// queryKNN's packed hand-over: pinned host staging and device buffers for the packed rows and their offsets (grown on demand, alive as
-// long as the object), the copy stream and its two events
-void PerturbationProTree::ensureStaging(size_t _n, size_t _qn) {
-  if (!d_copyStream) {
-    if (hipStreamCreateWithFlags(&d_copyStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d_evIdx, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d_evDist, hipEventDisableTiming) != hipSuccess)
+// batch, PerturbationProTree.cu:8201-8238,8315-8321 -- the overhead SURVEY App. C lists first); staging = queryKNN's packed hand-over: pinned
+// host staging and device buffers for the packed rows and their offsets
+void PerturbationProTree::ensureSlot(KnnSlot& s, size_t _n, size_t _qn, bool staging) {
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.evOff, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.evIdx, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.evDist, hipEventDisableTiming) != hipSuccess)
       throw std::runtime_error("stream / event creation failed");
   }
-  if (_n > h_stageCap) {
-    if (h_stageIdx) (void)hipHostFree(h_stageIdx);
-    if (h_stageDist) (void)hipHostFree(h_stageDist);
-    if (d_packIdx) (void)hipFree(d_packIdx);
-    if (d_packDist) (void)hipFree(d_packDist);
-    h_stageIdx = nullptr; h_stageDist = nullptr; d_packIdx = nullptr; d_packDist = nullptr; h_stageCap = 0;
-    // (the packed rows of a batch that takes this path fill at most half of the padded size; the staging is sized for the worst case once)
-    if (hipHostMalloc((void**)&h_stageIdx, _n * 4, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&h_stageDist, _n * 4, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc((void**)&d_packIdx, _n * 4) != hipSuccess || hipMalloc((void**)&d_packDist, _n * 4) != hipSuccess)
-      throw std::runtime_error("staging allocation failed");
-    h_stageCap = _n;
+  if (_n > s.resCap) {
+    if (s.d_resIdx) (void)hipFree(s.d_resIdx);
+    if (s.d_resDist) (void)hipFree(s.d_resDist);
+    s.d_resIdx = nullptr; s.d_resDist = nullptr; s.resCap = 0;
+    if (hipMalloc((void**)&s.d_resIdx, _n * 4) != hipSuccess || hipMalloc((void**)&s.d_resDist, _n * 4) != hipSuccess)
+      throw std::runtime_error("device allocation failed");
+    s.resCap = _n;
   }
-  if (_qn + 1 > h_stageCntCap) {
-    if (h_offsets) (void)hipHostFree(h_offsets);
-    if (d_offsets) (void)hipFree(d_offsets);
-    if (d_resCnt) (void)hipFree(d_resCnt);
-    h_offsets = nullptr; d_offsets = nullptr; d_resCnt = nullptr; h_stageCntCap = 0;
-    if (hipHostMalloc((void**)&h_offsets, (_qn + 1) * 4, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&d_offsets, (_qn + 1) * 4) != hipSuccess ||
-        hipMalloc((void**)&d_resCnt, (_qn + 1) * 4) != hipSuccess)
+  if (!staging) return;
+  if (_n > s.stageCap) {
+    if (s.h_stageIdx) (void)hipHostFree(s.h_stageIdx);
+    if (s.h_stageDist) (void)hipHostFree(s.h_stageDist);
+    if (s.d_packIdx) (void)hipFree(s.d_packIdx);
+    if (s.d_packDist) (void)hipFree(s.d_packDist);
+    s.h_stageIdx = nullptr; s.h_stageDist = nullptr; s.d_packIdx = nullptr; s.d_packDist = nullptr; s.stageCap = 0;
+    // (the packed rows of a batch that takes this path fill at most half of the padded size; the staging is sized for the worst case once)
+    if (hipHostMalloc((void**)&s.h_stageIdx, _n * 4, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&s.h_stageDist, _n * 4, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&s.d_packIdx, _n * 4) != hipSuccess || hipMalloc((void**)&s.d_packDist, _n * 4) != hipSuccess)
       throw std::runtime_error("staging allocation failed");
-    h_stageCntCap = _qn + 1;
+    s.stageCap = _n;
+  }
+  if (_qn + 1 > s.cntCap) {
+    if (s.h_offsets) (void)hipHostFree(s.h_offsets);
+    if (s.d_offsets) (void)hipFree(s.d_offsets);
+    if (s.d_resCnt) (void)hipFree(s.d_resCnt);
+    s.h_offsets = nullptr; s.d_offsets = nullptr; s.d_resCnt = nullptr; s.cntCap = 0;
+    if (hipHostMalloc((void**)&s.h_offsets, (_qn + 1) * 4, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&s.d_offsets, (_qn + 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&s.d_resCnt, (_qn + 1) * 4) != hipSuccess)
+      throw std::runtime_error("staging allocation failed");
+    s.cntCap = _qn + 1;
   }
 }
 
@@ -191,7 +201,7 @@ void PerturbationProTree::prepareDistSequence(int _maxCluster, int _groupParts) 
 void PerturbationProTree::prepare2DDistSequence(int _maxCluster) {
   if (d_multi) { if (pqt_multi_build_heuristic_2d(d_multi, (uint32_t)_maxCluster) != PQT_OK) throw std::runtime_error(pqt_multi_last_error()); }
   else ProTree::prepare2DDistSequence(_maxCluster);
-  d_heurRows = 65536;
+  d_heurRows = (uint32_t)std::min<uint64_t>(65536, (uint64_t)_maxCluster * (uint64_t)_maxCluster);  // what the library holds (pqt_index_build_heuristic_2d)
 }
 
 void PerturbationProTree::uploadLines(size_t _N) {
@@ -204,8 +214,10 @@ void PerturbationProTree::setTree(uint _c1, uint _c2, const float* _cb1, const f
   d_nClusters = _c1; d_nClusters2 = _c2;
   h_codeBook.assign(_cb1, _cb1 + (size_t)_c1 * d_dim);
   h_codeBook2.assign(_cb2, _cb2 + (size_t)_c1 * _c2 * d_dim);
-  if (d_idx) { pqt_index_destroy(d_idx); d_idx = nullptr; }
+  if (d_idx) { pqt_index_destroy(d_idx); d_idx = nullptr; }   // (the view of slot 1 is destroyed with it)
   if (d_multi) { pqt_multi_destroy(d_multi); d_multi = nullptr; }
+  for (KnnSlot& sl : d_slots) { sl.h = nullptr; sl.busy = false; }
+  d_issued = d_collected = 0;
   pqt_params prm = {d_dim, d_p, _c1, _c2, std::min(d_w, _c1), d_lineParts};
   if (d_devices.size() > 1) {
     if (pqt_multi_create(&prm, (int)d_devices.size(), d_devices.data(), &d_multi) != PQT_OK ||
@@ -642,95 +654,143 @@ namespace {
 inline void fillStream32(void* p, size_t n, uint32_t v) {
   uint32_t* w = static_cast<uint32_t*>(p);
   size_t i = 0;
+#if defined(__SSE2__)
   while (i < n && (reinterpret_cast<uintptr_t>(w + i) & 15)) w[i++] = v;
   const __m128i x = _mm_set1_epi32((int)v);
   for (; i + 4 <= n; i += 4) _mm_stream_si128(reinterpret_cast<__m128i*>(w + i), x);
-  for (; i < n; ++i) w[i] = v;
+#endif
+  for (; i < n; ++i) w[i] = v;  // (no SSE2: plain stores)
+}
+inline void fillFence() {
+#if defined(__SSE2__)
+  _mm_sfence();
+#endif
 }
 double msSince(const std::chrono::steady_clock::time_point& t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 }  // namespace
 
 // Same contract as the reference (PerturbationProTree.cu:8179-8183, 8278-8281): the two vectors are resized to _QN * _nVec and every
 // row is padded (here: id 0xffffffff, distance +inf).  Round 3 copied the whole padded arrays with two synchronous copies -- 134 MB per
-// 4096-query batch at _nVec = 4096, ~82 % of it padding, 2.4 ms at the PCIe rate against 0.4 ms of kernels.  Now, for large sparse
-// results: the filled prefixes are packed on the device (pqt_compact_results), only they cross PCIe (into pinned staging owned by the
-// object) while a few host threads write the padding with streaming stores, and the same threads then scatter the packed rows.
-// Small or dense results (every row full, e.g. _nVec = 100) are copied straight into the caller's vectors as before.
+// 4096-query batch at _nVec = 4096, ~82 % of it padding, 2.4 ms at the PCIe rate against 0.4 ms of kernels.  For large sparse results
+// the filled prefixes are packed on the device (pqt_compact_results), only they cross PCIe (into pinned staging owned by the object)
+// while a few host threads write the padding -- only where the previous hand-over into the same vectors left entries (setKeepPadding) --
+// and the same threads then scatter the packed rows.  Small or dense results (every row full, e.g. _nVec = 100) are copied straight
+// into the caller's vectors.  queryKNN = queryKNNAsync + queryKNNCollect.
 void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec) {
-  const auto tAll = std::chrono::steady_clock::now();
+  queryKNNCollect(queryKNNAsync(_Q, _QN, _nVec), _resIdx, _resDist);
+}
+
+int PerturbationProTree::queryKNNAsync(const float* _Q, uint _QN, uint _nVec) {
+  if (d_issued - d_collected >= 2) throw std::runtime_error("queryKNNAsync: two batches are in flight already (collect one first)");
+  const auto t0 = std::chrono::steady_clock::now();
   pqt_index* h = handle();
   ensureHeuristic(d_boundBins);
+  const int si = (int)(d_issued & 1u);
+  KnnSlot& s = d_slots[si];
+  if (s.busy) throw std::runtime_error("queryKNNAsync: slot still holds an uncollected batch");
   const size_t n = (size_t)_QN * _nVec;
+  s.QN = _QN; s.nVec = _nVec; s.compact = false; s.issueMs = 0;
+  s.busy = true;
+  ++d_issued;
+  if (!_QN || !_nVec) return si;
+  if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+  // the packed hand-over pays for itself on large results only (two extra kernels, one extra round trip, thread wake-ups)
+  s.compact = !d_legacyCopy && n * 8 >= d_packMin && n <= 0xffffffffull;
+  ensureSlot(s, n, _QN, s.compact);
+  uint* cnt = s.compact ? s.d_resCnt : nullptr;
+  if (d_multi) {
+    // several devices: pqt_multi_query runs the batch on the multi handle's own streams and is waited for here (one batch at a time)
+    s.h = h;
+    if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error());
+  } else {
+    if (si == 0) s.h = h;
+    else if (!s.h) check(pqt_index_create_view(h, &s.h), "pqt_index_create_view");
+    check(pqt_query(s.h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, s.stream, 0), "queryKNN");
+  }
+  if (s.compact) {
+    // offsets + packed rows + the copy of the offsets behind the query on the slot's stream; nothing is waited for here
+    check(pqt_compact_results(s.h, _QN, _nVec, s.d_resIdx, s.d_resDist, s.d_resCnt, s.d_offsets, s.d_packIdx, s.d_packDist, s.stream, 0), "pqt_compact_results");
+    if (hipMemcpyAsync(s.h_offsets, s.d_offsets, ((size_t)_QN + 1) * 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipEventRecord(s.evOff, s.stream) != hipSuccess)
+      throw std::runtime_error("D2H copy failed");
+  }
+  s.issueMs = msSince(t0);
+  return si;
+}
+
+void PerturbationProTree::queryKNNCollect(int _ticket, std::vector<uint>& _resIdx, std::vector<float>& _resDist) {
+  if (_ticket < 0 || _ticket > 1 || !d_slots[_ticket].busy) throw std::runtime_error("queryKNNCollect: no such batch in flight");
+  if (_ticket != (int)(d_collected & 1u)) throw std::runtime_error("queryKNNCollect: batches are collected in the order they were issued");
+  const auto tAll = std::chrono::steady_clock::now();
+  KnnSlot& s = d_slots[_ticket];
+  const uint _QN = s.QN, _nVec = s.nVec;
+  const size_t n = (size_t)_QN * _nVec;
+  s.busy = false;
+  ++d_collected;
   double hostMs = 0;
   {
     const auto t = std::chrono::steady_clock::now();
-    if (_resIdx.size() != n) _resIdx.resize(n);    // (value-initialises only what is new: a caller that reuses its vectors pays once)
-    if (_resDist.size() != n) _resDist.resize(n);
+    if (_resIdx.size() != n) { _resIdx.resize(n); d_padIdx = nullptr; }   // (value-initialises only what is new: a caller that reuses its vectors pays once)
+    if (_resDist.size() != n) { _resDist.resize(n); d_padIdx = nullptr; }
     hostMs += msSince(t);
   }
   d_lastTiming = CallTiming();
   if (!_QN || !_nVec) return;
   if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-  ensureResultBuffers(n);
-  const bool legacyCopy = getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr;  // measurement only (bench.py's "legacy_copy" leg): always the whole-array copy
-  // the packed hand-over pays for itself on large results only (two extra kernels, one extra round trip, thread wake-ups)
-  static const size_t packMin = getenv("PQT_FRONTEND_PACK_MIN_BYTES") ? (size_t)atoll(getenv("PQT_FRONTEND_PACK_MIN_BYTES")) : ((size_t)8 << 20);  // (tests lower it)
-  const bool tryCompact = !legacyCopy && n * 8 >= packMin && n <= 0xffffffffull;
-  if (tryCompact) ensureStaging(n, _QN);
   auto t = std::chrono::steady_clock::now();
-  uint* cnt = tryCompact ? d_resCnt : nullptr;
-  // (several devices: pqt_multi_query runs on the multi handle's own stream, not on the stream of shard 0's handle that the compaction
-  // below is enqueued on -- it is waited for here)
-  if (d_multi) { if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error()); }
-  else check(pqt_query(h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, d_resIdx, d_resDist, cnt, nullptr, tryCompact ? 0 : 1), "queryKNN");
   size_t total = n;
-  if (tryCompact) {
-    // offsets + packed rows behind the query on the handle's stream (NULL = the same stream pqt_query used); one synchronisation
-    check(pqt_compact_results(h, _QN, _nVec, d_resIdx, d_resDist, d_resCnt, d_offsets, d_packIdx, d_packDist, nullptr, 1), "pqt_compact_results");
-    d_lastTiming.kernels_ms = msSince(t);
-    t = std::chrono::steady_clock::now();
-    if (hipMemcpyAsync(h_offsets, d_offsets, ((size_t)_QN + 1) * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipStreamSynchronize(d_copyStream) != hipSuccess)
-      throw std::runtime_error("D2H copy failed");
-    total = h_offsets[_QN];
-    d_lastTiming.d2h_ms = msSince(t);
-  } else d_lastTiming.kernels_ms = msSince(t);
-  if (!tryCompact || total * 2 > n) {
+  if (s.compact) {
+    if (hipEventSynchronize(s.evOff) != hipSuccess) throw std::runtime_error("queryKNN: the batch failed on the device");
+    d_lastTiming.kernels_ms = s.issueMs + msSince(t);  // issue + what was left of the kernels when the caller came to collect
+    total = s.h_offsets[_QN];
+  } else {
+    if (hipStreamSynchronize(s.stream) != hipSuccess) throw std::runtime_error("queryKNN: the batch failed on the device");
+    d_lastTiming.kernels_ms = s.issueMs + msSince(t);
+  }
+  if (!s.compact || total * 2 > n) {
     // dense (or small) result: the device arrays go straight into the caller's vectors
     t = std::chrono::steady_clock::now();
-    d2h(_resIdx.data(), d_resIdx, n * 4);
-    d2h(_resDist.data(), d_resDist, n * 4);
+    d2h(_resIdx.data(), s.d_resIdx, n * 4);
+    d2h(_resDist.data(), s.d_resDist, n * 4);
+    d_padIdx = nullptr;  // (the row lengths of this hand-over are not known here)
     d_lastTiming.d2h_ms += msSince(t);
     d_lastTiming.host_ms = hostMs;
-    d_lastTiming.total_ms = msSince(tAll);
-    d_lastTiming.d2h_bytes = 2 * n * 4 + (tryCompact ? ((size_t)_QN + 1) * 4 : 0);
+    d_lastTiming.total_ms = s.issueMs + msSince(tAll);
+    d_lastTiming.d2h_bytes = 2 * n * 4 + (s.compact ? ((size_t)_QN + 1) * 4 : 0);
     d_lastTiming.columns = _nVec;
     d_lastTiming.packed = false;
     return;
   }
   t = std::chrono::steady_clock::now();
   if (total) {
-    if (hipMemcpyAsync(h_stageIdx, d_packIdx, total * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipEventRecord(d_evIdx, d_copyStream) != hipSuccess ||
-        hipMemcpyAsync(h_stageDist, d_packDist, total * 4, hipMemcpyDeviceToHost, d_copyStream) != hipSuccess || hipEventRecord(d_evDist, d_copyStream) != hipSuccess)
+    if (hipMemcpyAsync(s.h_stageIdx, s.d_packIdx, total * 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipEventRecord(s.evIdx, s.stream) != hipSuccess ||
+        hipMemcpyAsync(s.h_stageDist, s.d_packDist, total * 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipEventRecord(s.evDist, s.stream) != hipSuccess)
       throw std::runtime_error("D2H copy failed");
   }
-  if (!d_pool) d_pool = new HostPool((int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())));
+  if (!d_pool) d_pool = new HostPool(d_poolThreads);
   uint* const oi = _resIdx.data(); float* const od = _resDist.data();
-  const uint* const off = h_offsets; const size_t nv = _nVec, qn = _QN;
+  const uint* const off = s.h_offsets; const size_t nv = _nVec, qn = _QN;
+  // the padding this storage already holds (left by the previous hand-over into the very same vectors): only what that batch filled
+  // beyond this batch's prefix is written again
+  const bool known = d_keepPadding && d_padIdx == oi && d_padDist == od && d_padQN == _QN && d_padNVec == _nVec && h_padCnt.size() == qn;
+  if (h_padCnt.size() != qn) h_padCnt.assign(qn, 0u);
+  uint* const prev = h_padCnt.data();
   // phase A (while the packed rows are in flight): the padding of both arrays
   d_pool->run_all([=](int tid, int nt) {
     for (size_t r = qn * tid / nt; r < qn * (tid + 1) / nt; ++r) {
       const size_t c = off[r + 1] - off[r];
-      fillStream32(oi + r * nv + c, nv - c, 0xffffffffu);
-      fillStream32(od + r * nv + c, nv - c, 0x7f800000u);
+      const size_t end = known ? std::max<size_t>(c, prev[r]) : nv;
+      if (end > c) { fillStream32(oi + r * nv + c, end - c, 0xffffffffu); fillStream32(od + r * nv + c, end - c, 0x7f800000u); }
+      prev[r] = (uint)c;
     }
-    _mm_sfence();
+    fillFence();
   });
+  d_padIdx = oi; d_padDist = od; d_padQN = _QN; d_padNVec = _nVec;
   hostMs += msSince(t);
   t = std::chrono::steady_clock::now();
-  if (total && (hipEventSynchronize(d_evIdx) != hipSuccess || hipEventSynchronize(d_evDist) != hipSuccess)) throw std::runtime_error("D2H copy failed");
+  if (total && (hipEventSynchronize(s.evIdx) != hipSuccess || hipEventSynchronize(s.evDist) != hipSuccess)) throw std::runtime_error("D2H copy failed");
   d_lastTiming.d2h_ms += msSince(t);
   t = std::chrono::steady_clock::now();
-  const uint* const si = h_stageIdx; const float* const sd = h_stageDist;
+  const uint* const si = s.h_stageIdx; const float* const sd = s.h_stageDist;
   // phase B: the packed rows into their places
   d_pool->run_all([=](int tid, int nt) {
     for (size_t r = qn * tid / nt; r < qn * (tid + 1) / nt; ++r) {
@@ -740,7 +800,7 @@ void PerturbationProTree::queryKNN(std::vector<uint>& _resIdx, std::vector<float
   });
   hostMs += msSince(t);
   d_lastTiming.host_ms = hostMs;
-  d_lastTiming.total_ms = msSince(tAll);
+  d_lastTiming.total_ms = s.issueMs + msSince(tAll);
   d_lastTiming.d2h_bytes = ((size_t)_QN + 1) * 4 + 2 * total * 4;
   d_lastTiming.columns = (uint)(total / _QN);
   d_lastTiming.packed = true;

@@ -144,6 +144,20 @@ class PerturbationProTree : public ProTree {
   /** _Q is a DEVICE pointer (like the reference), results are resized to _QN*_nVec (PerturbationProTree.cu:8182-8183).
    *  Unused slots: id 0xffffffff, distance +inf (the reference pads with 1e7). */
   void queryKNN(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN, uint _nVec);
+  /** Two batches in flight behind the same contract (no reference counterpart: its loop, tool_query.cpp:152-160, answers one batch at a
+   *  time).  queryKNNAsync enqueues the whole batch -- traversal, rerank, packing of the filled prefixes, the copy of the row lengths -- on
+   *  one of TWO slots (the index and a view of it, pqt_index_create_view: own scratch, own stream, own result and staging buffers) and
+   *  returns a ticket without waiting; queryKNNCollect(ticket, ..) waits for that batch and hands it over exactly like queryKNN (which
+   *  is queryKNNAsync + queryKNNCollect).  A caller that issues batch i + 1 before it collects batch i has batch i + 1's kernels running
+   *  under batch i's copies and host-side scatter.  At most two tickets are outstanding; tickets are collected in the order they were
+   *  issued.  _Q must stay valid until the ticket is collected.  With several devices (setDevices) the batch runs at issue time. */
+  int queryKNNAsync(const float* _Q, uint _QN, uint _nVec);
+  void queryKNNCollect(int _ticket, std::vector<uint>& _resIdx, std::vector<float>& _resDist);
+  /** The padding of a row (id 0xffffffff, distance +inf behind its filled prefix) is remembered per result storage: a caller that hands
+   *  the SAME two vectors back with the same shape -- the reference's loop does, tool_query.cpp:149-154 -- gets only the slots re-padded
+   *  that the previous batch filled beyond the new one's prefix (110 MB of padding per 4096 x 4096 call otherwise, 1.1 of the call's
+   *  1.6 ms).  false: always write the whole padding (for callers that write into the vectors between calls).  Default true. */
+  void setKeepPadding(bool _on) { d_keepPadding = _on; d_padIdx = nullptr; }
   /** same with line codes "in host memory": the codes live in HBM here, _hlines is ignored (kept for signature parity) */
   void queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,
                           uint _nVec, const float* _hlines);
@@ -194,8 +208,6 @@ class PerturbationProTree : public ProTree {
   void ensureHeuristic(uint rows);
   void check(int rc, const char* what);
 
-  void ensureResultBuffers(size_t _n);
-  void ensureStaging(size_t _n, size_t _qn);
   void releaseDeviceScratch();
 
   void uploadLines(size_t _N);
@@ -204,12 +216,26 @@ class PerturbationProTree : public ProTree {
   pqt_index* d_idx;
   pqt_multi* d_multi;           // several devices: the shards live here and d_idx stays null
   std::vector<int> d_devices;
-  // persistent device buffers (grown on demand, freed in the destructor): results of queryKNN, dense hashed getters
-  uint* d_resIdx; float* d_resDist; size_t d_resCap;
-  uint* d_resCnt; uint* d_offsets; uint* d_packIdx; float* d_packDist;  // list lengths, row offsets and packed rows of the last batch (device)
-  uint* h_stageIdx; float* h_stageDist; size_t h_stageCap;              // pinned host staging of the packed rows
-  uint* h_offsets; size_t h_stageCntCap;
-  hipStream_t d_copyStream; hipEvent_t d_evIdx, d_evDist;
+  // one batch in flight: the handle that runs it, its stream, its device result arrays and host staging (grown on demand, freed in the
+  // destructor), and what queryKNNCollect needs to know about the batch
+  struct KnnSlot {
+    pqt_index* h = nullptr;                                   // slot 0: the index (or the multi handle's first shard); slot 1: a view of the index
+    uint* d_resIdx = nullptr; float* d_resDist = nullptr; size_t resCap = 0;
+    uint* d_resCnt = nullptr; uint* d_offsets = nullptr; uint* d_packIdx = nullptr; float* d_packDist = nullptr;  // list lengths, row offsets, packed rows (device)
+    uint* h_stageIdx = nullptr; float* h_stageDist = nullptr; size_t stageCap = 0;                               // pinned host staging of the packed rows
+    uint* h_offsets = nullptr; size_t cntCap = 0;
+    hipStream_t stream = nullptr; hipEvent_t evOff = nullptr, evIdx = nullptr, evDist = nullptr;
+    bool busy = false; uint QN = 0, nVec = 0; bool compact = false; double issueMs = 0;
+  };
+  KnnSlot d_slots[2]; unsigned d_issued, d_collected;
+  void ensureSlot(KnnSlot& s, size_t _n, size_t _qn, bool staging);
+  void releaseSlot(KnnSlot& s);
+  // padding memory (setKeepPadding): the storage the last hand-over padded, its shape and the filled prefix of every row
+  bool d_keepPadding; const uint* d_padIdx; const float* d_padDist; uint d_padQN, d_padNVec; std::vector<uint> h_padCnt;
+  // environment switches, read ONCE at construction: PQT_FRONTEND_LEGACY_COPY (any value: always the whole-array copy -- bench.py's
+  // "legacy_copy" leg), PQT_FRONTEND_PACK_MIN_BYTES (smallest result, in bytes, that takes the packed hand-over; default 8 MiB; tests lower it),
+  // PQT_FRONTEND_THREADS (host threads of the scatter / padding pool, default min(8, hardware threads))
+  bool d_legacyCopy; size_t d_packMin; int d_poolThreads;
   HostPool* d_pool;                                                      // host threads that write the padding and scatter the packed rows
   CallTiming d_lastTiming;
   uint* d_hashPrefix; uint* d_hashCounts; uint d_hashSizeHeld;

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--out", default="gpurun_out/r05_shared_ab.json")
     ap.add_argument("--knobs", default="20000,500;4096,4096")
+    ap.add_argument("--modes", default="0,1")
     a = ap.parse_args()
     pkg = importlib.import_module("product-quantization-tree_amd")
     w = bench.WORKLOADS[a.workload]
@@ -43,7 +44,8 @@ def main():
         idx.build_heuristic(bb)
         outs = {}
         row = {}
-        for mode in (0, 1):
+        modes = [int(x) for x in a.modes.split(",")]
+        for mode in modes:
             idx.set_option("shared_rows", mode)
             idx.set_option("stage_timing", 1)
             oi = torch.empty((qn, k), dtype=torch.int32, device=dev)
@@ -64,8 +66,20 @@ def main():
                 print("[%d,%d] shared_rows=%d %s: wall %.3f ms/step  traverse %.3f  gap %.3f  rerank %.3f  (%s) fallbacks %d" %
                       (bv, bb, mode, "fresh" if fresh else "same ", wall, h[1], h[2], h[3], idx.last_path(), idx.stats()["filter_fallbacks"]), flush=True)
             idx.query_dev(batches[0], bv, bb, k, oi, od, oc, stream=stream, sync=True)
+            if os.environ.get("PQT_TSTAMP"):
+                import ctypes
+                ts = np.zeros((qn, 24), np.uint64)
+                L = pkg.lib()
+                L.pqt_debug_tstamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+                if L.pqt_debug_tstamps(idx.h, ts.ctypes.data, qn) == 0:
+                    r = ts[:, 9:14].astype(np.int64)
+                    tot = r[:, 4] & 0xffffffff
+                    x = ts[:, 16:20].astype(np.int64)
+                    print("[tstamp] mode %d per query (shader clocks, medians | means): total %d | %d  rows wait %d | %d  adc+filter %d | %d  flush %d | %d  set-up %d | %d  band %d | %d  out %d | %d  candidates %d; sum/3072 slots %d" %
+                          (mode, np.median(tot), tot.mean(), np.median(r[:, 1]), r[:, 1].mean(), np.median(r[:, 2]), r[:, 2].mean(), np.median(r[:, 3]), r[:, 3].mean(),
+                           np.median(x[:, 0]), x[:, 0].mean(), np.median(x[:, 1]), x[:, 1].mean(), np.median(x[:, 2]), x[:, 2].mean(), np.median(x[:, 3]), tot.sum() // 3072), flush=True)
             outs[mode] = (oi.cpu().numpy().copy(), od.cpu().numpy().view(np.uint32).copy(), oc.cpu().numpy().copy())
-        same = all(np.array_equal(outs[0][j], outs[1][j]) for j in range(3))
+        same = all(np.array_equal(outs[modes[0]][j], outs[modes[-1]][j]) for j in range(3))
         row["identical"] = bool(same)
         print("[%d,%d] results identical: %s" % (bv, bb, same), flush=True)
         res["knobs_%d_%d" % (bv, bb)] = row

@@ -113,7 +113,7 @@ class OracleShardEngine:
             out_dist[qi] = torch.from_numpy(d[order])
 
 
-def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", bin_cap=None, pipelined=False):
+def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", bin_cap=None, pipelined=False, nq=7):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -124,7 +124,7 @@ def _worker(rank, world, port, q, exchange="alltoall", traversal="replicated", b
         n = fx.oracle.num_vectors
         lo, hi = sh.shard_range(rank, world, n)
         eng = OracleShardEngine(fx, lo, hi)
-        queries = torch.from_numpy(fx.queries[:7])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded
+        queries = torch.from_numpy(fx.queries[:nq])  # 7 % 2 != 0 and 7 % 3 != 0: the last query slice is padded (8 ranks: 13 queries, the last rank's slice is EMPTY)
         k, bv, bb = 20, 300, 100
         # a small capacity: some queries' lists overflow and take the traverse-it-yourself fallback
         timer = sh.ExchangeTimer(cuda=False)
@@ -286,4 +286,23 @@ def test_gloo_two_whole_batches_in_flight(world, exchange, traversal):
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("exchange,traversal,bin_cap,pipelined,nq", [("alltoall", "sharded", 256, False, 13), ("allgather", "replicated", None, False, 13),
+                                                                    ("alltoall", "sharded", 3, "batches", 13), ("alltoall", "sharded", None, True, 7)])
+def test_gloo_eight_ranks(exchange, traversal, bin_cap, pipelined, nq):
+    """BASELINE configs[3]'s world size: 8 ranks, a query count that is not a multiple of 8 -- 13 queries: slices of
+    ceil(13 / 8) = 2, rank 6 owns one query, rank 7 none; 7 queries: slices of 1, rank 7 none --, the 256-entry bin lists, the small ones
+    whose overflow sends queries to the traverse-it-yourself fallback, one batch at a time, two whole batches and two half batches in flight."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + (os.getpid() % 2000) + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (17 if bin_cap == 256 else 0) + (23 if pipelined is True else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, bin_cap, pipelined, nq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
     assert sorted(res) == [(r, True) for r in range(world)]

@@ -49,9 +49,14 @@ def test_cfg3_100m_properties_and_variant_identity(big100m, bv, bb):
     pkg, w, idx, meta, queries = big100m
     ids, dist, cnt = run(idx, queries, bv, bb, 100)
     path = idx.last_path()
-    assert "rerank=mode2-nw12-runs" in path.split() and "traverse=fused" in path, path
+    # (20000, 500): the shared-row pass is the automatic choice (bound_vectors reaches past the first long bin); (4096, 4096): the
+    # wave-per-query filter kernel
+    want = "rerank=mode2-nw12-runs-shared" if 2 * bv >= meta["max_bin"] else "rerank=mode2-nw12-runs"
+    assert want in path.split() and "traverse=fused" in path, path
     st = idx.stats()
-    assert st["filter_fallbacks"] == 0
+    # queries handed back to the exact kernels: near-tie bands beyond the filter's 256 slots -- and, with the shared-row pass, the queries
+    # whose run list did not fit its hand-over; a handful at most
+    assert st["filter_fallbacks"] <= 20
     assert int(cnt.astype(np.int64).sum()) == st["candidates"]
     assert int(cnt.max()) <= bv + meta["max_bin"] and float(cnt.mean()) > 10000  # the rerank really works on long lists
     n_valid = np.minimum(cnt, 100)
@@ -64,11 +69,13 @@ def test_cfg3_100m_properties_and_variant_identity(big100m, bv, bb):
     ids10, dist10, cnt10 = run(idx, queries, bv, bb, 10)
     assert np.array_equal(ids10, ids[:, :10]) and np.array_equal(dist10.view(np.uint32), dist[:, :10].view(np.uint32)) and np.array_equal(cnt10, cnt)
     for opt, val, back, expect in (("exact_filter", 0, 1, "rerank=wg-g"), ("bin_runs", 0, -1, "rerank=mode2-nw12"), ("balance", 0, -1, None), ("balance", 1, -1, None),
-                                   ("balance", 2, -1, None)):
+                                   ("balance", 2, -1, None), ("shared_rows", 0, -1, "rerank=mode2-nw12-runs"), ("shared_rows", 1, -1, "rerank=mode2-nw12-runs-shared")):
         idx.set_option(opt, val)
         try:
             b = run(idx, queries, bv, bb, 100)
-            if expect:
+            if expect and opt == "shared_rows":
+                assert expect in idx.last_path().split(), idx.last_path()
+            elif expect:
                 assert any(t.startswith(expect) for t in idx.last_path().split()) and "-runs" not in idx.last_path(), idx.last_path()
         finally:
             idx.set_option(opt, back)
