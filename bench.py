@@ -666,7 +666,7 @@ def live_issue(args, wl_name, bv, bb, k, kernel, launch_ms, n_cus):
     if means is None:
         return {"error": why}
     simds = 4 * n_cus
-    clk_ghz = torch.cuda.get_device_properties(0).clock_rate / 1e6 if torch.cuda.is_available() else 2.4
+    clk_ghz = 2.4  # MI355X_MICROARCH.md: max engine clock 2400 MHz (profiled runs measure 1.9 - 2.3 GHz effective: the fraction below is a lower bound)
     cycles = launch_ms * 1e-3 * clk_ghz * 1e9
     insts = means["SQ_INSTS"]
     return {"kernel": kernel, "instructions_per_launch": insts, "valu_share": means["SQ_INSTS_VALU"] / max(insts, 1.0),
@@ -962,7 +962,18 @@ def hbm_roofline_leg(ctx, args):
             leg["knobs_%d_%d" % (bv, bb)]["dram_side"] = dram_side_figures(ctx, args, W, bv, bb, args.k, steps, leg["knobs_%d_%d" % (bv, bb)])
         except Exception as e:
             leg["knobs_%d_%d" % (bv, bb)]["dram_side"] = {"error": repr(e)[:300]}
-        leg["knobs_%d_%d" % (bv, bb)].pop("_Rfresh", None)
+        kl_ = leg["knobs_%d_%d" % (bv, bb)]
+        kl_.pop("_Rfresh", None)
+        ds_ = kl_.get("dram_side", {})
+        if kl_["roofline"].get("kernel") == "pqt_k_sr_adc" and "distinct_rows_per_batch" in ds_:
+            # the shared-row pass reads a row ONCE per batch (per tile and chunk of <= 8 queries): its own lower bound of bytes = the distinct
+            # rows (code row + bias word) + the 4-byte filter distance it writes per candidate; `achieved` / `frac` above price SURVEY 8(d)'s
+            # formula (a row per candidate and query), which is why they can exceed the peak
+            once_ = ds_["distinct_rows_per_batch"] * (4 * W["w"]["LP"] + 4) + ds_["candidates_per_batch"] * 4
+            ms_ = max(kl_["roofline"]["avg_launch_ms"], 1e-9)
+            kl_["roofline"]["bytes_read_once_plus_written"] = once_
+            kl_["roofline"]["achieved_read_once"] = once_ / ms_ / 1e6
+            kl_["roofline"]["frac_read_once"] = once_ / ms_ / 1e6 / HBM_PEAK_GBS
     W["idx"].close()
     del W
     torch.cuda.empty_cache()
@@ -1221,16 +1232,23 @@ def main():
                                                 ("qn%d_nvec100" % qn, qn, 100, args.bv, args.bb)):
                 e_ = {}
                 for variant in ("compact", "legacy_copy"):
-                    if variant == "legacy_copy":
-                        os.environ["PQT_FRONTEND_LEGACY_COPY"] = "1"
-                    else:
-                        os.environ.pop("PQT_FRONTEND_LEGACY_COPY", None)
-                    fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=1, want_results=False)
+                    fe.set_legacy_copy(variant == "legacy_copy")
+                    fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=2, want_results=False)
                     tm_, _, _ = fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=5, want_results=False)
                     tm_["queries_per_sec"] = qn_ / (tm_["total_ms"] * 1e-3)
                     tm_["copy_share_of_call"] = tm_["d2h_ms"] / max(tm_["total_ms"], 1e-9)
                     e_[variant] = tm_
-                os.environ.pop("PQT_FRONTEND_LEGACY_COPY", None)
+                fe.set_legacy_copy(False)
+                # the padding memory switched off (every call writes the whole padding, round 4's form), and two batches in flight
+                # (queryKNNAsync / queryKNNCollect: the loop of host/tool_query.cpp), wall clock per batch over 8 batches
+                fe.set_keep_padding(False)
+                fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=1, want_results=False)
+                tm_, _, _ = fe.queryKNN(queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=5, want_results=False)
+                e_["compact_whole_padding_every_call"] = tm_
+                fe.set_keep_padding(True)
+                fe.queryKNN_inflight(queries.data_ptr(), queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=3, keep_padding=True, want_results=False)
+                ms_, _, _ = fe.queryKNN_inflight(queries.data_ptr(), queries.data_ptr(), qn_, nvec_, bv_, bb_, reps=8, keep_padding=True, want_results=False)
+                e_["two_batches_in_flight"] = {"ms_per_batch": ms_, "queries_per_sec": qn_ / (ms_ * 1e-3)}
                 leg[name_] = e_
             fe.close()
             out["config"]["frontend_queryKNN"] = leg
@@ -1284,6 +1302,51 @@ def main():
             out["config"]["h2d_included"] = {"queries_per_sec": qn / t_h, "ms_per_step": t_h * 1e3, "h2d_bytes_per_step": int(qh.numel() * 4),
                                              "results_identical": bool(torch.equal(oi1, out_idx) and torch.equal(od1, out_dist)),
                                              "what": "every step first copies its %d x %d f32 queries from pinned host memory on the launch stream (no stage events); results stay in HBM" % (qn, w["D"])}
+            # two batches in flight like `value` -- consecutive steps alternate between the index and its view, each on its
+            # own stream with its own device query buffer: the copy of one batch crosses PCIe under the other batch's kernels
+            if "view" in W and "slot_stream" in W:
+                view2, s2 = W["view"], W["slot_stream"]
+                qd2 = torch.empty_like(queries)
+                oi2, od2, oc2 = torch.empty_like(out_idx), torch.empty_like(out_dist), torch.empty_like(out_cnt)
+                view2.set_option("stage_timing", 0)
+                idx.set_option("stage_timing", 0)
+                calls2 = [0]
+
+                def step_h2d2():
+                    if calls2[0] & 1:
+                        with torch.cuda.stream(s2):
+                            qd2.copy_(qh, non_blocking=True)
+                        view2.query_dev(qd2, args.bv, args.bb, k, oi2, od2, oc2, stream=s2.cuda_stream)
+                    else:
+                        qd.copy_(qh, non_blocking=True)
+                        idx.query_dev(qd, args.bv, args.bb, k, oi1, od1, oc1, stream=stream)
+                    calls2[0] += 1
+                t_h2 = time_steps(step_h2d2, lambda: torch.cuda.synchronize(dev), 4, args.steps) / args.steps
+                idx.set_option("stage_timing", 1)
+                out["config"]["h2d_included"]["two_batches_in_flight"] = {
+                    "queries_per_sec": qn / t_h2, "ms_per_step": t_h2 * 1e3,
+                    "results_identical": bool(torch.equal(oi1, out_idx) and torch.equal(od1, out_dist) and torch.equal(oi2, out_idx) and torch.equal(od2, out_dist)),
+                    "what": "the same steps alternating between the index and its view on two streams, each copying its own batch on its own stream"}
+                # zero copy: the batch stays in the pinned host buffer (device-visible host memory) and the traversal kernel reads its 512-byte query
+                # vectors over PCIe itself -- unlike the copy engine's transfers (which do not overlap the other slot's kernels on this stack:
+                # scripts/r05_h2d_overlap.py, copies only 0.09 + kernels 0.12 = the 0.27 ms of the variant above) these reads are ordinary loads
+                # of a kernel and pass under the other batch's rerank
+                calls3 = [0]
+
+                def step_zero():
+                    if calls3[0] & 1:
+                        view2.query_dev(qh, args.bv, args.bb, k, oi2, od2, oc2, stream=s2.cuda_stream)
+                    else:
+                        idx.query_dev(qh, args.bv, args.bb, k, oi1, od1, oc1, stream=stream)
+                    calls3[0] += 1
+                idx.set_option("stage_timing", 0)
+                t_z = time_steps(step_zero, lambda: torch.cuda.synchronize(dev), 4, args.steps) / args.steps
+                idx.set_option("stage_timing", 1)
+                out["config"]["h2d_included"]["zero_copy_two_batches_in_flight"] = {
+                    "queries_per_sec": qn / t_z, "ms_per_step": t_z * 1e3,
+                    "results_identical": bool(torch.equal(oi1, out_idx) and torch.equal(od1, out_dist) and torch.equal(oi2, out_idx) and torch.equal(od2, out_dist)),
+                    "what": "no copy at all: every step's query pointer is the pinned HOST buffer, the traversal reads it over PCIe; steps alternate between the index and its view"}
+                del qd2, oi2, od2, oc2
             del qh, qd, oi1, od1, oc1
         except Exception as e:
             out["config"]["h2d_included"] = {"error": repr(e)[:200]}

@@ -23,6 +23,13 @@ def lib():
         L.pqtfe_destroy.argtypes = [C.c_void_p]
         L.pqtfe_destroy.restype = None
         L.pqtfe_queryKNN.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqtfe_queryKNN_inflight.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pqtfe_set_keep_padding.argtypes = [C.c_void_p, C.c_int]
+        L.pqtfe_set_keep_padding.restype = None
+        L.pqtfe_set_legacy_copy.argtypes = [C.c_void_p, C.c_int]
+        L.pqtfe_set_legacy_copy.restype = None
+        L.pqtfe_scribble.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.pqtfe_scribble.restype = None
         _LIB = L
     return _LIB
 
@@ -61,3 +68,24 @@ class FrontEnd:
             raise RuntimeError("pqtfe_queryKNN: " + lib().pqtfe_last_error().decode())
         tm = dict(zip(("total_ms", "kernels_ms", "d2h_ms", "host_ms", "d2h_bytes", "columns", "packed"), t.tolist()))
         return tm, oi, od
+
+    def queryKNN_inflight(self, q_dev_ptr, q_dev_ptr2, qn, nvec, bv, bb, reps=2, keep_padding=True, want_results=True):
+        """reps batches through queryKNNAsync / queryKNNCollect with two in flight (batches alternate between the two query arrays);
+        returns (wall ms per batch, idx, dist of the last batch)."""
+        t = np.zeros(1, np.float64)
+        oi = np.empty((qn, nvec), np.uint32) if want_results else None
+        od = np.empty((qn, nvec), np.float32) if want_results else None
+        rc = lib().pqtfe_queryKNN_inflight(self.h, q_dev_ptr, q_dev_ptr2, qn, nvec, bv, bb, reps, int(keep_padding), t.ctypes.data,
+                                           oi.ctypes.data if want_results else None, od.ctypes.data if want_results else None)
+        if rc:
+            raise RuntimeError("pqtfe_queryKNN_inflight: " + lib().pqtfe_last_error().decode())
+        return float(t[0]), oi, od
+
+    def set_keep_padding(self, on):
+        lib().pqtfe_set_keep_padding(self.h, int(on))
+
+    def set_legacy_copy(self, on):
+        lib().pqtfe_set_legacy_copy(self.h, int(on))
+
+    def scribble(self, nvec, col, value):
+        lib().pqtfe_scribble(self.h, nvec, col, value)

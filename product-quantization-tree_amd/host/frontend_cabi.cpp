@@ -4,6 +4,8 @@
 // surface is the class (host/pqt/PerturbationProTree.hh) and the C-ABI under it (include/pqt_hip.h).
 #include <hip/hip_runtime_api.h>
 #include <string.h>
+#include <chrono>
+#include <stdexcept>
 #include <string>
 #include <vector>
 #include "pqt/PerturbationProTree.hh"
@@ -62,6 +64,39 @@ int pqtfe_queryKNN(void* h, const float* q_dev, uint32_t qn, uint32_t nvec, uint
     if (out_dist) memcpy(out_dist, f->dist.data(), f->dist.size() * 4);
     return 0;
   } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// the same `reps` batches with TWO in flight (queryKNNAsync / queryKNNCollect, the loop of host/tool_query.cpp): batch r + 1 is issued before
+// batch r is collected; the batches alternate between q_dev and q_dev2 (q_dev2 may equal q_dev).  wall_ms[0] = wall clock per batch over the
+// whole loop; the vectors of the LAST batch (q_dev2 when reps is even) go to out_idx / out_dist.  keep_padding: setKeepPadding.
+int pqtfe_queryKNN_inflight(void* h, const float* q_dev, const float* q_dev2, uint32_t qn, uint32_t nvec, uint32_t bv, uint32_t bb, int reps, int keep_padding,
+                            double* wall_ms, uint32_t* out_idx, float* out_dist) {
+  try {
+    Fe* f = static_cast<Fe*>(h);
+    f->t.setBounds(bv, bb);
+    f->t.setKeepPadding(keep_padding != 0);
+    if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("device");
+    const auto t0 = std::chrono::steady_clock::now();
+    int pending = -1;
+    for (int r = 0; r < reps; ++r) {
+      const int tk = f->t.queryKNNAsync((r & 1) ? q_dev2 : q_dev, qn, nvec);
+      if (pending >= 0) f->t.queryKNNCollect(pending, f->idx, f->dist);
+      pending = tk;
+    }
+    if (pending >= 0) f->t.queryKNNCollect(pending, f->idx, f->dist);
+    if (wall_ms) wall_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
+    if (out_idx) memcpy(out_idx, f->idx.data(), f->idx.size() * 4);
+    if (out_dist) memcpy(out_dist, f->dist.data(), f->dist.size() * 4);
+    return 0;
+  } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+void pqtfe_set_keep_padding(void* h, int on) { static_cast<Fe*>(h)->t.setKeepPadding(on != 0); }
+void pqtfe_set_legacy_copy(void* h, int on) { static_cast<Fe*>(h)->t.setLegacyCopy(on != 0); }
+// writes `value` into slot `col` of every row of the wrapper's result vectors (a caller that scribbles on them between calls: tests)
+void pqtfe_scribble(void* h, uint32_t nvec, uint32_t col, uint32_t value) {
+  Fe* f = static_cast<Fe*>(h);
+  for (size_t i = col; i < f->idx.size(); i += nvec) f->idx[i] = value;
 }
 
 }  // extern "C"

@@ -78,7 +78,7 @@ void ProTree::prepare2DDistSequence(int _maxCluster) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_issued(0), d_collected(0), d_keepPadding(true), d_padIdx(nullptr), d_padDist(nullptr), d_padQN(0), d_padNVec(0),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_issued(0), d_collected(0), d_lastSlot(0), d_keepPadding(true), d_padIdx(nullptr), d_padDist(nullptr), d_padQN(0), d_padNVec(0),
       d_legacyCopy(getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr),
       d_packMin(getenv("PQT_FRONTEND_PACK_MIN_BYTES") ? (size_t)atoll(getenv("PQT_FRONTEND_PACK_MIN_BYTES")) : ((size_t)8 << 20)),
       d_poolThreads(getenv("PQT_FRONTEND_THREADS") ? std::max(1, atoi(getenv("PQT_FRONTEND_THREADS"))) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()))),
@@ -685,7 +685,9 @@ int PerturbationProTree::queryKNNAsync(const float* _Q, uint _QN, uint _nVec) {
   const auto t0 = std::chrono::steady_clock::now();
   pqt_index* h = handle();
   ensureHeuristic(d_boundBins);
-  const int si = (int)(d_issued & 1u);
+  // nothing in flight: slot 0 (a caller of the synchronous queryKNN never touches the view); one batch in flight: the other slot
+  const int si = (d_issued == d_collected) ? 0 : 1 - d_lastSlot;
+  d_lastSlot = si;
   KnnSlot& s = d_slots[si];
   if (s.busy) throw std::runtime_error("queryKNNAsync: slot still holds an uncollected batch");
   const size_t n = (size_t)_QN * _nVec;
@@ -719,7 +721,7 @@ int PerturbationProTree::queryKNNAsync(const float* _Q, uint _QN, uint _nVec) {
 
 void PerturbationProTree::queryKNNCollect(int _ticket, std::vector<uint>& _resIdx, std::vector<float>& _resDist) {
   if (_ticket < 0 || _ticket > 1 || !d_slots[_ticket].busy) throw std::runtime_error("queryKNNCollect: no such batch in flight");
-  if (_ticket != (int)(d_collected & 1u)) throw std::runtime_error("queryKNNCollect: batches are collected in the order they were issued");
+  if (d_issued - d_collected == 2 && _ticket == d_lastSlot) throw std::runtime_error("queryKNNCollect: batches are collected in the order they were issued");
   const auto tAll = std::chrono::steady_clock::now();
   KnnSlot& s = d_slots[_ticket];
   const uint _QN = s.QN, _nVec = s.nVec;

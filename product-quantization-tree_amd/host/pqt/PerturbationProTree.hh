@@ -158,6 +158,8 @@ class PerturbationProTree : public ProTree {
    *  that the previous batch filled beyond the new one's prefix (110 MB of padding per 4096 x 4096 call otherwise, 1.1 of the call's
    *  1.6 ms).  false: always write the whole padding (for callers that write into the vectors between calls).  Default true. */
   void setKeepPadding(bool _on) { d_keepPadding = _on; d_padIdx = nullptr; }
+  /** measurement only (bench.py's "legacy_copy" leg): always hand over with two whole-array copies (round 3's form; = PQT_FRONTEND_LEGACY_COPY at construction) */
+  void setLegacyCopy(bool _on) { d_legacyCopy = _on; }
   /** same with line codes "in host memory": the codes live in HBM here, _hlines is ignored (kept for signature parity) */
   void queryBIGKNNRerank2(std::vector<uint>& _resIdx, std::vector<float>& _resDist, const float* _Q, uint _QN,
                           uint _nVec, const float* _hlines);
@@ -227,7 +229,7 @@ class PerturbationProTree : public ProTree {
     hipStream_t stream = nullptr; hipEvent_t evOff = nullptr, evIdx = nullptr, evDist = nullptr;
     bool busy = false; uint QN = 0, nVec = 0; bool compact = false; double issueMs = 0;
   };
-  KnnSlot d_slots[2]; unsigned d_issued, d_collected;
+  KnnSlot d_slots[2]; unsigned d_issued, d_collected; int d_lastSlot;
   void ensureSlot(KnnSlot& s, size_t _n, size_t _qn, bool staging);
   void releaseSlot(KnnSlot& s);
   // padding memory (setKeepPadding): the storage the last hand-over padded, its shape and the filled prefix of every row

@@ -33,6 +33,7 @@ int main(int argc, char* argv[]) {
   F.def("boundbins", "500", "query(., boundBins)");
   F.def("hashed", "0", "1: load the CUDA library's dump family even when a .bins dump exists");
   F.def("nvec", "4096", "results per query (queryKNN _nVec)");
+  F.def("sync", "0", "1: one batch at a time (queryKNN) like the reference's loop; 0: the next batch is issued before the current one is collected");
   F.def("gpus", "1", "range-shard the database over the devices 0 .. gpus-1 of this node (one process, one handle)");
   F.def("devices", "", "explicit device list for the shards, e.g. 0,1,2,3 (overrides --gpus / --device; a device may repeat)");
   if (!F.parse(argc, argv)) return 1;
@@ -83,10 +84,29 @@ int main(int argc, char* argv[]) {
     std::vector<uint> resIdx, all((size_t)qn * nvec);
     std::vector<float> resDist;
     auto t0 = std::chrono::steady_clock::now();
+    // the reference's loop (tool_query.cpp:152-160) answers one batch at a time; here batch i + 1 is issued before batch i is collected, so
+    // its kernels run under batch i's copies and the host-side scatter (PerturbationProTree::queryKNNAsync / queryKNNCollect); --sync 1 =
+    // the reference's form
+    const bool syncLoop = F.num("sync") != 0;
+    int pending = -1;
+    size_t pendA = 0;
     for (size_t a = 0; a < qn; a += 4096) {
       const uint len = (uint)std::min<size_t>(4096, qn - a);
-      ppt.queryKNN(resIdx, resDist, qd + a * dim, len, nvec);
-      std::copy(resIdx.begin(), resIdx.end(), all.begin() + a * nvec);
+      if (syncLoop) {
+        ppt.queryKNN(resIdx, resDist, qd + a * dim, len, nvec);
+        std::copy(resIdx.begin(), resIdx.end(), all.begin() + a * nvec);
+        continue;
+      }
+      const int tk = ppt.queryKNNAsync(qd + a * dim, len, nvec);
+      if (pending >= 0) {
+        ppt.queryKNNCollect(pending, resIdx, resDist);
+        std::copy(resIdx.begin(), resIdx.end(), all.begin() + pendA * nvec);
+      }
+      pending = tk; pendA = a;
+    }
+    if (pending >= 0) {
+      ppt.queryKNNCollect(pending, resIdx, resDist);
+      std::copy(resIdx.begin(), resIdx.end(), all.begin() + pendA * nvec);
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     (void)hipFree(qd);

@@ -397,3 +397,85 @@ def test_frontend_queryKNN_packed_handover_equals_engine_and_whole_array_copy(nv
     assert res["default"]["packed"] == 0.0  # 32 queries: below the 8 MB threshold
     if nvec == 4096:
         assert res["packed_two_shards"]["packed"] == 1.0
+
+
+def test_frontend_two_batches_in_flight_and_padding_memory():
+    """queryKNNAsync / queryKNNCollect (two batches in flight on the index and a view of it, the loop of host/tool_query.cpp)
+    and the padding memory of the hand-over (only the slots the previous batch filled beyond the new one's prefix are re-padded when the
+    caller hands the same vectors back, tool_query.cpp:149-154).  Two different batches alternate, so rows shrink and grow between
+    consecutive hand-overs into the same vectors: every collected batch must equal the engine's padded arrays bit for bit.  A caller that
+    writes into the padding between calls sees its bytes survive with the memory on and restored with setKeepPadding(false)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import importlib, os, sys, json
+        import numpy as np, torch
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        from common import fixture
+        fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
+        nvec = 4096
+        f = fixture("cfg2_small")
+        c = f.cfg
+        fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes, devices=(0,))
+        qa = torch.from_numpy(f.queries).cuda()
+        qb = torch.from_numpy(np.ascontiguousarray(f.queries[::-1] * 0.5 + 20.0)).cuda()
+        qn, bv, bb = qa.shape[0], 3000, 512
+        idx = f.hip_index()
+        idx.build_heuristic(bb)
+        def engine(q):
+            gi = torch.empty((qn, nvec), dtype=torch.int32, device="cuda"); gd = torch.empty((qn, nvec), dtype=torch.float32, device="cuda"); gc = torch.empty(qn, dtype=torch.int32, device="cuda")
+            idx.query_dev(q, bv, bb, nvec, gi, gd, gc, sync=True)
+            return gi.cpu().numpy().view(np.uint32), gd.cpu().numpy().view(np.uint32), gc.cpu().numpy()
+        ea, eb = engine(qa), engine(qb)
+        res = {"rows_differ": int((ea[2] != eb[2]).sum())}
+        for reps in (1, 2, 4, 5):
+            ms, oi, od = fe.queryKNN_inflight(qa.data_ptr(), qb.data_ptr(), qn, nvec, bv, bb, reps=reps, keep_padding=True)
+            want = ea if reps %% 2 == 1 else eb
+            res["inflight_%%d" %% reps] = bool(np.array_equal(oi, want[0]) and np.array_equal(od.view(np.uint32), want[1]))
+        # the synchronous call on top of the same slots, alternating batches into the same vectors
+        ok = True
+        for q, want in ((qa, ea), (qb, eb), (qa, ea), (qa, ea)):
+            tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=1)
+            ok &= bool(np.array_equal(oi, want[0]) and np.array_equal(od.view(np.uint32), want[1]) and tm["packed"] == 1.0)
+        res["sync_alternating"] = ok
+        # a caller that scribbles on the padding: survives with the memory on, repaired with it off
+        fe.scribble(nvec, nvec - 1, 7)
+        tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=1)
+        short = ea[2] < nvec
+        res["scribble_survives"] = bool((oi[short, nvec - 1] == 7).all() and np.array_equal(oi[:, :nvec - 1], ea[0][:, :nvec - 1]))
+        fe.set_keep_padding(False)
+        tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=1)
+        res["repaired"] = bool(np.array_equal(oi, ea[0]) and np.array_equal(od.view(np.uint32), ea[1]))
+        res["short_rows"] = int(short.sum())
+        print("RESULT " + json.dumps(res))
+    """ % (ROOT,))
+    env = dict(os.environ, PQT_FRONTEND_PACK_MIN_BYTES="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = __import__("json").loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r["rows_differ"] > 0 and r["short_rows"] > 0, r
+    assert all(v for k_, v in r.items() if k_ not in ("rows_differ", "short_rows")), r
+
+
+def test_tool_query_async_loop_equals_sync_loop(tmp_path):
+    """host/tool_query: the default loop (next batch issued before the current one is collected) prints the recall the one-batch-at-a-time loop
+    (--sync 1, the reference's form) prints; several batches (4096 queries each) so that both slots and the short last batch are used."""
+    os.chdir(tmp_path)
+    from common import sift_like
+    base = sift_like(30000, 128, 91)
+    queries = sift_like(9000, 128, 92)
+    write_umem("base.umem", base, np.uint8)
+    write_umem("query.umem", queries, np.uint8)
+    args = ["--basename", "db", "--dim", "128", "--p", "4", "--c1", "16", "--c2", "16", "--w", "2", "--lineparts", "16"]
+    out = subprocess.run([os.path.join(HOST, "tool_createdb")] + args + ["--dataset", "base.umem", "--train", "4000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    gt = np.zeros((queries.shape[0], 1), np.int32)
+    d2 = ((queries[:200, None, :] - base[None, :3000, :]) ** 2).sum(-1)  # (a partial ground truth is enough: both loops must print the same numbers)
+    gt[:200, 0] = d2.argmin(1)
+    write_umem("gt.imem", gt, np.int32)
+    outs = []
+    for sync in ("0", "1"):
+        o = subprocess.run([os.path.join(HOST, "tool_query")] + args + ["--queryset", "query.umem", "--groundtruth", "gt.imem", "--boundvectors", "2000", "--boundbins", "500",
+                                                                      "--nvec", "256", "--sync", sync], capture_output=True, text=True)
+        assert o.returncode == 0, o.stdout + o.stderr
+        outs.append([l for l in o.stdout.splitlines() if l.startswith("@R")])
+    assert outs[0] == outs[1] and len(outs[0]) == 6, outs
