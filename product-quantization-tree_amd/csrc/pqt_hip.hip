@@ -126,6 +126,26 @@ int uploadBins(pqt_index* idx, const std::vector<BinDesc>& bins, const std::vect
     if ((rc = devAlloc(&idx->d_filter, filt.size()))) return rc;
     HIPCHK(hipMemcpy(idx->d_filter, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
     idx->filterBits = fb;
+    // first level for the wide enumeration (pqt_k_traverse_f1): the bitmap folded to at most 2^19 bits = 64 KB of LDS, bit i = OR of the
+    // bits whose index starts with i; kept only while it still rejects most rows (at most ~40 % of its bits set)
+    idx->filter1Bits = 0;
+    if (idx->d_filter1) { (void)hipFree(idx->d_filter1); idx->d_filter1 = nullptr; }
+    {
+      const uint32_t f1 = std::min<uint32_t>(fb, 19u);
+      size_t nonEmpty = 0;
+      for (const BinDesc& b0 : bins) nonEmpty += b0.gcount != 0;
+      if (f1 >= 12 && (double)nonEmpty <= 0.5 * (double)((uint64_t)1 << f1)) {
+        std::vector<uint32_t> f1w((size_t)1 << (f1 - 5), 0u);
+        for (const BinDesc& b0 : bins) {
+          if (b0.gcount == 0) continue;
+          const uint32_t bit = pqt_hash_filter(b0.key, fb) >> (fb - f1);
+          f1w[bit >> 5] |= 1u << (bit & 31u);
+        }
+        if ((rc = devAlloc(&idx->d_filter1, f1w.size()))) return rc;
+        HIPCHK(hipMemcpy(idx->d_filter1, f1w.data(), f1w.size() * 4, hipMemcpyHostToDevice));
+        idx->filter1Bits = f1;
+      }
+    }
   }
   if ((rc = devAlloc(&idx->d_ids, localIds.size()))) return rc;
   if (!localIds.empty()) HIPCHK(hipMemcpy(idx->d_ids, localIds.data(), localIds.size() * 4, hipMemcpyHostToDevice));
@@ -438,7 +458,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                         (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                         emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
                         countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 3u,
-                        schedCntArg, idx->d_schedList, idx->curSchedCap, nullptr, nullptr, nullptr, 0u};
+                        schedCntArg, idx->d_schedList, idx->curSchedCap, nullptr, nullptr, nullptr, 0u,
+                        (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits};
       if (binsIn) {
         // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
         // shard's table, and the (normally empty) list of queries whose list overflowed at the sender traversed here
@@ -758,11 +779,11 @@ void pqt_index_destroy(pqt_index* idx) {
   for (auto& e : idx->evJoin) if (e) (void)hipEventDestroy(e);
   if (idx->isView) {  // the arrays of the index belong to the owner
     idx->d_cb1 = idx->d_cb2 = idx->d_coarse = idx->d_cb1L = idx->d_cb2T = nullptr; idx->d_heur = idx->d_heur8 = nullptr; idx->d_heur4 = nullptr; idx->d_seq2d = nullptr;
-    idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_codesX = idx->d_filter = nullptr; idx->d_bias = nullptr;
+    idx->d_table = nullptr; idx->d_lower = idx->d_ids = idx->d_codes = idx->d_codesBin = idx->d_codesGrp = idx->d_codesX = idx->d_filter = idx->d_filter1 = nullptr; idx->d_bias = nullptr;
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -808,6 +829,12 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "xcode") == 0) { idx->useXCode = value < 0 ? -1 : (value != 0); return PQT_OK; }
   // shared-row pass of the filtered rerank (pqt_shared_rows.h): -1 automatic (line stores of 1 GiB and more), 0 off, 1 on where the shape allows
   if (strcmp(name, "shared_rows") == 0) { idx->sharedRows = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  // first level of the presence bitmap in LDS for the wide enumeration (512 < bound_bins <= 4096, pqt_k_traverse_f1): 1 = on where it exists,
+  // 0 / -1 (default) off.  MEASURED AND NOT THE DEFAULT (scripts/r05_wide_ab.py, SIFT1M shape): (4096, 4096) traversal 0.205 -> 0.197 ms,
+  // (20000, 2048) 0.123 -> 0.147, (4096, 1024) 0.085 -> 0.116; 100 M: no change.  A query's enumeration takes half the clocks (133 k -> 72 k
+  // per query) but 8 wavefronts per CU behind the 64 KB copy instead of 15 answer exactly as many queries per clock: the wide mode is not
+  // bound by the probe rate of the 512 KB bitmap
+  if (strcmp(name, "filter_l1") == 0) { idx->useFilter1 = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
@@ -1228,13 +1255,13 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   memset(&v, 0, sizeof(v));
   v.dp = x->dp; v.prm = x->prm;
   const void* ps[] = {x->d_cb1, x->d_cb2, x->d_coarse, x->d_cb1L, x->d_cb2T, x->d_heur, x->d_heur8, x->d_heur4, x->d_table, x->d_lower, x->d_ids,
-                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter, x->d_codesX, x->d_seq2d};
+                      x->d_codes, x->d_codesBin, x->d_bias, x->d_codesGrp, x->d_filter, x->d_codesX, x->d_seq2d, x->d_filter1};
   for (size_t j = 0; j < sizeof(ps) / sizeof(ps[0]); ++j) v.p[j] = ps[j];
   v.u[0] = x->heurRows; v.u[1] = x->maxMultiIndex; v.u[2] = x->nIds; v.u[3] = x->nTotal; v.u[4] = x->nCodes; v.u[5] = x->idBase; v.u[6] = x->scratchBudget;
-  v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc;
+  v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc; v.w[5] = x->filter1Bits;
   v.f[0] = x->coarseMax;
   for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1244,13 +1271,13 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->d_cb1 = (float*)v.p[0]; t->d_cb2 = (float*)v.p[1]; t->d_coarse = (float*)v.p[2]; t->d_cb1L = (float*)v.p[3]; t->d_cb2T = (float*)v.p[4];
   t->d_heur = (uint16_t*)v.p[5]; t->d_heur8 = (uint16_t*)v.p[6]; t->d_heur4 = (uint32_t*)v.p[7];
   t->d_table = (PqtBinEntry*)v.p[8]; t->d_lower = (uint32_t*)v.p[9]; t->d_ids = (uint32_t*)v.p[10];
-  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15]; t->d_codesX = (uint32_t*)v.p[16]; t->d_seq2d = (uint32_t*)v.p[17];
+  t->d_codes = (uint32_t*)v.p[11]; t->d_codesBin = (uint32_t*)v.p[12]; t->d_bias = (float*)v.p[13]; t->d_codesGrp = (uint32_t*)v.p[14]; t->d_filter = (uint32_t*)v.p[15]; t->d_codesX = (uint32_t*)v.p[16]; t->d_seq2d = (uint32_t*)v.p[17]; t->d_filter1 = (uint32_t*)v.p[18];
   t->codesOwned = false;
   t->heurRows = v.u[0]; t->maxMultiIndex = v.u[1]; t->nIds = v.u[2]; t->nTotal = v.u[3]; t->nCodes = v.u[4]; t->idBase = v.u[5]; t->scratchBudget = (size_t)v.u[6];
-  t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4];
+  t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4]; t->filter1Bits = v.w[5];
   t->coarseMax = v.f[0];
   for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6];
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7];
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
@@ -1392,7 +1419,8 @@ int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t 
                             idx->d_segD, idx->d_segBin, idx->d_ovList, idx->d_ovCount,
                             (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                             nullptr, nullptr, nullptr, 0u, nullptr, (idx->dbg >> 5) & 3u,
-                            nullptr, nullptr, 0u, nullptr, nullptr, out_bins_dev, cap};
+                            nullptr, nullptr, 0u, nullptr, nullptr, out_bins_dev, cap,
+                            (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits};
     launchFusedTraversal(idx, targs, tp, qn, st, nullptr, nullptr);
   }
   HIPCHK(hipGetLastError());

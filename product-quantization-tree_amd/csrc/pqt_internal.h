@@ -99,6 +99,7 @@ struct pqt_index {
   uint32_t* d_srTable = nullptr; uint64_t srTableCap = 0; uint32_t* d_srPairs = nullptr; uint64_t srPairCap = 0; uint32_t* d_srBlocks = nullptr; uint64_t srBlockCap = 0;
   unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; const uint32_t* curPreOk = nullptr; const float* curPreQmax = nullptr;
   int sharedRows = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastShared = false;
+  uint32_t* d_filter1 = nullptr; uint32_t filter1Bits = 0; int useFilter1 = -1 /* -1 auto, 0 off, 1 on */;  // first level of the presence bitmap, folded for the LDS (wide enumeration)
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
   uint64_t* d_sortKeys = nullptr; uint64_t sortCap = 0;

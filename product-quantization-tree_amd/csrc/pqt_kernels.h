@@ -1922,6 +1922,9 @@ struct PqtTravArgs {
   // (visiting order), trailer word [gbinCap] = number of entries (0xffffffff: more than gbinCap, or the wide traversal's own
   // overflow -- the receiving shard traverses such a query itself) | global candidate count << 32; or null
   unsigned long long* gbins; uint32_t gbinCap;
+  // wide enumeration (He > 512), pqt_k_traverse_f1 only: first level of the presence bitmap, folded to 2^filter1Bits bits (bit i = OR of the
+  // 2^(filterBits - filter1Bits) bits of `filter` whose index starts with i) -- small enough for the LDS of a workgroup; or null
+  const uint32_t* filter1; uint32_t filter1Bits;
 };
 
 // the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
@@ -1942,7 +1945,8 @@ __host__ __device__ inline int pqt_shape_of(const PqtDevParams& d) {
 template <int WCR, bool SHARDED, bool P2 /* C1, C2, W, LP, D, S, SS, R all powers of two: shifts and masks instead of
                                             runtime integer divisions (~25 VALU each) and quarter-rate multiplies */,
           int SHAPE = 0>
-__device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const uint32_t q, unsigned char* const base, const uint32_t perWaveBytes) {
+__device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const uint32_t q, unsigned char* const base, const uint32_t perWaveBytes,
+                                                   const uint32_t* const sF1 = nullptr /* the workgroup's LDS copy of A.filter1 (pqt_k_traverse_f1), or null */) {
   const float* __restrict__ Q = A.Q; const float* __restrict__ cb1 = A.cb1; const float* __restrict__ cb2 = A.cb2;
   const float4* __restrict__ cb2T = A.cb2T; const PqtDevParams& prm = A.prm; const uint4* __restrict__ heur8 = A.heur8;
   const uint32_t He = A.He, Bv = A.Bv; const PqtBinEntry* __restrict__ table = A.table; const uint32_t* __restrict__ lower = A.lower;
@@ -2683,7 +2687,15 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
 #pragma unroll
           for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) gg += sSegB[PQT_MUL((uint32_t)p, WC, shWC) + ((w[r] >> (8 * p)) & 0xffu)];
           g[r] = gg;
-          f[r] = filter[pqt_hash_filter(gg, filterBits) >> 5];
+          const uint32_t hbit = pqt_hash_filter(gg, filterBits);
+          if (sF1) {
+            // first level in LDS: 4096 rows per query name ~1 % existing bins, and the word of the 512 KB bitmap behind every row was what
+            // bounded this mode (~190 G random 4-byte reads per second through the texture path); a clear first-level bit proves the word's
+            // bit clear, so only the rows that pass (the set fraction of the folded bitmap) still ask for it
+            const uint32_t i1 = hbit >> (filterBits - A.filter1Bits);
+            f[r] = ((sF1[i1 >> 5] >> (i1 & 31u)) & 1u) ? filter[hbit >> 5] : 0u;
+          } else
+          f[r] = filter[hbit >> 5];
         }
       };
       stageA(0, gA, fA);
@@ -2839,6 +2851,22 @@ __global__ __launch_bounds__(NW * 64, PQT_TR_WPS) void pqt_k_traverse(const PqtT
   if (q >= A.qn) return;
   if (A.qlist) { if (q >= *A.qcount) return; q = A.qlist[q]; }
   pqt_traverse_query<WCR, SHARDED, P2, SHAPE>(A, q, smem_raw + (size_t)wave * perWaveBytes, perWaveBytes);
+}
+
+// Wide enumeration with the first level of the presence bitmap in LDS: NW wavefronts (= queries) per workgroup share one copy of
+// A.filter1 in front of their private slices; everything else is pqt_k_traverse.
+template <int NW, int WCR, bool SHARDED, bool P2, int SHAPE = 0>
+__global__ __launch_bounds__(NW * 64, 2) void pqt_k_traverse_f1(const PqtTravArgs A, uint32_t perWaveBytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t f1Words = 1u << (A.filter1Bits - 5u);
+  uint32_t* const sF1 = reinterpret_cast<uint32_t*>(smem_raw);
+  for (uint32_t t = threadIdx.x; t < f1Words / 4; t += NW * 64) reinterpret_cast<uint4*>(sF1)[t] = reinterpret_cast<const uint4*>(A.filter1)[t];
+  __syncthreads();
+  uint32_t q = blockIdx.x * NW + wave;
+  if (q >= A.qn) return;
+  if (A.qlist) { if (q >= *A.qcount) return; q = A.qlist[q]; }
+  pqt_traverse_query<WCR, SHARDED, P2, SHAPE>(A, q, smem_raw + (size_t)f1Words * 4 + (size_t)wave * perWaveBytes, perWaveBytes, sF1);
 }
 
 // ---------------------------------------------------------------------------------------------------

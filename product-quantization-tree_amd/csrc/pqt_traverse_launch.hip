@@ -60,6 +60,25 @@ void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPl
 #define PQT_LAUNCH_TR(WCR) do { if (idx->sharded) { if (travP2) PQT_LAUNCH_TR1(WCR, true, true); else PQT_LAUNCH_TR1(WCR, true, false); } \
                                 else { if (travP2) PQT_LAUNCH_TR1(WCR, false, true); else PQT_LAUNCH_TR1(WCR, false, false); } } while (0)
   const int shape = travShape(idx, targs);
+#ifndef PQT_DEV_SIFT1M_ONLY
+  // wide enumeration at the two BASELINE shapes: kF1Waves wavefronts per workgroup behind one LDS copy of the bitmap's first level
+  constexpr int kF1Waves = 8;
+  if (tp.wide && targs.filter1 && targs.filter && (shape == 1 || shape == 2)) {
+    const size_t f1Bytes = (size_t)1 << (targs.filter1Bits - 3);
+    const size_t lds = f1Bytes + (size_t)kF1Waves * travPerWave;
+    if (lds <= kMaxLds) {
+      const uint32_t g1 = (waves + kF1Waves - 1) / kF1Waves;
+#define PQT_LAUNCH_F1(SH, SHAPEV)                                                                                              \
+      do { auto kern = pqt_k_traverse_f1<kF1Waves, 1, SH, true, SHAPEV>;                                                        \
+           if (pqtAllowLds((const void*)kern, lds) == PQT_OK) {                                                                  \
+             hipExtLaunchKernelGGL(kern, dim3(g1), dim3(kF1Waves * 64), (uint32_t)lds, st, ev0, ev1, 0u, targs, travPerWave);    \
+             return; } } while (0)
+      if (shape == 1) { if (idx->sharded) PQT_LAUNCH_F1(true, 1); else PQT_LAUNCH_F1(false, 1); }
+      else { if (idx->sharded) PQT_LAUNCH_F1(true, 2); else PQT_LAUNCH_F1(false, 2); }
+#undef PQT_LAUNCH_F1
+    }
+  }
+#endif
 #ifdef PQT_DEV_SIFT1M_ONLY
   // development builds (scripts/r04_devlib.sh): only the SIFT1M-shape instantiation; anything else launches nothing
   (void)d; (void)travP2;

@@ -1659,3 +1659,23 @@ def test_shared_row_pass_keeps_the_tie_cluster_fallback():
         assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
     finally:
         idx.close()
+
+
+@pytest.mark.parametrize("name", ["cfg2_small", "cfg3_small"])
+def test_wide_enumeration_with_the_lds_first_level_of_the_bitmap(name):
+    """Option "filter_l1" (pqt_k_traverse_f1, opt-in: measured no faster): the wide enumeration asks the folded first level of the presence bitmap
+    in LDS before the bitmap word itself; a clear first-level bit proves the bit clear, so nothing may change."""
+    f = fixture(name)
+    idx = f.hip_index()
+    try:
+        for bv, bb in ((400, 4096), (3000, 1024)):
+            if bb > f.heur.shape[0]:
+                idx.build_heuristic(bb)
+            a = idx.query(f.queries, bv, bb, 64)
+            idx.set_option("filter_l1", 1)
+            b = idx.query(f.queries, bv, bb, 64)
+            idx.set_option("filter_l1", 0)
+            assert "fused-wide" in idx.last_path(), idx.last_path()
+            assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2]), (bv, bb)
+    finally:
+        idx.close()
