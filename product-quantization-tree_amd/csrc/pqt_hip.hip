@@ -371,12 +371,13 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   }
   idx->curRuns = emitRuns;
   // shared-row pass in front of the filtered selection (configs[2]/[3] shape with bin runs).  Automatic choice: where the line store is far
-  // beyond the caches (the pass costs six small launches per chunk) AND the vector bound reaches past the first long bin of a query -- the
-  // pass wins by the visits of one query to the same (aliased) bin and by bins shared between queries; with bound_vectors below half the
-  // largest bin a query takes ~1.3 bins, hardly any twice (measured at 100 M: 3.27 against 4.98 ms per batch at (20000, 500), 2.97 against
-  // 2.88 at (4096, 4096): DESIGN.md section 4)
+  // beyond the caches (the pass costs eight small launches per chunk); on a range shard only when the vector bound reaches past the first
+  // long bin of a query -- the pass wins by the visits of one query to the same (aliased) bin and by bins shared between queries, and a
+  // shard's slices of the bins are short.  Measured at 100 M, ms per 10 k-query batch with / without: unsharded (20000, 500) 2.9 / 5.0,
+  // (4096, 4096) 2.77 / 2.89; one shard of eight, two batches in flight: (20000, 500) 0.69 / 0.82, (4096, 4096) 0.70 / 0.61
   const bool sharedPass = runsBig && useFilter && sharedRowsShape(idx) && !(idx->dbg & 0xffffu) &&
-                          (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30) && (uint64_t)Bv * 2 >= idx->maxBin));
+                          (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30) &&
+                                                    (!idx->sharded || (uint64_t)Bv * 2 >= idx->maxBin)));
   // X-code rows for the exact rerank with the LDS table at C1 = 32 (SIFT1M shape): a second copy of the line store with cheaper
   // address arithmetic (pqt_rs_query XC); not for stores beyond 16 GiB (the copy doubles their footprint) and not with bin runs
   bool xcode = idx->useXCode != 0 && fused && !useBias && !wgG && coarseLds && d.C1 == 32 && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !emitRuns &&
@@ -783,7 +784,7 @@ void pqt_index_destroy(pqt_index* idx) {
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1, idx->d_srKeys};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);

@@ -97,7 +97,7 @@ struct pqt_index {
   uint32_t curDynamic = 0; unsigned long long* curZero8 = nullptr; uint32_t* curPool = nullptr; uint32_t* curPoolNext = nullptr; uint32_t poolPos = 0; unsigned long long* d_schedList = nullptr; uint64_t schedCapQ = 0; uint32_t curSchedCap = 0;  // rerank schedule and next statistics block of the current chunk
   // shared-row pass of the filtered rerank (pqt_shared_rows.h; scratch of this handle): per-batch bin table, pair records, block sums, items
   uint32_t* d_srTable = nullptr; uint64_t srTableCap = 0; uint32_t* d_srPairs = nullptr; uint64_t srPairCap = 0; uint32_t* d_srBlocks = nullptr; uint64_t srBlockCap = 0;
-  unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; const uint32_t* curPreOk = nullptr; const float* curPreQmax = nullptr;
+  unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; unsigned long long* d_srKeys = nullptr; uint64_t srKeysCap = 0; const uint32_t* curPreOk = nullptr; const float* curPreQmax = nullptr;
   int sharedRows = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastShared = false;
   uint32_t* d_filter1 = nullptr; uint32_t filter1Bits = 0; int useFilter1 = -1 /* -1 auto, 0 off, 1 on */;  // first level of the presence bitmap, folded for the LDS (wide enumeration)
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)

@@ -890,6 +890,9 @@ struct PqtRsArgs {
   // distinct (bin, query) pair, the rows of a bin read once for all the queries of the batch that include it -- into
   // preDist[q * stride + visiting position]; preOk[q] != 0 marks the queries it covered (the others evaluate their rows here)
   const float* preDist; const uint32_t* preOk; const float* preQmax /* [q] largest entry of the query's L1virt table (pqt_k_sr_visits) */;
+  // PRE split in two launches (2: scan, 3: band): the scan leaves the <= 256 smallest filter keys of query q, ascending, in preKeys[q][256] and
+  // their number in preCnt[q] (0xffffffff: handed back); the band launch takes them from there
+  unsigned long long* preKeys; uint32_t* preCnt;
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -919,8 +922,9 @@ struct PqtRsArgs {
 //   instruction (the running sums of both in one packed add) -- every candidate's own sequence of roundings is unchanged: same bits.
 // NSLOT: 8-byte key slots of the wavefront (best list + pending buffer): 512 by default, 384 in the 16-wavefront configuration
 template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND,
-          bool PRE = false /* MODE 2 + RUNS, selection only (pqt_k_sr_select): the filter distances come from A.preDist (see PqtRsArgs), sVirt is the
-                                  query's table in GLOBAL memory (read by the band re-evaluation only), no row is fetched in the batch loop */>
+          int PRE = 0 /* != 0: MODE 2 / 0 + RUNS, selection only (pqt_k_sr_select): the filter distances come from A.preDist (see PqtRsArgs), no row is
+                         fetched in the batch loop; 1: the whole selection (sVirt may be the query's table in GLOBAL memory: only the band re-evaluation
+                         reads it); 2: the scan alone -- the best list goes to A.preKeys; 3: the band re-evaluation, sort and results alone, from A.preKeys */>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
                                              unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
@@ -970,13 +974,13 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       // a query the shared-row pass did not cover (its runs did not fit the hand-over, or its bins the pass's table) goes where the
       // queries with an overflowing near-tie band go: exact distances by a whole workgroup, then the MODE 0 selection (pqt_k_sr_exact_list)
       if (n && A.preOk[q] == 0u) {
-        if (lane == 0) A.fbList[atomicAdd(A.fbCount, 1u)] = q;
+        if (PRE != 3 && lane == 0) { A.fbList[atomicAdd(A.fbCount, 1u)] = q; if (PRE == 2) A.preCnt[q] = 0xffffffffu; }
         return;
       }
     }
   }
   const bool useRuns = kRuns && mRuns != 0xffffffffu;
-  constexpr bool usePre = PRE;
+  constexpr bool usePre = PRE != 0;
   const float* const preRow = PRE ? A.preDist + (size_t)q * stride : nullptr;
   (void)preRow;
   // PRE: a batch costs ~50 instructions here, so its distances must be on their way long before they are used: a queue of PRE_DEPTH
@@ -984,7 +988,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   constexpr int PRE_DEPTH = PRE ? 8 : 1;
   float preQ[PRE_DEPTH][UREQ];
   (void)preQ;
-  if constexpr (PRE) {
+  if constexpr (PRE != 0 && PRE != 3) {
     if (usePre) {
 #pragma unroll
       for (int dq = 0; dq < PRE_DEPTH; ++dq) {
@@ -1224,6 +1228,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     phase1 = false;
   };
 
+  if constexpr (PRE == 3) {
+    // the scan launch left the best list (ascending) in global memory
+    off0 = A.preCnt[q];
+    if (off0 == 0xffffffffu) return;  // handed back by the scan
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < off0) sKeys[e] = A.preKeys[(size_t)q * 256 + e]; }
+    __builtin_amdgcn_wave_barrier();
+  } else
   for (uint32_t base = 0;; base += 64 * U) {
     if (base < n) {
       if (tstamp) ts0 = __builtin_readcyclecounter();
@@ -1463,6 +1475,14 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
     }
     if (last) break;
+  }
+  if constexpr (PRE == 2) {
+    // scan launch: the best list (<= 256 keys, ascending after the final flush) goes to global memory for the band launch
+    static_assert(MODE == 2, "the split selection is the filtered one");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < off0) A.preKeys[(size_t)q * 256 + e] = sKeys[e]; }
+    if (lane == 0) A.preCnt[q] = off0;
+    return;
   }
   // results: first min(k, n) entries of the best list
   const uint32_t kk = n < k ? n : k;

@@ -94,14 +94,13 @@ int launchHandedBack(pqt_index* idx, hipStream_t st, const PqtRsArgs& rargs) {
 #ifndef PQT_SR_SEL_WGS
 #define PQT_SR_SEL_WGS 2
 #endif
+#ifndef PQT_SR_SEL_SPLIT
+#define PQT_SR_SEL_SPLIT 1
+#endif
 template <bool SH>
 static int launchSel(pqt_index* idx, hipStream_t st, const float* qL1virt, const uint32_t* nLocal,
                      uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
   constexpr int NW = PQT_SR_SEL_WAVES, LPV = 8, UV = 2;
-  auto kern = pqt_k_sr_select<NW, LPV, UV, SH, 6, false>;
-  const size_t lds = (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->curRunCap * 12);
-  int rc = allowLds(kern, lds);
-  if (rc) return rc;
   const double lp = idx->dp.LP;
   const float kappa = (float)(2.02 * (lp * lp + 8.0 * lp + 2.0) / 16777216.0);
   PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
@@ -110,8 +109,36 @@ static int launchSel(pqt_index* idx, hipStream_t st, const float* qL1virt, const
                   idx->d_fbList, idx->d_fbCount, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
   rargs.preDist = idx->d_candDist; rargs.preOk = idx->curPreOk; rargs.preQmax = idx->curPreQmax;
   HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
-  const uint32_t grid = std::min<uint32_t>((nq + NW - 1) / NW, (uint32_t)idx->numCUs * PQT_SR_SEL_WGS);
-  hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, rargs);
+  int rc;
+#if PQT_SR_SEL_SPLIT
+  // two launches: the scan over the distances (keys and run list in LDS only: more wavefronts per CU) and the band re-evaluation + results
+  // (table copy in LDS) -- the best lists travel through global memory (2 KB per query)
+  if ((rc = growArr(&idx->d_srKeys, &idx->srKeysCap, (uint64_t)nq * 257))) return rc;
+  rargs.preKeys = idx->d_srKeys; rargs.preCnt = reinterpret_cast<uint32_t*>(idx->d_srKeys + (size_t)nq * 256);
+  {
+    auto kern = pqt_k_sr_select<NW, LPV, UV, SH, 6, false, 2>;
+    const size_t lds = (size_t)NW * ((size_t)1024 * 8);  // the lean scan: 1024 key slots per wavefront, nothing else
+    if ((rc = allowLds(kern, lds))) return rc;
+    const uint32_t grid = std::min<uint32_t>((nq + NW - 1) / NW, (uint32_t)idx->numCUs * PQT_SR_SEL_WGS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, rargs);
+  }
+  {
+    constexpr int BW = 12;
+    auto kern = pqt_k_sr_select<BW, LPV, UV, SH, 6, false, 3>;
+    const size_t lds = (size_t)BW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->curRunCap * 12 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
+    if ((rc = allowLds(kern, lds))) return rc;
+    const uint32_t grid = std::min<uint32_t>((nq + BW - 1) / BW, (uint32_t)idx->numCUs);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(BW * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, rargs);
+  }
+#else
+  {
+    auto kern = pqt_k_sr_select<NW, LPV, UV, SH, 6, false>;
+    const size_t lds = (size_t)NW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->curRunCap * 12);
+    if ((rc = allowLds(kern, lds))) return rc;
+    const uint32_t grid = std::min<uint32_t>((nq + NW - 1) / NW, (uint32_t)idx->numCUs * PQT_SR_SEL_WGS);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, rargs);
+  }
+#endif
   return launchHandedBack(idx, st, rargs);
 }
 int launchSharedSelect(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,

@@ -284,20 +284,110 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_
   }
 }
 
+// 5a. the scan of the split selection: the <= 256 smallest filter keys (f32 key << 32 | visiting position) of query q out of the n distances
+// pqt_k_sr_adc wrote, by one wavefront.  pqt_rs_query's batch loop spends ~75 instructions per 64 candidates (64-bit keys, two candidates per
+// lane and round trip, its bookkeeping for rows it does not fetch here) and the selection launch was at the instruction-issue ceiling (37 k
+// instructions per 23 k-candidate query); here a lane takes FOUR consecutive distances per 16-byte request (four requests in flight), rejects
+// on the 32-bit key alone (anything above the current 256-th smallest key's high word cannot belong), and only the survivors get a 64-bit key
+// and a slot.  Same result: every key below the final 256-th smallest is kept, the exact radix select and the final sort are pqt_rs_query's.
+// sKeys: NSLOT 8-byte slots of this wavefront ([best <= 256 | pending]).
+template <int NSLOT>
+__device__ __forceinline__ void pqt_sr_scan_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys) {
+  const uint32_t lane = threadIdx.x & 63;
+  constexpr uint32_t BESTN = 256, SLOTS = NSLOT;
+  constexpr int RK = NSLOT / 64;
+  static_assert(BESTN + 256 <= SLOTS / 2 + 256 && SLOTS >= 768, "a block of 256 appended keys must fit behind the best list and a half-full pending area");
+  if (n && A.preOk[q] == 0u) {  // not covered by the pass: handed back like a query whose near-tie band overflows
+    if (lane == 0) { A.fbList[atomicAdd(A.fbCount, 1u)] = q; A.preCnt[q] = 0xffffffffu; }
+    return;
+  }
+  const float* const row = A.preDist + (size_t)q * A.stride;  // 256-byte aligned (the stride is a multiple of 64 floats)
+  uint32_t off0 = 0, npend = 0, tauHi = 0xffffffffu;
+  auto flush = [&](const bool final) {
+    uint32_t have = off0 + npend;
+    if (have > BESTN) {
+      uint64_t key[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) { const uint32_t e = r * 64 + lane; key[r] = (e < have) ? sKeys[e] : ~0ull; }
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t tau = pqt_wave_kth_u64<RK>(key, BESTN, reinterpret_cast<uint32_t*>(sKeys + BESTN));
+      tauHi = (uint32_t)(tau >> 32);
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
+        if (key[r] <= tau) sKeys[cnt + rk] = key[r];
+        cnt += tot;
+      }
+      have = BESTN;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (final) {
+      uint64_t key[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const uint32_t e = lane * 4 + r; key[r] = (e < have) ? sKeys[e] : ~0ull; }
+      pqt_wave_sort_u64<4>(key);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sKeys[lane * 4 + r] = key[r];
+      __builtin_amdgcn_wave_barrier();
+    }
+    npend = 0;
+    off0 = have;
+  };
+  constexpr int QD = 4;
+  float4 qv[QD];
+  const uint32_t lastQuad = n ? ((n - 1u) & ~3u) : 0u;
+#pragma unroll
+  for (int d = 0; d < QD; ++d) { const uint32_t j = ((uint32_t)d * 64u + lane) * 4u; qv[d] = *reinterpret_cast<const float4*>(row + (j < n ? j : lastQuad)); }
+  for (uint32_t base = 0; base < n; base += 256) {
+    const float4 v = qv[0];
+#pragma unroll
+    for (int d = 0; d + 1 < QD; ++d) qv[d] = qv[d + 1];
+    {  // (unconditional, clamped: the compiler must be able to count the requests in flight)
+      const uint32_t j = base + (uint32_t)QD * 256u + lane * 4u;
+      qv[QD - 1] = *reinterpret_cast<const float4*>(row + (j < n ? j : lastQuad));
+    }
+    const float c4[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t j0 = base + lane * 4u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t k32 = pqt_f2key(c4[c]);
+      const bool pass = j0 + c < n && k32 <= tauHi;
+      const unsigned long long m = __ballot(pass);
+      if (m) {  // (uniform)
+        const uint32_t rk = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pass) sKeys[off0 + npend + rk] = ((uint64_t)k32 << 32) | (j0 + c);
+        npend += (uint32_t)__popcll(m);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (off0 + npend + 256 > SLOTS) flush(false);
+  }
+  flush(true);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < off0) A.preKeys[(size_t)q * 256 + e] = sKeys[e]; }
+  if (lane == 0) A.preCnt[q] = off0;
+}
+
 // 5. selection: one wavefront per query over the distances of step 4 (pqt_rs_query PRE): no row is read before the band re-evaluation, the
 // query's table stays in global memory (the band reads ~k entries of it), so a wavefront needs its key slots and run list only -- 5 KB of LDS
 // instead of 12.5 KB, and none of the row registers of the evaluating kernel.
 // LIST: the queries of A.qlist (those the first selection handed back: not covered by the pass, or a near-tie band beyond its 256 slots),
 // MODE 0 over the EXACT distances pqt_k_sr_exact_list wrote for them.
-template <int NW, int LPV, int UREQ, bool SHARDED, int C1M, bool LIST>
+template <int NW, int LPV, int UREQ, bool SHARDED, int C1M, bool LIST, int PHASE = 1 /* 1 whole selection, 2 scan only, 3 band + results only (table copied to LDS) */>
 __global__ __launch_bounds__(NW * 64) void pqt_k_sr_select(const PqtRsArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M;
-  constexpr int NSLOT = PQT_RS_BEST + PQT_RS_PEND;
+  constexpr int SCANSLOT = 1024;  // PHASE 2: key slots of the lean scan (256 best + up to 768 pending: a flush every >= 512 survivors)
+  constexpr int NSLOT = PHASE == 2 ? SCANSLOT : PQT_RS_BEST + PQT_RS_PEND;
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  (void)lane;
   uint64_t* const sKeys = reinterpret_cast<uint64_t*>(smem_raw) + (size_t)wave * NSLOT;
   unsigned long long* const sRuns = reinterpret_cast<unsigned long long*>(smem_raw + (size_t)NW * NSLOT * 8) + (size_t)wave * (A.runCap + A.runCap / 2);
-  if constexpr (!LIST) {
+  float* const sTab = reinterpret_cast<float*>(smem_raw + (size_t)NW * ((size_t)NSLOT * 8 + (size_t)A.runCap * 12)) + (size_t)wave * LP * C1;  // PHASE 3 only
+  (void)sRuns; (void)sTab;
+  if constexpr (!LIST && PHASE != 3) {
     // (what the evaluating kernel does for the next call: statistics block and the schedule's registration block zeroed)
     if (blockIdx.x == 0 && threadIdx.x < 8 && A.zero8) A.zero8[threadIdx.x] = 0;
     if (blockIdx.x == 0 && A.poolNext) for (uint32_t t = threadIdx.x; t < 16u + 8u * PQT_SCHED_CLASSES; t += NW * 64) A.poolNext[t] = 0;
@@ -308,11 +398,25 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_sr_select(const PqtRsArgs A) {
   for (uint32_t e = slot; e < cnt; e += gridDim.x * NW) {
     const uint32_t q = LIST ? A.qlist[e] : e;
     uint32_t nN = 0;
-    float* const tableG = const_cast<float*>(A.qL1virt) + (size_t)q * LP * C1;
-    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, LIST ? 0 : 2, true, false, NSLOT, true>(A, q, A.nLocal[q], sKeys, tableG, A.coarse, 0xffffffffu, nN, slot, tiesAcc, sRuns);
+    float* table = const_cast<float*>(A.qL1virt) + (size_t)q * LP * C1;
+    if constexpr (PHASE == 3) {
+      // the band re-evaluation reads ~k x 2 LP entries of the table: from an LDS copy (3 x faster than gathering them from global memory)
+      constexpr uint32_t NV = LP * C1 / 4, IT = (NV + 63) / 64;
+      const float4* src4 = reinterpret_cast<const float4*>(table);
+      float4 tmp[IT];
+#pragma unroll
+      for (uint32_t x = 0; x < IT; ++x) { const uint32_t t = lane + 64 * x; tmp[x] = src4[t < NV ? t : 0]; }
+#pragma unroll
+      for (uint32_t x = 0; x < IT; ++x) { const uint32_t t = lane + 64 * x; if (t < NV) reinterpret_cast<float4*>(sTab)[t] = tmp[x]; }
+      __builtin_amdgcn_wave_barrier();
+      table = sTab;
+    }
+    if constexpr (PHASE == 2) pqt_sr_scan_query<SCANSLOT>(A, q, A.nLocal[q], sKeys);
+    else
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, LIST ? 0 : 2, true, false, NSLOT, PHASE>(A, q, A.nLocal[q], sKeys, table, A.coarse, 0xffffffffu, nN, slot, tiesAcc, sRuns);
     __builtin_amdgcn_wave_barrier();
   }
-  pqt_count_ties(&A.counters[3], tiesAcc);
+  if constexpr (PHASE != 2) pqt_count_ties(&A.counters[3], tiesAcc);
 }
 
 // 6. the queries the selection handed back: EXACT distances (the reference's association, term by term, p ascending: the sequence of the

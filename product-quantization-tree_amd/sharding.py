@@ -307,6 +307,8 @@ def sharded_query_pipelined(engines, dist, world, q, bv, bb, k, pbuf, exchange="
     fork.record(cur)
     for s_ in pbuf.streams:
         s_.wait_event(fork)
+        if q.is_cuda:
+            q.record_stream(s_)  # (the halves' streams read slices of q: see BatchesInFlight.step)
     for sidx in range(len(plans[0])):
         for i in range(2):
             with torch.cuda.stream(pbuf.streams[i]):
@@ -336,6 +338,7 @@ class BatchesInFlight:
         self.streams = [torch.cuda.Stream(device), torch.cuda.Stream(device)] if self.cuda else [None, None]
         self.n = 0
         self.last = None
+        self.done = [None, None]  # event behind the last step of each slot: ready(slot) / wait_slot(slot)
         if self.cuda:  # whatever the caller enqueued so far (the queries) is visible to both streams
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -351,8 +354,15 @@ class BatchesInFlight:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.streams[slot].wait_event(ev)
+            if q.is_cuda:
+                # the slot's stream reads q (and slices of it) after step() has returned: tell the caching allocator, so that a caller
+                # which drops or reuses the batch right away does not get its memory handed out while the slot still reads it
+                q.record_stream(self.streams[slot])
             with torch.cuda.stream(self.streams[slot]):
-                return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
+                out = sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
+            self.done[slot] = torch.cuda.Event()
+            self.done[slot].record(self.streams[slot])
+            return out
         return sharded_query(self.engines[slot], dist, world, q, bv, bb, k, self.bufs[slot], **kw)
 
     def wait(self):
@@ -363,6 +373,13 @@ class BatchesInFlight:
                 ev = torch.cuda.Event()
                 ev.record(s_)
                 cur.wait_event(ev)
+
+    def wait_slot(self, slot=None):
+        """The caller's current stream waits for the last step issued on `slot` (default: the most recent step): its views are then valid
+        for work enqueued on that stream; they are overwritten by the step after next."""
+        slot = self.last if slot is None else slot
+        if self.cuda and slot is not None and self.done[slot] is not None:
+            torch.cuda.current_stream().wait_event(self.done[slot])
 
     def result(self):
         b = self.bufs[self.last if self.last is not None else 0]
