@@ -1531,7 +1531,8 @@ int pqt_index_device_bytes(const pqt_index* idx, uint64_t* out8) {
   out8[4] = (idx->d_bias ? rows * 4 : 0) + rows * 4;                                    // row bias + member ids
   out8[5] = (idx->tableBits ? ((uint64_t)1 << idx->tableBits) * (sizeof(PqtBinEntry) + (idx->d_lower ? 4 : 0)) : 0) + (idx->filterBits ? ((uint64_t)1 << idx->filterBits) / 8 : 0);  // bin table + presence bitmap
   out8[6] = (uint64_t)d.C1 * d.D * 8 + (uint64_t)d.P * d.C1 * d.C2 * d.S * 8 + (uint64_t)d.LP * d.C1 * d.C1 * 4 + idx->heurRows * 22;  // codebooks (+ re-tiled copies), coarse table, heuristic
-  out8[7] = idx->candCap * (idx->sharded ? 12 : 8) + (uint64_t)idx->qCap * ((uint64_t)d.LP * d.C1 * 4 + (uint64_t)d.P * d.WC * 8 + 32) + idx->sortCap * 8;  // scratch arena of this handle
+  out8[7] = idx->candCap * (idx->sharded ? 12 : 8) + (uint64_t)idx->qCap * ((uint64_t)d.LP * d.C1 * 4 + (uint64_t)d.P * d.WC * 8 + 32) + idx->sortCap * 8 +
+            idx->srTableCap * 4 + idx->srPairCap * 4 + idx->srBlockCap * 4 + idx->srItemCap * 8 + idx->srKeysCap * 8;  // scratch arena of this handle (the shared-row pass's tables and lists included)
   return PQT_OK;
 }
 
