@@ -83,6 +83,10 @@ def test_default_line_carries_the_hbm_roofline_leg():
     assert "two whole batches in flight" in d["config"]["pipeline"] and "two batches in flight" in d["config"]["kernel_path"]
     one = d["config"]["one_batch_at_a_time"]
     assert "error" not in one and one["results_identical"] is True and one["queries_per_sec"] > 0
+    # both figures at the top level, each labelled; the view slot's outputs were compared with slot 0
+    assert d["value_one_batch_at_a_time"] == one["queries_per_sec"] and d["ms_per_step_one_batch_at_a_time"] == one["ms_per_step"] and "two whole" in d["value_is"]
+    assert d["config"]["view_slot_results_identical"] is True
+    assert d["roofline"]["bound"] == "issue"  # the 64 MB line store of configs[1] is cache resident: `frac` is the contract's figure, not the bound
     # `roofline` prices the kernel alone on the device (the one-batch-at-a-time steps); the overlapped launches of `value` ride along
     fl = d["roofline"]["in_flight"]
     assert fl["kernel"] == d["roofline"]["kernel"] and fl["avg_launch_ms"] > 0 and d["roofline"]["avg_launch_ms"] > 0 and len(fl["all_kernels"]) == 2
@@ -94,6 +98,7 @@ def test_default_line_carries_the_hbm_roofline_leg():
     for knobs in ("knobs_20000_500", "knobs_4096_4096"):
         e = leg[knobs]
         assert e["queries_per_sec"] > 0 and 0 < e["roofline"]["frac"] < 1 and e["roofline"]["kernel"].startswith("pqt_k_")
+        assert e["batches"].startswith("a fresh batch") and e["same_batch_every_step"]["queries_per_sec"] > 0  # the leg's figures: a fresh batch every step
         assert "rerank=mode2" in e["kernel_path"] and e["filter_fallbacks"] == 0
 
 
