@@ -1046,6 +1046,18 @@ def main():
     SWEEP_WL = os.environ.get("PQT_BENCH_SWEEP_WL", "synth100m")
     head_wl = os.environ.get("PQT_BENCH_HEAD_WL") or ("synth1b" if world >= 8 else SWEEP_WL)
     wl_name = args.workload or ("sift1m" if mode != "shard_db" else head_wl)
+    # what the chosen workload costs to BUILD on this run's ranks, before anything is built -- a rank encodes ~13 M vectors/s
+    # (7.5 s per 100 M, profiles/r04_bench_default.json build_s) and synthesises, sorts and brute-forces its ground truth at about the same rate
+    # again; a default that would not fit the budget falls back to the sweep's workload and says so
+    planned_build_s = WORKLOADS[wl_name]["n_base"] / max(1, world if mode == "shard_db" else 1) / 13e6 * 2.0 + 20.0
+    build_budget_s = float(os.environ.get("PQT_BENCH_BUILD_BUDGET_S", "900"))
+    head_fallback = None
+    log("[bench] workload %s on %d rank(s): planned build time %.0f s per rank (budget %.0f s)" % (wl_name, world, planned_build_s, build_budget_s))
+    if not args.workload and mode == "shard_db" and wl_name != SWEEP_WL and planned_build_s > build_budget_s:
+        head_fallback = "the default headline workload %s would take ~%.0f s per rank to build (budget %.0f s, PQT_BENCH_BUILD_BUDGET_S): the sweep's workload %s is the headline instead" % (
+            wl_name, planned_build_s, build_budget_s, SWEEP_WL)
+        log("[bench] " + head_fallback)
+        wl_name = SWEEP_WL
     W = build_workload(ctx, args, wl_name, mode)
     w, n, qn, idx, meta, queries, k = W["w"], W["n"], W["qn"], W["idx"], W["meta"], W["queries"], args.k
     R = time_path(ctx, args, W, args.bv, args.bb, k, args.steps, args.warmup, args.timing_period, single_pipeline=mode != "shard_db")
@@ -1084,6 +1096,9 @@ def main():
         barrier(ctx)
 
     out = make_line(ctx, args, W, R)
+    out["config"]["planned_build_s_per_rank"] = planned_build_s
+    if head_fallback:
+        out["config"]["headline_workload_fallback"] = head_fallback
 
     # ---- one device, two batches in flight: the same steps one batch at a time on one stream (each kernel alone on the device: the
     # per-kernel durations and roofline fractions without the overlap), beside the line's own figures

@@ -147,3 +147,23 @@ def test_bare_command_launches_its_own_ranks_and_reports_the_exchange(pipeline):
     ab = c["pipeline_ab"]
     assert "error" not in ab, ab
     assert ab["results_identical"] is True and ab["other"] == "pipeline=%d" % (2 if pipeline == 1 else 1) and ab["other_ms_per_step"] > 0
+
+
+def test_bare_command_with_eight_ranks_on_one_device():
+    """BASELINE configs[3]'s world size through the driver's own command form: `python bench.py --gpus 8` with no rank
+    environment, eight gloo ranks on the one device, a small stand-in database: 2000 queries = 250 per rank, every collective with eight
+    participants, the line carries the three exchange times, every rank's stage times and the one-GPU denominator."""
+    env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1")
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k_, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "synth1m", "--steps", "4", "--warmup", "1", "--timing-period", "2"],
+                         capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["collective_world_size"] == 8 and d["scaling"] == "strong"
+    assert c["ranks_agree"] is True and c["same_workload_1gpu"]["results_identical_to_sharded"] is True
+    ex = c["exchange_ms"]
+    assert set(ex) == {"bins_allgather", "topk_alltoall", "merged_allgather", "calls_timed"}, ex
+    assert [r_["rank"] for r_ in c["per_rank_stage_ms"]] == list(range(8))
+    assert d["scaling_vs_1gpu"] > 0 and c["planned_build_s_per_rank"] > 0
