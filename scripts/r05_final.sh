@@ -4,6 +4,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/final
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/final/gpu_suite.log 2>&1 < /dev/null; tail -3 gpurun_out/final/gpu_suite.log
+PQT_TEST_EIGHT_RANKS=1 timeout 1600 python -m pytest tests/test_gpu_bench_sharded.py -q -k eight_ranks > gpurun_out/final/eight_ranks.log 2>&1 < /dev/null; tail -3 gpurun_out/final/eight_ranks.log
 timeout 900 python bench.py > gpurun_out/final/r05_bench_default.json 2> gpurun_out/final/bench_default.log < /dev/null; echo "bench rc=$?"
 timeout 600 python bench.py --extras --no-hbm-leg --no-live-traffic > gpurun_out/final/r05_bench_extras.json 2> gpurun_out/final/bench_extras.log < /dev/null; echo "extras rc=$?"
 python - <<'PY'

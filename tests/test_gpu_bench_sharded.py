@@ -153,6 +153,10 @@ def test_bare_command_with_eight_ranks_on_one_device():
     """BASELINE configs[3]'s world size through the driver's own command form: `python bench.py --gpus 8` with no rank
     environment, eight gloo ranks on the one device, a small stand-in database: 2000 queries = 250 per rank, every collective with eight
     participants, the line carries the three exchange times, every rank's stage times and the one-GPU denominator."""
+    if not os.environ.get("PQT_TEST_EIGHT_RANKS"):
+        # written while the GPU pool was closed for this repository: not yet run once on a GPU box, so it does not gate the suite.
+        # PQT_TEST_EIGHT_RANKS=1 python -m pytest tests/test_gpu_bench_sharded.py -k eight_ranks   (scripts/r05_final.sh does)
+        pytest.skip("set PQT_TEST_EIGHT_RANKS=1 (eight processes on one device: ~5 minutes)")
     env = dict(os.environ, PQT_BENCH_BACKEND="gloo", PQT_BENCH_SAME_DEVICE="1")
     for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k_, None)
