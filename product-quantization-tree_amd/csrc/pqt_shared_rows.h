@@ -40,6 +40,9 @@
 #ifndef PQT_SR_DB
 #define PQT_SR_DB 1    // 1: two register sets of rows (next batch in flight under the current one's arithmetic), 0: one
 #endif
+#ifndef PQT_SR_B64
+#define PQT_SR_B64 0   // 1: table look-ups as ds_read_b64 of entry pairs (experiment, see pqt_k_sr_adc)
+#endif
 #ifndef PQT_SR_QC
 #define PQT_SR_QC 8   // queries of a bin evaluated per item against one copy of the rows (their L1virt tables side by side in LDS: 8 KB each)
 #endif
@@ -232,8 +235,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_
               const uint32_t Aa = ww & 0xffu, Bb = (ww >> 8) & 0xffu;
               lam2[h] = (float)(ww >> 16);
               if (PQT_SR_ABL & 2) { sb2[h] = __uint_as_float(Aa); sa2[h] = __uint_as_float(Bb); } else {
+#if PQT_SR_B64
+              // experiment (default off, not yet measured): a 64-entry table row read as 32 eight-byte pairs -- ds_read_b64 banks are
+              // (a / 4) mod 64, conflict free for any 64 lanes inside one 256-byte row, where ds_read_b32 ((a / 4) mod 32) is 2-way; one
+              // select per look-up more
+              const float2 pa = reinterpret_cast<const float2*>(sVirt)[(p << (C1M - 1)) + (Aa >> 1)], pb = reinterpret_cast<const float2*>(sVirt)[(p << (C1M - 1)) + (Bb >> 1)];
+              sb2[h] = (Aa & 1u) ? pa.y : pa.x;
+              sa2[h] = (Bb & 1u) ? pb.y : pb.x;
+#else
               sb2[h] = sVirt[(p << C1M) + Aa];
               sa2[h] = sVirt[(p << C1M) + Bb];
+#endif
               }
             }
             const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
