@@ -18,7 +18,7 @@ struct Fe {
   PerturbationProTree t;
   std::vector<uint> idx;
   std::vector<float> dist;
-  Fe(uint dim, uint p) : t(dim, p, p) {}
+  Fe(uint dim, uint p) : t(dim, p, p) { t.setKeepPadding(true); }  // idx / dist are owned here for the object's life (pqtfe_set_keep_padding switches it)
 };
 }  // namespace
 

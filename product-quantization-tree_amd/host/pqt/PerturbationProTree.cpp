@@ -78,7 +78,7 @@ void ProTree::prepare2DDistSequence(int _maxCluster) {
 }
 
 PerturbationProTree::PerturbationProTree(uint _dim, uint _p, uint _p2)
-    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_issued(0), d_collected(0), d_lastSlot(0), d_keepPadding(true), d_padIdx(nullptr), d_padDist(nullptr), d_padQN(0), d_padNVec(0),
+    : ProTree(_dim, _p, _p2), d_idx(nullptr), d_multi(nullptr), d_issued(0), d_collected(0), d_lastSlot(0), d_keepPadding(false), d_padIdx(nullptr), d_padDist(nullptr), d_padQN(0), d_padNVec(0),
       d_legacyCopy(getenv("PQT_FRONTEND_LEGACY_COPY") != nullptr),
       d_packMin(getenv("PQT_FRONTEND_PACK_MIN_BYTES") ? (size_t)atoll(getenv("PQT_FRONTEND_PACK_MIN_BYTES")) : ((size_t)8 << 20)),
       d_poolThreads(getenv("PQT_FRONTEND_THREADS") ? std::max(1, atoi(getenv("PQT_FRONTEND_THREADS"))) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()))),
@@ -687,34 +687,47 @@ int PerturbationProTree::queryKNNAsync(const float* _Q, uint _QN, uint _nVec) {
   ensureHeuristic(d_boundBins);
   // nothing in flight: slot 0 (a caller of the synchronous queryKNN never touches the view); one batch in flight: the other slot
   const int si = (d_issued == d_collected) ? 0 : 1 - d_lastSlot;
-  d_lastSlot = si;
   KnnSlot& s = d_slots[si];
   if (s.busy) throw std::runtime_error("queryKNNAsync: slot still holds an uncollected batch");
   const size_t n = (size_t)_QN * _nVec;
+  // The slot becomes a ticket only once everything has been enqueued: a call that throws on the way (bad bounds, out of memory, a view that
+  // cannot be created) leaves the object exactly as it was -- no busy slot, no ticket counted -- so the next call can simply be made,
+  // like after a failed call of the reference's queryKNN.
   s.QN = _QN; s.nVec = _nVec; s.compact = false; s.issueMs = 0;
+  if (_QN && _nVec) {
+    bool enqueued = false;
+    try {
+      if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+      // the packed hand-over pays for itself on large results only (two extra kernels, one extra round trip, thread wake-ups)
+      s.compact = !d_legacyCopy && n * 8 >= d_packMin && n <= 0xffffffffull;
+      ensureSlot(s, n, _QN, s.compact);
+      uint* cnt = s.compact ? s.d_resCnt : nullptr;
+      if (d_multi) {
+        // several devices: pqt_multi_query runs the batch on the multi handle's own streams and is waited for here (one batch at a time)
+        s.h = h;
+        if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error());
+      } else {
+        if (si == 0) s.h = h;
+        else if (!s.h) check(pqt_index_create_view(h, &s.h), "pqt_index_create_view");
+        check(pqt_query(s.h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, s.stream, 0), "queryKNN");
+      }
+      enqueued = true;
+      if (s.compact) {
+        // offsets + packed rows + the copy of the offsets behind the query on the slot's stream; nothing is waited for here
+        check(pqt_compact_results(s.h, _QN, _nVec, s.d_resIdx, s.d_resDist, s.d_resCnt, s.d_offsets, s.d_packIdx, s.d_packDist, s.stream, 0), "pqt_compact_results");
+        if (hipMemcpyAsync(s.h_offsets, s.d_offsets, ((size_t)_QN + 1) * 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipEventRecord(s.evOff, s.stream) != hipSuccess)
+          throw std::runtime_error("D2H copy failed");
+      }
+    } catch (...) {
+      // whatever part of the batch reached the slot's stream is drained before the slot is handed out again (its buffers are reused)
+      if (enqueued && s.stream) (void)hipStreamSynchronize(s.stream);
+      s.compact = false; s.QN = s.nVec = 0;
+      throw;
+    }
+  }
   s.busy = true;
   ++d_issued;
-  if (!_QN || !_nVec) return si;
-  if (hipSetDevice(d_device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-  // the packed hand-over pays for itself on large results only (two extra kernels, one extra round trip, thread wake-ups)
-  s.compact = !d_legacyCopy && n * 8 >= d_packMin && n <= 0xffffffffull;
-  ensureSlot(s, n, _QN, s.compact);
-  uint* cnt = s.compact ? s.d_resCnt : nullptr;
-  if (d_multi) {
-    // several devices: pqt_multi_query runs the batch on the multi handle's own streams and is waited for here (one batch at a time)
-    s.h = h;
-    if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error());
-  } else {
-    if (si == 0) s.h = h;
-    else if (!s.h) check(pqt_index_create_view(h, &s.h), "pqt_index_create_view");
-    check(pqt_query(s.h, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, s.stream, 0), "queryKNN");
-  }
-  if (s.compact) {
-    // offsets + packed rows + the copy of the offsets behind the query on the slot's stream; nothing is waited for here
-    check(pqt_compact_results(s.h, _QN, _nVec, s.d_resIdx, s.d_resDist, s.d_resCnt, s.d_offsets, s.d_packIdx, s.d_packDist, s.stream, 0), "pqt_compact_results");
-    if (hipMemcpyAsync(s.h_offsets, s.d_offsets, ((size_t)_QN + 1) * 4, hipMemcpyDeviceToHost, s.stream) != hipSuccess || hipEventRecord(s.evOff, s.stream) != hipSuccess)
-      throw std::runtime_error("D2H copy failed");
-  }
+  d_lastSlot = si;
   s.issueMs = msSince(t0);
   return si;
 }
@@ -771,6 +784,7 @@ void PerturbationProTree::queryKNNCollect(int _ticket, std::vector<uint>& _resId
   if (!d_pool) d_pool = new HostPool(d_poolThreads);
   uint* const oi = _resIdx.data(); float* const od = _resDist.data();
   const uint* const off = s.h_offsets; const size_t nv = _nVec, qn = _QN;
+  const uint32_t* const odBits = reinterpret_cast<const uint32_t*>(od);
   // the padding this storage already holds (left by the previous hand-over into the very same vectors): only what that batch filled
   // beyond this batch's prefix is written again
   const bool known = d_keepPadding && d_padIdx == oi && d_padDist == od && d_padQN == _QN && d_padNVec == _nVec && h_padCnt.size() == qn;
@@ -780,7 +794,13 @@ void PerturbationProTree::queryKNNCollect(int _ticket, std::vector<uint>& _resId
   d_pool->run_all([=](int tid, int nt) {
     for (size_t r = qn * tid / nt; r < qn * (tid + 1) / nt; ++r) {
       const size_t c = off[r + 1] - off[r];
-      const size_t end = known ? std::max<size_t>(c, prev[r]) : nv;
+      // the memory is trusted row by row only while the storage still shows it: the slot behind the previous prefix and the last slot
+      // of the row must hold the sentinels the last hand-over left there (a vector that was reallocated at the same address, assigned
+      // or filled in between does not) -- otherwise the whole row is padded like the reference does
+      const size_t pr = prev[r];
+      const bool rowKnown = known && (pr >= nv || (oi[r * nv + pr] == 0xffffffffu && oi[r * nv + nv - 1] == 0xffffffffu &&
+                                                    odBits[r * nv + pr] == 0x7f800000u && odBits[r * nv + nv - 1] == 0x7f800000u));
+      const size_t end = rowKnown ? std::max<size_t>(c, pr) : nv;
       if (end > c) { fillStream32(oi + r * nv + c, end - c, 0xffffffffu); fillStream32(od + r * nv + c, end - c, 0x7f800000u); }
       prev[r] = (uint)c;
     }

@@ -156,7 +156,10 @@ class PerturbationProTree : public ProTree {
   /** The padding of a row (id 0xffffffff, distance +inf behind its filled prefix) is remembered per result storage: a caller that hands
    *  the SAME two vectors back with the same shape -- the reference's loop does, tool_query.cpp:149-154 -- gets only the slots re-padded
    *  that the previous batch filled beyond the new one's prefix (110 MB of padding per 4096 x 4096 call otherwise, 1.1 of the call's
-   *  1.6 ms).  false: always write the whole padding (for callers that write into the vectors between calls).  Default true. */
+   *  1.6 ms).  false: always write the whole padding, like the reference.  Default FALSE: pointer identity and shape alone do not prove
+   *  that the storage still holds the last hand-over's padding (a vector freed and reallocated at the same address, assign / fill
+   *  between calls); callers that own their vectors for the whole loop opt in (host/tool_query.cpp, host/frontend_cabi.cpp).  With the
+   *  memory on a row is still trusted only while its sentinels (the slot behind the previous prefix, the last slot) are in place. */
   void setKeepPadding(bool _on) { d_keepPadding = _on; d_padIdx = nullptr; }
   /** measurement only (bench.py's "legacy_copy" leg): always hand over with two whole-array copies (round 3's form; = PQT_FRONTEND_LEGACY_COPY at construction) */
   void setLegacyCopy(bool _on) { d_legacyCopy = _on; }

@@ -83,6 +83,8 @@ int main(int argc, char* argv[]) {
     const uint nvec = (uint)F.num("nvec");
     std::vector<uint> resIdx, all((size_t)qn * nvec);
     std::vector<float> resDist;
+    // resIdx / resDist live for the whole loop and are only read between calls: the padding the previous hand-over left is still there
+    ppt.setKeepPadding(true);
     auto t0 = std::chrono::steady_clock::now();
     // the reference's loop (tool_query.cpp:152-160) answers one batch at a time; here batch i + 1 is issued before batch i is collected, so
     // its kernels run under batch i's copies and the host-side scatter (PerturbationProTree::queryKNNAsync / queryKNNCollect); --sync 1 =

@@ -195,17 +195,52 @@ def _worker_counts(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_three_rank_gloo_build_time_bin_count_exchange():
-    """Shard-by-shard build: per-bin global population / lower / local counts from ONE padded all-gather."""
+def _free_port():
+    """a port nobody listens on right now (bind to 0): the fixed pid-derived ports of the first version could collide with a socket of an
+    earlier case still in TIME_WAIT -- one rank then died in the rendezvous and the others waited for it forever"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _run_world(target, world, extra, timeout=180):
+    """world ranks of target(rank, world, port, queue, *extra) as daemon processes; their (rank, ok) results.  A rank that dies before it
+    reports fails the test at once (with its exit code) instead of leaving the others in a collective, and whatever is still alive when
+    the test ends -- pass or fail -- is terminated, so a failure here can never hang the pytest process at exit."""
+    import queue as _queue, time
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_counts, args=(r, 3, port, q)) for r in range(3)]
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res, deadline = [], time.time() + timeout
+    try:
+        while len(res) < world:
+            try:
+                res.append(q.get(timeout=1.0))
+                continue
+            except _queue.Empty:
+                pass
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            assert not dead, "ranks died before reporting (rank, exit code): %r; reported so far: %r" % (dead, sorted(res))
+            assert time.time() < deadline, "timeout after %d s; reported so far: %r" % (timeout, sorted(res))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+    return res
+
+
+
+def test_three_rank_gloo_build_time_bin_count_exchange():
+    """Shard-by-shard build: per-bin global population / lower / local counts from ONE padded all-gather."""
+    res = _run_world(_worker_counts, 3, (), timeout=180)
     assert sorted(res) == [(0, True), (1, True), (2, True)]
 
 
@@ -224,15 +259,7 @@ def test_gloo_sharded_query_equals_unsharded(world, exchange):
     """6 queries over 2 or 3 ranks (3: the query slices are padded, qn % world != 0 for the rows of the last slice): exchange
     by query slice (all-to-all + all-gather of the merged slices) and the single all-gather give the unsharded result."""
     fixture("odd")  # build once before forking
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_world(_worker, world, (exchange,), timeout=180)
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
@@ -242,15 +269,7 @@ def test_gloo_query_sharded_traversal_equals_unsharded(world, exchange, bin_cap)
     every rank resolves them against its own slice of the database -- same result as the unsharded engine; with a small list
     capacity the overflowed queries take the traverse-it-yourself fallback."""
     fixture("odd")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (17 if bin_cap == 256 else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, "sharded", bin_cap)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_world(_worker, world, (exchange, "sharded", bin_cap), timeout=180)
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
@@ -260,15 +279,7 @@ def test_gloo_two_half_batches_in_flight_equal_unsharded(world, exchange, traver
     """sharded_query_pipelined: the batch as two halves whose stages (and collectives) are interleaved -- every rank issues the
     collectives of both halves in the same order, and the assembled answer is the unsharded engine's bit for bit."""
     fixture("odd")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 35500 + (os.getpid() % 2000) + 7 * world + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (19 if traversal == "replicated" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, bin_cap, True)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_world(_worker, world, (exchange, traversal, bin_cap, True), timeout=180)
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
@@ -277,15 +288,7 @@ def test_gloo_two_whole_batches_in_flight(world, exchange, traversal):
     """BatchesInFlight: consecutive steps alternate between two buffer sets / engines (on the GPU: two streams), every rank issues all
     collectives in program order, and each step returns the unsharded engine's answer."""
     fixture("odd")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 37500 + (os.getpid() % 2000) + 7 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, None, "batches")) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    res = _run_world(_worker, world, (exchange, traversal, None, "batches"), timeout=180)
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
@@ -296,13 +299,5 @@ def test_gloo_eight_ranks(exchange, traversal, bin_cap, pipelined, nq):
     ceil(13 / 8) = 2, rank 6 owns one query, rank 7 none; 7 queries: slices of 1, rank 7 none --, the 256-entry bin lists, the small ones
     whose overflow sends queries to the traverse-it-yourself fallback, one batch at a time, two whole batches and two half batches in flight."""
     world = 8
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 39500 + (os.getpid() % 2000) + (3 if exchange == "allgather" else 0) + (11 if bin_cap == 3 else 0) + (17 if bin_cap == 256 else 0) + (23 if pipelined is True else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, traversal, bin_cap, pipelined, nq)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(60)
+    res = _run_world(_worker, world, (exchange, traversal, bin_cap, pipelined, nq), timeout=300)
     assert sorted(res) == [(r, True) for r in range(world)]

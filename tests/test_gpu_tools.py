@@ -404,7 +404,8 @@ def test_frontend_two_batches_in_flight_and_padding_memory():
     and the padding memory of the hand-over (only the slots the previous batch filled beyond the new one's prefix are re-padded when the
     caller hands the same vectors back, tool_query.cpp:149-154).  Two different batches alternate, so rows shrink and grow between
     consecutive hand-overs into the same vectors: every collected batch must equal the engine's padded arrays bit for bit.  A caller that
-    writes into the padding between calls sees its bytes survive with the memory on and restored with setKeepPadding(false)."""
+    writes into the padding between calls sees its bytes survive with the memory on and restored with setKeepPadding(false); a row whose
+    sentinel slots were overwritten is padded whole; a failing call leaves the object usable."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import importlib, os, sys, json
@@ -437,14 +438,33 @@ def test_frontend_two_batches_in_flight_and_padding_memory():
             tm, oi, od = fe.queryKNN(q.data_ptr(), qn, nvec, bv, bb, reps=1)
             ok &= bool(np.array_equal(oi, want[0]) and np.array_equal(od.view(np.uint32), want[1]) and tm["packed"] == 1.0)
         res["sync_alternating"] = ok
-        # a caller that scribbles on the padding: survives with the memory on, repaired with it off
-        fe.scribble(nvec, nvec - 1, 7)
+        # a caller that scribbles INSIDE the padding (not on a sentinel slot): survives with the memory on ...
+        short = ea[2] < nvec - 2
+        fe.scribble(nvec, nvec - 2, 7)
         tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=1)
-        short = ea[2] < nvec
-        res["scribble_survives"] = bool((oi[short, nvec - 1] == 7).all() and np.array_equal(oi[:, :nvec - 1], ea[0][:, :nvec - 1]))
+        res["scribble_survives"] = bool((oi[short, nvec - 2] == 7).all() and np.array_equal(np.delete(oi, nvec - 2, 1), np.delete(ea[0], nvec - 2, 1)))
+        # ... a caller whose storage no longer shows the sentinels (last slot overwritten: what assign / fill / a reallocation at the same
+        # address look like) gets the whole row padded again, memory on or not (ADVICE r05)
+        fe.scribble(nvec, nvec - 1, 9)
+        tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=1)
+        res["lost_sentinel_repads_row"] = bool(np.array_equal(oi, ea[0]) and np.array_equal(od.view(np.uint32), ea[1]))
+        fe.scribble(nvec, nvec - 2, 7)
         fe.set_keep_padding(False)
         tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=1)
         res["repaired"] = bool(np.array_equal(oi, ea[0]) and np.array_equal(od.view(np.uint32), ea[1]))
+        # a call that fails inside pqt_query (more than 8192 heuristic rows: PQT_ERR_LIMIT) leaves the object usable: the next call, synchronous or two in
+        # flight, answers as if nothing had happened (ADVICE r05: the slot stayed busy and the ticket counter ahead)
+        failed = 0
+        for _ in range(3):
+            try:
+                fe.queryKNN(qa.data_ptr(), qn, nvec, bv, 9000, reps=1)
+            except RuntimeError:
+                failed += 1
+        res["bad_call_throws"] = failed == 3
+        tm, oi, od = fe.queryKNN(qb.data_ptr(), qn, nvec, bv, bb, reps=1)
+        res["good_after_bad"] = bool(np.array_equal(oi, eb[0]) and np.array_equal(od.view(np.uint32), eb[1]))
+        ms, oi, od = fe.queryKNN_inflight(qa.data_ptr(), qb.data_ptr(), qn, nvec, bv, bb, reps=3, keep_padding=True)
+        res["inflight_after_bad"] = bool(np.array_equal(oi, ea[0]) and np.array_equal(od.view(np.uint32), ea[1]))
         res["short_rows"] = int(short.sum())
         print("RESULT " + json.dumps(res))
     """ % (ROOT,))
