@@ -364,9 +364,16 @@ int pqt_debug_stream_read(int device, uint64_t bytes, int reps, float* out_ms);
 int pqt_debug_sort_scan(int device, uint32_t mode, uint32_t n, uint32_t* out_host);
 int pqt_get_stats(const pqt_index* idx, pqt_stats* out);
 /* Which kernels the last pqt_query* call launched, as text (tests assert the path taken, not only the result):
- * "traverse=<fused|fused-wide|staged>[-shape1|-shape2|-p2|-generic] rerank=<lds-table|l2-table|mode1-nwN|mode2-nwN|wg-gG|
+ * "traverse=<fused|fused-wide|staged>[-shape1|-shape2|-p2|-generic][-f1] rerank=<lds-table|l2-table|mode1-nwN|mode2-nwN|wg-gG|
  * big-*|staged-*>[-runs] chunks=<n>".  Returns the length written (<= cap - 1, NUL terminated). */
 int pqt_get_last_path(const pqt_index* idx, char* out, int cap);
+/* What the shared-row pass of the filtered rerank (csrc/pqt_shared_rows.h; no reference counterpart: the reference reads a line code per
+ * candidate, cpu_version/quantizer/treequantizer.hpp:423-439,462-476) read and wrote for the last batch, counted on the device when
+ * pqt_index_set_option("sr_stats", 1) is on: out8 = {bins in the per-batch table, (query, bin) pairs, distinct rows, rows the evaluating
+ * kernel reads (a bin's rows once per chunk of 8 queries), items, queries with candidates the pass did not cover (handed back to the exact
+ * kernels), filter distances written for the covered queries, capacity flag (non-zero: items or lists did not fit, every query handed
+ * back)}.  bench.py prices the evaluating kernel's roofline with these.  PQT_ERR_STATE when the last call did not take the pass. */
+int pqt_get_shared_rows_stats(const pqt_index* idx, uint64_t* out8);
 /* duration (ms) of each launch of the dominant kernel (rerank) in the most recent query call that carried per-kernel events
  * (with "stage_timing" = N > 1 not every call does; 0 launches are reported when none of the last 32 calls did), via HIP
  * events on the stream it ran on; returns the number of launches written (<= cap).  pqt_get_stats reports its ms_* fields

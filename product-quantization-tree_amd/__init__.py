@@ -47,7 +47,7 @@ EXPORTS = [
     "pqt_index_get_heuristic", "pqt_index_set_bins", "pqt_index_set_bins_shard", "pqt_index_set_bins_local", "pqt_index_set_db_hashed",
     "pqt_index_set_lines_host", "pqt_index_set_lines_dev", "pqt_build_assign_encode", "pqt_query", "pqt_query_host",
     "pqt_merge_topk", "pqt_compact_results", "pqt_index_device_bytes", "pqt_query_shard", "pqt_query_candidates", "pqt_index_device_arrays", "pqt_debug_stride", "pqt_debug_read", "pqt_get_stats",
-    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
+    "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_get_shared_rows_stats", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
     "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
     "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_build_heuristic_2d", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
     "pqt_multi_query_host",
@@ -56,7 +56,7 @@ EXPORTS = [
 
 def build(force=False):
     """Compile csrc/libpqt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_rerank_launch.hip", "pqt_traverse_launch.hip", "pqt_fused_launch.hip", "pqt_internal.h", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h",
+    srcs = [os.path.join(CSRC, f) for f in ("pqt_hip.hip", "pqt_rerank_launch.hip", "pqt_traverse_launch.hip", "pqt_fused_launch.hip", "pqt_shared_launch.hip", "pqt_shared_rows.h", "pqt_internal.h", "pqt_kernels.h", "pqt_device.h", "pqt_wave.h",
                                            "pqt_multi.cpp", "Makefile")] + \
            [os.path.join(_HERE, "..", "include", "pqt_hip.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
@@ -119,6 +119,7 @@ def lib():
     L.pqt_get_rerank_launch_ms.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_get_stage_ms_history.argtypes = [C.c_void_p, f32p, C.c_int]
     L.pqt_get_last_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.pqt_get_shared_rows_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pqt_debug_stream_read.argtypes = [C.c_int, C.c_uint64, C.c_int, f32p]
     L.pqt_debug_sort_scan.argtypes = [C.c_int, C.c_uint32, C.c_uint32, u32p]
     L.pqt_multi_last_error.restype = C.c_char_p
@@ -315,6 +316,22 @@ class PqtIndex:
         s = pqt_stats()
         _chk(self.L.pqt_get_stats(self.h, C.byref(s)))
         return s.as_dict()
+
+    def shared_rows_stats(self):
+        """What the shared-row pass read and wrote for the last batch (option "sr_stats" = 1 before the call; include/pqt_hip.h)."""
+        out = (C.c_uint64 * 8)()
+        _chk(self.L.pqt_get_shared_rows_stats(self.h, out))
+        names = ("bins", "pairs", "distinct_rows", "rows_read", "items", "uncovered_queries", "distances_written", "capacity_flag")
+        return dict(zip(names, [int(v) for v in out]))
+
+    def debug_read_dist(self, qn):
+        """(ncand [qn], cand_dist [qn][stride]) of the last call where it left distances in HBM (staged path; shared-row pass: filter
+        distances d1, exact ones for the queries handed back)."""
+        stride = self.L.pqt_debug_stride(self.h)
+        nc = np.zeros(qn, np.uint32)
+        cd = np.zeros((qn, stride), np.float32)
+        _chk(self.L.pqt_debug_read(self.h, qn, None, None, None, None, _p(cd, f32p), _p(nc, u32p)))
+        return nc, cd
 
     def device_bytes(self):
         """Device memory of this handle by purpose (include/pqt_hip.h: pqt_index_device_bytes)."""

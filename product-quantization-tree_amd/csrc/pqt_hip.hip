@@ -689,6 +689,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       const bool twoOk = idx->d_heur4 && idx->d_filter && !(idx->dbg & (4096u | 2048u | 32u)) && !d.hashMod;
       const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
       tp += shape ? (shape == 1 ? "-shape1" : "-shape2") : (travP2 ? "-p2" : "-generic");
+      if (idx->lastTravF1) tp += "-f1";  // pqt_k_traverse_f1 really ran (launchFusedTraversal falls back to the plain kernel when the first level does not exist or fit)
     }
     std::string rp;
     if (fused) {
@@ -699,7 +700,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     else rp = fullSort ? "rerank=staged-fullsort" : "rerank=staged-select";
     idx->lastPath = tp + " " + rp + " chunks=" + std::to_string(nChunks) + (usedOneLaunch ? " one-launch" : "");
   }
-  idx->lastDistKept = !fused && !bigK;        // the fused rerank kernels never write candDist
+  idx->lastDistKept = (!fused && !bigK) || sharedPass;  // the fused rerank kernels never write candDist; the shared-row pass leaves its filter distances d1 there
+                                                        // (exact distances for the queries handed back): pqt_debug_read lets the tests compare evaluating kernels bit for bit
   if (sync) HIPCHK(hipStreamSynchronize(st));
   return PQT_OK;
 }
@@ -830,6 +832,13 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "xcode") == 0) { idx->useXCode = value < 0 ? -1 : (value != 0); return PQT_OK; }
   // shared-row pass of the filtered rerank (pqt_shared_rows.h): -1 automatic (line stores of 1 GiB and more), 0 off, 1 on where the shape allows
   if (strcmp(name, "shared_rows") == 0) { idx->sharedRows = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  // evaluating kernel of the shared-row pass: 1 = pqt_k_sr_adc, 2 = pqt_k_sr_adc2 (tables of two queries interleaved, row decode hoisted; same bits)
+  // tests / measurement: size of the pass's per-batch bin table (10..24 bits, 0 = automatic), probes before a pair gives up (1..128), and the
+  // statistics launch behind the preparation (pqt_get_shared_rows_stats)
+  if (strcmp(name, "sr_slot_bits") == 0) { if (value != 0 && (value < 10 || value > 24)) return fail(PQT_ERR_INVALID, "sr_slot_bits: 0 or 10..24"); idx->srSlotBits = (uint32_t)value; return PQT_OK; }
+  if (strcmp(name, "sr_probes") == 0) { if (value < 1 || value > 128) return fail(PQT_ERR_INVALID, "sr_probes: 1..128"); idx->srProbes = (uint32_t)value; return PQT_OK; }
+  if (strcmp(name, "sr_stats") == 0) { idx->srStats = value != 0; if (!idx->srStats) idx->srStatPtr = nullptr; return PQT_OK; }
+  if (strcmp(name, "sr_kernel") == 0) { if (value != 1 && value != 2) return fail(PQT_ERR_INVALID, "sr_kernel: 1 or 2"); idx->srKernel = value; return PQT_OK; }
   // first level of the presence bitmap in LDS for the wide enumeration (512 < bound_bins <= 4096, pqt_k_traverse_f1): 1 = on where it exists,
   // 0 / -1 (default) off.  MEASURED AND NOT THE DEFAULT (scripts/r05_wide_ab.py, SIFT1M shape): (4096, 4096) traversal 0.205 -> 0.197 ms,
   // (20000, 2048) 0.123 -> 0.147, (4096, 1024) 0.085 -> 0.116; 100 M: no change.  A query's enumeration takes half the clocks (133 k -> 72 k
@@ -1262,7 +1271,7 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc; v.w[5] = x->filter1Bits;
   v.f[0] = x->coarseMax;
   for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1; v.i[8] = x->srKernel;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1278,7 +1287,7 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4]; t->filter1Bits = v.w[5];
   t->coarseMax = v.f[0];
   for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7];
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7]; t->srKernel = v.i[8] ? v.i[8] : 1;
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
@@ -1746,6 +1755,16 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   }
   idx->stats = s;
   *out = s;
+  return PQT_OK;
+}
+
+int pqt_get_shared_rows_stats(const pqt_index* idx, uint64_t* out8) {
+  if (!idx || !out8) return fail(PQT_ERR_INVALID, "null argument");
+  if (!idx->srStats || !idx->srStatPtr || !idx->lastShared) return fail(PQT_ERR_STATE, "no statistics held: set_option(\"sr_stats\", 1) and run a query that takes the shared-row pass");
+  int rc = setDevice(idx);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out8, idx->srStatPtr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return PQT_OK;
 }
 

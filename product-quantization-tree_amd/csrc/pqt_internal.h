@@ -99,6 +99,9 @@ struct pqt_index {
   uint32_t* d_srTable = nullptr; uint64_t srTableCap = 0; uint32_t* d_srPairs = nullptr; uint64_t srPairCap = 0; uint32_t* d_srBlocks = nullptr; uint64_t srBlockCap = 0;
   unsigned long long* d_srItems = nullptr; uint64_t srItemCap = 0; unsigned long long* d_srKeys = nullptr; uint64_t srKeysCap = 0; const uint32_t* curPreOk = nullptr; const float* curPreQmax = nullptr;
   int sharedRows = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastShared = false;
+  const uint32_t* curPreFlags = nullptr;  // PqtSrArgs::total of the pass just launched ([2]: capacity flag)
+  uint32_t srSlotBits = 0, srProbes = 128; bool srStats = false; const unsigned long long* srStatPtr = nullptr;  // test / measurement knobs of the pass (pqt_index_set_option)
+  int srKernel = 1;  // evaluating kernel of the pass: 1 pqt_k_sr_adc (one table per query), 2 pqt_k_sr_adc2 (pair-interleaved tables, decode hoisted)
   uint32_t* d_filter1 = nullptr; uint32_t filter1Bits = 0; int useFilter1 = -1 /* -1 auto, 0 off, 1 on */;  // first level of the presence bitmap, folded for the LDS (wide enumeration)
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
   uint32_t* d_ovList = nullptr; uint32_t* d_ovCount = nullptr;  // queries deferred to the full-size bins pass; [0] list length, [1] append cursor
@@ -127,6 +130,7 @@ struct pqt_index {
   hipEvent_t evFork = nullptr, evJoin[kMaxViews] = {nullptr, nullptr, nullptr};
   uint32_t lastPieces = 0, pieceStart[kMaxViews + 2] = {0, 0, 0, 0, 0};  // last call: pieces (0: one piece on this handle); piece i = queries [pieceStart[i], pieceStart[i+1]), piece 0 on this handle, piece i >= 1 on views[i-1]
   bool poolDirty = false;  // a traversal registered queries in the current pool block and no rerank launch has consumed (and re-zeroed) them yet
+  bool lastTravF1 = false;  // the last fused traversal ran pqt_k_traverse_f1 (LDS first level of the presence bitmap)
   std::string lastPath;    // kernel variants of the last query call (pqt_get_last_path)
   int oneLaunch = -1;  // SIFT1M shape: traversal + rerank of a query by the same wavefront in ONE launch (pqt_k_query_fused): 1 on, 0 / -1 (default) off -- measured slower than the two launches
   bool smallLists = true;  // 128 < k <= 4096: lists of <= 1024 candidates go through the wave-per-query evaluate + sort kernel

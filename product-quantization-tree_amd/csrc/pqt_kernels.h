@@ -893,6 +893,7 @@ struct PqtRsArgs {
   // PRE split in two launches (2: scan, 3: band): the scan leaves the <= 256 smallest filter keys of query q, ascending, in preKeys[q][256] and
   // their number in preCnt[q] (0xffffffff: handed back); the band launch takes them from there
   unsigned long long* preKeys; uint32_t* preCnt;
+  const uint32_t* preFlags;  // PqtSrArgs::total of the pass: [2] != 0 = its items / lists did not fit, no query is covered
 };
 
 // a7 + a8 of query q (n local candidates) by the calling wavefront.  sKeys: its PQT_RS_BEST + PQT_RS_PEND key slots,
@@ -973,7 +974,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     if constexpr (MODE == 2) {
       // a query the shared-row pass did not cover (its runs did not fit the hand-over, or its bins the pass's table) goes where the
       // queries with an overflowing near-tie band go: exact distances by a whole workgroup, then the MODE 0 selection (pqt_k_sr_exact_list)
-      if (n && A.preOk[q] == 0u) {
+      if (n && (A.preOk[q] == 0u || (A.preFlags && A.preFlags[2]))) {
         if (PRE != 3 && lane == 0) { A.fbList[atomicAdd(A.fbCount, 1u)] = q; if (PRE == 2) A.preCnt[q] = 0xffffffffu; }
         return;
       }

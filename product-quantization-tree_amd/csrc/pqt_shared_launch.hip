@@ -30,30 +30,47 @@ int launchSharedRows(pqt_index* idx, hipStream_t st, const float* qL1virt, const
   int rc;
   uint32_t bits = 12;
   while ((1ull << bits) < (uint64_t)nq * 16 && bits < 24) ++bits;
+  if (idx->srSlotBits) bits = idx->srSlotBits;  // tests: a table small enough to fill up
   const uint64_t slots = 1ull << bits;
   const uint64_t itemCap = (uint64_t)nq * (stride / PQT_SR_TILE + 64), listCap = (uint64_t)nq * 64;
   if ((rc = growArr(&idx->d_srTable, &idx->srTableCap, slots * 5))) return rc;     // keys | cnt | len | base | lbase
   if ((rc = growArr(&idx->d_srPairs, &idx->srPairCap, (uint64_t)nq * 64 * 2 + 2 * (uint64_t)nq))) return rc;  // pairSlot | pairIdx | preOk | qmax
-  if ((rc = growArr(&idx->d_srBlocks, &idx->srBlockCap, 2 * (slots / 1024) + 16))) return rc;
+  if ((rc = growArr(&idx->d_srBlocks, &idx->srBlockCap, 2 * (slots / 1024) + 16 + 16))) return rc;  // block sums | total[16] | 8 statistics counters (64-bit)
   if ((rc = growArr(&idx->d_srItems, &idx->srItemCap, itemCap + listCap))) return rc;
   PqtSrArgs a{};
   a.runs = idx->d_runs; a.nRuns = idx->d_nRuns; a.nLocal = nLocal; a.qn = nq;
   a.keys = idx->d_srTable; a.cnt = a.keys + slots; a.len = a.cnt + slots; a.base = a.len + slots; a.lbase = a.base + slots; a.slotBits = bits;
   a.pairSlot = idx->d_srPairs; a.pairIdx = a.pairSlot + (size_t)nq * 64; a.preOk = a.pairIdx + (size_t)nq * 64; a.qmax = reinterpret_cast<float*>(a.preOk + nq);
   a.blockSum = idx->d_srBlocks; a.nBlocks = (uint32_t)(slots / 1024); a.total = idx->d_srBlocks + 2 * a.nBlocks;
+  a.maxProbes = idx->srProbes; a.stat = reinterpret_cast<unsigned long long*>(idx->d_srBlocks + ((2 * (size_t)a.nBlocks + 16 + 1) & ~(size_t)1));  // (8-byte aligned)
   a.items = idx->d_srItems; a.itemCap = itemCap; a.binList = idx->d_srItems + itemCap; a.listCap = listCap;
   a.codesGrp4 = (const uint4*)idx->d_codesGrp; a.nIds = idx->nIds; a.bias = idx->d_bias; a.qL1virt = qL1virt; a.dist = idx->d_candDist; a.stride = stride; a.tableFloats = idx->dp.LP * idx->dp.C1;
-  idx->curPreOk = a.preOk; idx->curPreQmax = a.qmax;
+  idx->curPreOk = a.preOk; idx->curPreQmax = a.qmax; idx->curPreFlags = a.total;
   HIPCHK(hipMemsetAsync(a.keys, 0xff, slots * 4, st));
   HIPCHK(hipMemsetAsync(a.cnt, 0, slots * 4, st));
   hipExtLaunchKernelGGL(pqt_k_sr_visits, dim3((nq + 3) / 4), dim3(256), 0, st, ev0, nullptr, 0u, a);
   hipLaunchKernelGGL(pqt_k_sr_scan, dim3(a.nBlocks), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(pqt_k_sr_scan2, dim3(1), dim3(1024), 0, st, a);
   hipLaunchKernelGGL(pqt_k_sr_items, dim3((uint32_t)(((uint64_t)nq * 64 + 255) / 256)), dim3(256), 0, st, a);
-  auto kern = pqt_k_sr_adc<kSrWaves, 8, 6>;
+  if (idx->srStats) {
+    // on request: what the pass will read and write for this batch (pqt_get_shared_rows_stats after the call)
+    HIPCHK(hipMemsetAsync(a.stat, 0, 8 * sizeof(unsigned long long), st));
+    const uint32_t sg = (uint32_t)((std::max<uint64_t>(slots, nq) + 1023) / 1024);
+    hipLaunchKernelGGL(pqt_k_sr_stats, dim3(sg), dim3(1024), 0, st, a);
+    idx->srStatPtr = a.stat;
+  }
   const size_t lds = (size_t)PQT_SR_QC * (idx->dp.LP * idx->dp.C1 * 4 + 64 * 4 + 8);
-  if ((rc = allowLds(kern, lds))) return rc;
   // (timed calls: the stop event of stage "rerank_select" = preparation + this kernel rides on its dispatch; the selection is stage "select")
+  if (idx->srKernel == 2) {
+    // pair-interleaved tables, row decode outside the query loop (pqt_k_sr_adc2; same LDS bytes, same results bit for bit)
+    static_assert(PQT_SR_QC == 8 && kSrWaves == 8, "pqt_k_sr_adc2 is written for chunks of 8 queries and 8 wavefronts");
+    auto kern = pqt_k_sr_adc2<kSrWaves, 8, 6>;
+    if ((rc = allowLds(kern, lds))) return rc;
+    hipExtLaunchKernelGGL(kern, dim3((uint32_t)idx->numCUs * kSrWgs), dim3(kSrWaves * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, a);
+    return PQT_OK;
+  }
+  auto kern = pqt_k_sr_adc<kSrWaves, 8, 6>;
+  if ((rc = allowLds(kern, lds))) return rc;
   hipExtLaunchKernelGGL(kern, dim3((uint32_t)idx->numCUs * kSrWgs), dim3(kSrWaves * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, a);
   return PQT_OK;
 }
@@ -107,7 +124,7 @@ static int launchSel(pqt_index* idx, hipStream_t st, const float* qL1virt, const
                   idx->ctr, idx->dbg, (nq <= (1u << 16)) ? idx->d_tstamp : nullptr, 0u, idx->curZero8,
                   (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
                   idx->d_fbList, idx->d_fbCount, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
-  rargs.preDist = idx->d_candDist; rargs.preOk = idx->curPreOk; rargs.preQmax = idx->curPreQmax;
+  rargs.preDist = idx->d_candDist; rargs.preOk = idx->curPreOk; rargs.preQmax = idx->curPreQmax; rargs.preFlags = idx->curPreFlags;
   HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
   int rc;
 #if PQT_SR_SEL_SPLIT

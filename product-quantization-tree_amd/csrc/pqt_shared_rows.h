@@ -53,7 +53,9 @@ struct PqtSrArgs {
   uint32_t* pairSlot; uint32_t* pairIdx;   // [qn][64]: table slot of the pair run r of query q is the canonical visit of (0xffffffff: none), its rank among the bin's queries
   uint32_t* preOk; float* qmax;            // [qn] covered by the pass; largest entry of the query's L1virt table (the selection's error bound)
   uint32_t* blockSum; uint32_t nBlocks;    // [nBlocks][2] per 1024 slots: items / list entries of the block, then (after _scan2) their exclusive prefixes
-  uint32_t* total;                         // [0] items of the batch
+  uint32_t* total;                         // [0] items of the batch, [1] list entries, [2] != 0: they did not fit itemCap / listCap (every query is handed back)
+  uint32_t maxProbes;                      // table probes before a pair gives up (128; tests: fewer)
+  unsigned long long* stat;                // pqt_k_sr_stats only: 8 counters, zeroed before its launch
   unsigned long long* items; uint64_t itemCap;  // slot | tile << 32 | chunk << 48
   unsigned long long* binList; uint64_t listCap;  // the queries of a bin, side by side: query | run << 32
   const uint4* codesGrp4; uint64_t nIds; const float* bias; const float* qL1virt; float* dist; uint64_t stride; uint32_t tableFloats /* LP * C1 */;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void pqt_k_sr_visits(const PqtSrArgs A) {
   if (canon) {
     const uint32_t mask = (1u << A.slotBits) - 1u;
     uint32_t h = (s * 2654435761u) >> (32u - A.slotBits);
-    for (uint32_t probe = 0; probe < 128u; ++probe) {
+    for (uint32_t probe = 0; probe < A.maxProbes; ++probe) {
       const uint32_t prev = atomicCAS(&A.keys[h], 0xffffffffu, s);
       if (prev == 0xffffffffu || prev == s) { slot = h; break; }
       h = (h + 1u) & mask;
@@ -139,7 +141,14 @@ __global__ __launch_bounds__(1024) void pqt_k_sr_scan2(const PqtSrArgs A) {
     const uint32_t b = threadIdx.x * per + i;
     if (b < A.nBlocks) { const uint32_t v = A.blockSum[2 * b], vL = A.blockSum[2 * b + 1]; A.blockSum[2 * b] = run; A.blockSum[2 * b + 1] = runL; run += v; runL += vL; }
   }
-  if (threadIdx.x == 1023) A.total[0] = off + incl;
+  if (threadIdx.x == 1023) {
+    // The capacities are worst-case bounds (a run is a whole bin: at most stride / TILE + 64 items and 64 list entries per query), so the
+    // flag cannot rise today; if a later change of the run emission or of the caps ever breaks that, the guards of pqt_k_sr_items /
+    // pqt_k_sr_adc would drop work silently -- instead every query of the batch is handed back to the exact kernels
+    const uint32_t items = off + incl, entries = offL + inclL;
+    A.total[0] = items; A.total[1] = entries;
+    A.total[2] = ((uint64_t)items > A.itemCap || (uint64_t)entries > A.listCap) ? 1u : 0u;
+  }
 }
 
 // 3. one thread per (query, run): a canonical visit enters its bin's query list; the first query of every chunk of PQT_SR_QC writes the chunk's items
@@ -296,6 +305,178 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_
   }
 }
 
+// statistics of the pass for the batch just prepared (on request only: option "sr_stats"; bench.py prices the roofline of pqt_k_sr_adc with
+// them).  stat[0] bins in the table, [1] (query, bin) pairs, [2] distinct rows (sum of the bins' lengths), [3] rows the evaluating kernel
+// reads (a bin's rows once per chunk of PQT_SR_QC queries), [4] items, [5] queries with candidates that the pass does not cover, [6] distances
+// it writes for the covered ones (their candidates: one per visit and row), [7] capacity flag (total[2]).
+__global__ __launch_bounds__(1024) void pqt_k_sr_stats(const PqtSrArgs A) {
+  const uint32_t t = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63;
+  unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (t < (1u << A.slotBits)) {
+    const uint32_t c = A.cnt[t];
+    if (c) {
+      const uint32_t len = A.len[t], chunks = (c + PQT_SR_QC - 1u) / PQT_SR_QC;
+      v[0] = 1; v[1] = c; v[2] = len; v[3] = (unsigned long long)len * chunks; v[4] = (unsigned long long)chunks * ((len + PQT_SR_TILE - 1u) / PQT_SR_TILE);
+    }
+  }
+  if (t < A.qn) {
+    const uint32_t n = A.nLocal[t];
+    if (n && !A.preOk[t]) v[5] = 1;
+    if (A.preOk[t]) v[6] = n;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    unsigned long long x = v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d, 64);
+    if (lane == 0 && x) atomicAdd(&A.stat[i], x);
+  }
+  if (t == 0) A.stat[7] = A.total[2];
+}
+
+// 4'. the same launch with the tables of TWO queries interleaved and the row decode outside the query loop (round 6; option "sr_kernel" = 2).
+// What pqt_k_sr_adc spends per (64 rows, query): 64 ds_read_b32 (2-way bank conflicts inside a 64-entry row: 4 LDS cycles each) and ~280
+// VALU instructions, of which the extraction of A, B, lambda from the code words and the two look-up addresses per term (~190) do not depend
+// on the query.  Here
+//   * the tables of queries (2k, 2k + 1) of a chunk sit interleaved in LDS as float2 [LP][C1]{q_2k, q_2k+1}: ONE ds_read_b64 at byte
+//     (p * C1 + A) * 8 returns the entry of both queries -- half the LDS instructions per (row, query), and their addresses are the decoded
+//     byte offset A * 8 of the row plus an immediate (pair * 16 KB + p * 512 B < 64 KB: the DS offset field), no address arithmetic at all;
+//   * a 16-byte piece of a row (4 terms) is decoded ONCE (A * 8, B * 8, lambda: 12 registers) and then walks the <= 4 query pairs, each pair
+//     advancing its two accumulators by the piece's 4 terms with packed f32 operations over the PAIR (v_pk_add / v_pk_mul: the two queries
+//     are the two halves) -- 4 packed instructions per term and pair instead of ~8.6 per term and query.
+// Per query the operations and their order are those of pqt_k_sr_adc (t = a - b; u = lambda * t; d = b + u; acc += d for p = 0 .. LP - 1, then
+// + bias; separate IEEE multiply and add, -ffp-contract=off): the same bits.  A chunk with an odd number of queries evaluates its last table
+// against a copy of itself (results of the second half dropped).
+template <int NW, int LPV, int C1M>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_OCC, PQT_SR_OCC))) void pqt_k_sr_adc2(const PqtSrArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M, QC = 8, NP = QC / 2;
+  constexpr uint32_t TF = LP * C1;      // floats of one table
+  constexpr uint32_t PB = TF * 8;       // bytes of one interleaved pair of tables
+  static_assert(NW == 8, "one wavefront per query of a chunk sets the chunk up; two wavefronts interleave one pair of tables");
+  static_assert((NP - 1) * PB + (LP - 1) * C1 * 8 + (C1 - 1) * 8 + 8 <= 65536, "look-up offsets must fit the DS instructions' 16-bit offset field");
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* const sJ0 = reinterpret_cast<uint32_t*>(smem_raw + (size_t)NP * PB);  // [QC][64] first visiting positions of the query's visits of this bin
+  uint32_t* const sNv = sJ0 + QC * 64;                                               // [QC] their number
+  uint32_t* const sQ = sNv + QC;                                                     // [QC] the query
+  uint64_t total = A.total[0];
+  if (total > A.itemCap) total = A.itemCap;
+  for (uint64_t i = blockIdx.x; i < total; i += gridDim.x) {
+    const unsigned long long it = A.items[i];
+    const uint32_t slot = (uint32_t)it, ti = (uint32_t)(it >> 32) & 0xffffu, chunk = (uint32_t)(it >> 48);
+    const uint32_t sr = A.keys[slot], lenr = A.len[slot], c = A.cnt[slot];
+    const uint64_t lo = (uint64_t)A.lbase[slot] + A.blockSum[2 * (slot >> 10) + 1] + (uint64_t)chunk * QC;
+    const uint32_t nq = c - chunk * QC < QC ? c - chunk * QC : QC;
+    const uint32_t npairs = (nq + 1u) >> 1;
+    __syncthreads();  // the previous item's tables are no longer read
+    if (wave < nq) {
+      // wavefront e: the visits of this bin by query e (the listed run is the first) -- first visiting positions, compacted
+      const uint32_t e = wave;
+      const uint32_t q = (uint32_t)A.binList[lo + e];
+      const uint32_t m = A.nRuns[q];
+      const unsigned long long rr = lane < m ? A.runs[(size_t)q * PQT_RUNCAP + lane] : ~0ull;
+      const bool vis = lane < m && (uint32_t)(rr >> 32) == sr;
+      uint32_t nv;
+      const uint32_t rk = pqt_ballot_rank(vis, &nv);
+      if (vis) sJ0[e * 64 + rk] = (uint32_t)rr;
+      if (lane == 0) { sNv[e] = nv; sQ[e] = q; }
+    }
+    if ((wave >> 1) < npairs) {
+      // wavefronts 2k and 2k + 1: one half each of the interleaved tables of pair k (4-byte loads side by side, 8-byte stores: conflict free)
+      const uint32_t k = wave >> 1, h = wave & 1u;
+      const uint32_t q0 = (uint32_t)A.binList[lo + 2 * k];
+      const uint32_t q1 = (2 * k + 1 < nq) ? (uint32_t)A.binList[lo + 2 * k + 1] : q0;
+      const float* const t0 = A.qL1virt + (size_t)q0 * TF + h * (TF / 2);
+      const float* const t1 = A.qL1virt + (size_t)q1 * TF + h * (TF / 2);
+      float2* const dst = reinterpret_cast<float2*>(smem_raw + (size_t)k * PB) + h * (TF / 2);
+      constexpr uint32_t IT = TF / 2 / 64;
+      float v0[IT], v1[IT];
+#pragma unroll
+      for (uint32_t x = 0; x < IT; ++x) { v0[x] = t0[x * 64 + lane]; v1[x] = t1[x * 64 + lane]; }
+#pragma unroll
+      for (uint32_t x = 0; x < IT; ++x) dst[x * 64 + lane] = make_float2(v0[x], v1[x]);
+    }
+    __syncthreads();
+    const uint32_t row0 = ti * PQT_SR_TILE, row1 = lenr < row0 + PQT_SR_TILE ? lenr : row0 + PQT_SR_TILE;
+    auto request = [&](uint4 (&rows)[LPV], float& rbias, const uint32_t b) {
+      const uint32_t o = b + lane;
+      const size_t pos = (size_t)sr + (o < row1 ? o : row1 - 1u);
+#pragma unroll
+      for (int v = 0; v < LPV; ++v) rows[v] = A.codesGrp4[(size_t)v * A.nIds + pos];
+      rbias = A.bias[pos];
+    };
+    auto evaluate = [&](const uint4 (&rows)[LPV], const float rbias, const uint32_t b) {
+      const uint32_t o = b + lane;
+      pqt_f2 acc[NP];
+#pragma unroll
+      for (uint32_t k = 0; k < NP; ++k) acc[k] = pqt_f2{0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < LPV; ++v) {
+        const uint32_t w[4] = {rows[v].x, rows[v].y, rows[v].z, rows[v].w};
+        // the piece's four terms, decoded once for every query of the chunk
+        uint32_t offA[4], offB[4];
+        pqt_f2 lam01, lam23;
+        lam01[0] = (float)(w[0] >> 16); lam01[1] = (float)(w[1] >> 16); lam23[0] = (float)(w[2] >> 16); lam23[1] = (float)(w[3] >> 16);
+        const pqt_f2 kScale = {8.f / 65536.f, 8.f / 65536.f}, kOff = {-4.f, -4.f};
+        lam01 = lam01 * kScale + kOff;
+        lam23 = lam23 * kScale + kOff;
+        const float lam[4] = {lam01[0], lam01[1], lam23[0], lam23[1]};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { offA[x] = (w[x] & 0xffu) << 3; offB[x] = ((w[x] >> 8) & 0xffu) << 3; }
+#pragma unroll
+        for (uint32_t k = 0; k < NP; ++k) {
+          if (k < npairs) {  // (uniform)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              const uint32_t partBase = k * PB + (uint32_t)(v * 4 + x) * (C1 * 8);  // compile-time: the DS offset field
+              const pqt_f2 sb = *reinterpret_cast<const pqt_f2*>(smem_raw + partBase + offA[x]);
+              const pqt_f2 sa = *reinterpret_cast<const pqt_f2*>(smem_raw + partBase + offB[x]);
+              const pqt_f2 l2 = {lam[x], lam[x]};
+              const pqt_f2 d2 = sb + l2 * (sa - sb);
+              acc[k] = acc[k] + d2;
+            }
+          }
+        }
+      }
+      const pqt_f2 b2 = {rbias, rbias};
+#pragma unroll
+      for (uint32_t k = 0; k < NP; ++k) {
+        if (k < npairs) {  // (uniform)
+          const pqt_f2 r2 = acc[k] + b2;
+#pragma unroll
+          for (uint32_t hq = 0; hq < 2; ++hq) {
+            const uint32_t e = 2 * k + hq;
+            if (e < nq) {  // (uniform)
+              float* const drow = A.dist + (size_t)sQ[e] * A.stride;
+              const uint32_t nv = sNv[e];
+              for (uint32_t vi = 0; vi < nv; ++vi) {  // uniform: one (coalesced) store per visit of the bin
+                const uint32_t jd = sJ0[e * 64 + vi];
+                if (o < row1) drow[jd + o] = r2[hq];
+              }
+            }
+          }
+        }
+      }
+    };
+    const uint32_t first = row0 + wave * 64;
+    uint4 rowsA[LPV], rowsB[LPV];
+    float biasA = 0.f, biasB = 0.f;
+    if (first < row1) request(rowsA, biasA, first);
+    for (uint32_t b = first; b < row1; b += 2 * NW * 64) {
+      const bool haveB = b + NW * 64 < row1;
+      if (haveB) request(rowsB, biasB, b + NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(rowsA, biasA, b);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!haveB) break;
+      if (b + 2 * NW * 64 < row1) request(rowsA, biasA, b + 2 * NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
+      evaluate(rowsB, biasB, b + NW * 64);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 // 5a. the scan of the split selection: the <= 256 smallest filter keys (f32 key << 32 | visiting position) of query q out of the n distances
 // pqt_k_sr_adc wrote, by one wavefront.  pqt_rs_query's batch loop spends ~75 instructions per 64 candidates (64-bit keys, two candidates per
 // lane and round trip, its bookkeeping for rows it does not fetch here) and the selection launch was at the instruction-issue ceiling (37 k
@@ -309,7 +490,7 @@ __device__ __forceinline__ void pqt_sr_scan_query(const PqtRsArgs& A, const uint
   constexpr uint32_t BESTN = 256, SLOTS = NSLOT;
   constexpr int RK = NSLOT / 64;
   static_assert(BESTN + 256 <= SLOTS / 2 + 256 && SLOTS >= 768, "a block of 256 appended keys must fit behind the best list and a half-full pending area");
-  if (n && A.preOk[q] == 0u) {  // not covered by the pass: handed back like a query whose near-tie band overflows
+  if (n && (A.preOk[q] == 0u || (A.preFlags && A.preFlags[2]))) {  // not covered by the pass (or the pass ran out of item / list space): handed back like a query whose near-tie band overflows
     if (lane == 0) { A.fbList[atomicAdd(A.fbCount, 1u)] = q; A.preCnt[q] = 0xffffffffu; }
     return;
   }

@@ -54,6 +54,7 @@ void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPl
   const size_t lTrav = tp.lTrav;
   const uint32_t travPerWave = tp.perWave;
   const bool travP2 = tp.p2;
+  idx->lastTravF1 = false;
 #define PQT_LAUNCH_TR1(WCR, SH, PP)                                                                                       \
   hipExtLaunchKernelGGL((pqt_k_traverse<kTravWaves, WCR, SH, PP>), dim3(grid), dim3(kTravWaves * 64), (uint32_t)lTrav, st, ev0, ev1, 0u, \
                         targs, travPerWave)
@@ -72,7 +73,7 @@ void launchFusedTraversal(pqt_index* idx, const PqtTravArgs& targs, const TravPl
       do { auto kern = pqt_k_traverse_f1<kF1Waves, 1, SH, true, SHAPEV>;                                                        \
            if (pqtAllowLds((const void*)kern, lds) == PQT_OK) {                                                                  \
              hipExtLaunchKernelGGL(kern, dim3(g1), dim3(kF1Waves * 64), (uint32_t)lds, st, ev0, ev1, 0u, targs, travPerWave);    \
-             return; } } while (0)
+             idx->lastTravF1 = true; return; } } while (0)
       if (shape == 1) { if (idx->sharded) PQT_LAUNCH_F1(true, 1); else PQT_LAUNCH_F1(false, 1); }
       else { if (idx->sharded) PQT_LAUNCH_F1(true, 2); else PQT_LAUNCH_F1(false, 2); }
 #undef PQT_LAUNCH_F1

@@ -1634,6 +1634,81 @@ def test_shared_row_pass_changes_no_bit(knobs):
             sh.close()
 
 
+@pytest.mark.parametrize("knobs", [(400, 500), (5000, 500), (10 ** 6, 512), (1, 500)])
+def test_shared_row_evaluating_kernels_agree_bit_for_bit(knobs):
+    """Round 6: pqt_k_sr_adc2 (tables of two queries interleaved as float2, one ds_read_b64 per look-up and pair; a row's 16-byte piece decoded
+    once for all the queries of a chunk) writes the same filter distances as pqt_k_sr_adc at EVERY visiting position -- the whole cand_dist
+    array is compared, not only the results that come out of the selection -- and the statistics launch of the pass adds up."""
+    bv, bb = knobs
+    f = fixture("cfg3_small")
+    idx = f.hip_index()
+    try:
+        qn, k = f.queries.shape[0], 100
+        idx.set_option("shared_rows", 1)
+        idx.set_option("sr_stats", 1)
+        out, dist = {}, {}
+        for kern in (1, 2, 1):
+            idx.set_option("sr_kernel", kern)
+            out[kern] = idx.query(f.queries, bv, bb, k)
+            assert "-shared" in idx.last_path(), idx.last_path()
+            dist[kern] = idx.debug_read_dist(qn)
+            st = idx.shared_rows_stats()
+        a, b = out[1], out[2]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        (n1, d1), (n2, d2) = dist[1], dist[2]
+        assert np.array_equal(n1, n2) and int(n1.sum()) > 0
+        for q in range(qn):
+            assert np.array_equal(bits(d1[q, :n1[q]]), bits(d2[q, :n2[q]])), q
+        # the statistics of the last batch: nothing dropped, sums consistent
+        assert st["capacity_flag"] == 0 and st["pairs"] >= st["bins"] > 0 and st["rows_read"] >= st["distinct_rows"] > 0 and st["items"] > 0
+        assert st["rows_read"] <= st["pairs"] * int(idx.stats()["max_bin"])
+        assert st["uncovered_queries"] <= qn and st["distances_written"] <= int(n1.sum())
+        if st["uncovered_queries"] == 0:
+            assert st["distances_written"] == int(n1.sum())
+    finally:
+        idx.close()
+
+
+def test_shared_row_pass_hands_back_what_it_cannot_hold():
+    """(a) a per-batch bin table that fills up (10-bit table, one probe per pair: every collision gives up), (b) queries with
+    more than 64 runs (short bins, large vector bound: the traversal writes the plain list, nRuns = 0xffffffff) -- the pass does not cover
+    them, they are handed back to the exact list kernels, and every id, distance bit and count is what the wave-per-query kernel returns.
+    The statistics say how many queries were not covered; the capacity flag stays down (its caps are worst-case bounds)."""
+    f = fixture("cfg3_small")
+    idx = f.hip_index()
+    try:
+        qn, k = f.queries.shape[0], 100
+        for bv, bb, probes, want_uncovered in ((400, 500, 1, True), (5000, 500, 1, True), (10 ** 6, 512, 128, None), (5000, 500, 128, None)):
+            idx.set_option("shared_rows", 0)
+            a = idx.query(f.queries, bv, bb, k)
+            idx.set_option("shared_rows", 1)
+            idx.set_option("sr_stats", 1)
+            idx.set_option("sr_slot_bits", 10)
+            idx.set_option("sr_probes", probes)
+            for kern in (1, 2):
+                idx.set_option("sr_kernel", kern)
+                b = idx.query(f.queries, bv, bb, k)
+                assert "-shared" in idx.last_path(), idx.last_path()
+                st = idx.shared_rows_stats()
+                fb = int(idx.stats()["filter_fallbacks"])
+                assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2]), (bv, bb, probes, kern)
+                assert st["capacity_flag"] == 0
+                assert fb >= st["uncovered_queries"], (fb, st)
+                if want_uncovered:
+                    assert st["uncovered_queries"] > 0, st
+            idx.set_option("sr_slot_bits", 0)
+            idx.set_option("sr_probes", 128)
+            idx.set_option("sr_kernel", 1)
+        # (b) more than 64 runs per query: at least one knob set of this fixture must produce such queries
+        idx.set_option("shared_rows", 1)
+        b = idx.query(f.queries, 10 ** 6, 512, k)
+        st = idx.shared_rows_stats()
+        nb = idx.stats()
+        assert st["uncovered_queries"] > 0 or nb["bins_nonempty"] <= 64 * qn, (st, nb)
+    finally:
+        idx.close()
+
+
 def test_shared_row_pass_keeps_the_tie_cluster_fallback():
     """The band overflow of the filter (hundreds of exactly tied candidates around the k-th distance) still sends the query to the plain
     exact kernel when the distances come from the shared-row pass."""
@@ -1673,9 +1748,12 @@ def test_wide_enumeration_with_the_lds_first_level_of_the_bitmap(name):
                 idx.build_heuristic(bb)
             a = idx.query(f.queries, bv, bb, 64)
             idx.set_option("filter_l1", 1)
+            pa = idx.last_path()
             b = idx.query(f.queries, bv, bb, 64)
+            pb = idx.last_path()
             idx.set_option("filter_l1", 0)
-            assert "fused-wide" in idx.last_path(), idx.last_path()
+            # the token says pqt_k_traverse_f1 really ran (the launcher falls back silently when the first level does not exist or fit)
+            assert "fused-wide" in pa and "-f1" not in pa and "fused-wide" in pb and "-f1" in pb, (pa, pb)
             assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2]), (bv, bb)
     finally:
         idx.close()
