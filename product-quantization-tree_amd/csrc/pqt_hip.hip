@@ -786,7 +786,7 @@ void pqt_index_destroy(pqt_index* idx) {
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1, idx->d_srKeys};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1, idx->d_srKeys, idx->d_srSeg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -838,6 +838,10 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   if (strcmp(name, "sr_slot_bits") == 0) { if (value != 0 && (value < 10 || value > 24)) return fail(PQT_ERR_INVALID, "sr_slot_bits: 0 or 10..24"); idx->srSlotBits = (uint32_t)value; return PQT_OK; }
   if (strcmp(name, "sr_probes") == 0) { if (value < 1 || value > 128) return fail(PQT_ERR_INVALID, "sr_probes: 1..128"); idx->srProbes = (uint32_t)value; return PQT_OK; }
   if (strcmp(name, "sr_stats") == 0) { idx->srStats = value != 0; if (!idx->srStats) idx->srStatPtr = nullptr; return PQT_OK; }
+  // the selection's scan over the pass's distances: position ranges per query (1 = one wavefront per query, the default kernel; 2 | 4) and
+  // 16-byte requests in flight per lane (4 | 8)
+  if (strcmp(name, "sr_scan_split") == 0) { if (value != 1 && value != 2 && value != 4) return fail(PQT_ERR_INVALID, "sr_scan_split: 1, 2 or 4"); idx->srScanSplit = value; return PQT_OK; }
+  if (strcmp(name, "sr_scan_depth") == 0) { if (value != 4 && value != 8) return fail(PQT_ERR_INVALID, "sr_scan_depth: 4 or 8"); idx->srScanDepth = value; return PQT_OK; }
   if (strcmp(name, "sr_kernel") == 0) { if (value != 1 && value != 2) return fail(PQT_ERR_INVALID, "sr_kernel: 1 or 2"); idx->srKernel = value; return PQT_OK; }
   // first level of the presence bitmap in LDS for the wide enumeration (512 < bound_bins <= 4096, pqt_k_traverse_f1): 1 = on where it exists,
   // 0 / -1 (default) off.  MEASURED AND NOT THE DEFAULT (scripts/r05_wide_ab.py, SIFT1M shape): (4096, 4096) traversal 0.205 -> 0.197 ms,
@@ -1271,7 +1275,7 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc; v.w[5] = x->filter1Bits;
   v.f[0] = x->coarseMax;
   for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1; v.i[8] = x->srKernel;
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1; v.i[8] = x->srKernel; v.i[9] = x->srScanSplit | (x->srScanDepth << 8);
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1287,7 +1291,7 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4]; t->filter1Bits = v.w[5];
   t->coarseMax = v.f[0];
   for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7]; t->srKernel = v.i[8] ? v.i[8] : 1;
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7]; t->srKernel = v.i[8] ? v.i[8] : 1; if (v.i[9]) { t->srScanSplit = v.i[9] & 0xff; t->srScanDepth = v.i[9] >> 8; }
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
@@ -1541,7 +1545,7 @@ int pqt_index_device_bytes(const pqt_index* idx, uint64_t* out8) {
   out8[5] = (idx->tableBits ? ((uint64_t)1 << idx->tableBits) * (sizeof(PqtBinEntry) + (idx->d_lower ? 4 : 0)) : 0) + (idx->filterBits ? ((uint64_t)1 << idx->filterBits) / 8 : 0);  // bin table + presence bitmap
   out8[6] = (uint64_t)d.C1 * d.D * 8 + (uint64_t)d.P * d.C1 * d.C2 * d.S * 8 + (uint64_t)d.LP * d.C1 * d.C1 * 4 + idx->heurRows * 22;  // codebooks (+ re-tiled copies), coarse table, heuristic
   out8[7] = idx->candCap * (idx->sharded ? 12 : 8) + (uint64_t)idx->qCap * ((uint64_t)d.LP * d.C1 * 4 + (uint64_t)d.P * d.WC * 8 + 32) + idx->sortCap * 8 +
-            idx->srTableCap * 4 + idx->srPairCap * 4 + idx->srBlockCap * 4 + idx->srItemCap * 8 + idx->srKeysCap * 8;  // scratch arena of this handle (the shared-row pass's tables and lists included)
+            idx->srTableCap * 4 + idx->srPairCap * 4 + idx->srBlockCap * 4 + idx->srItemCap * 8 + idx->srKeysCap * 8 + idx->srSegCap * 8;  // scratch arena of this handle (the shared-row pass's tables and lists included)
   return PQT_OK;
 }
 

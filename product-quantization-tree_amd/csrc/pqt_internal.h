@@ -101,6 +101,7 @@ struct pqt_index {
   int sharedRows = -1 /* -1 auto, 0 off, 1 on where supported */; bool lastShared = false;
   const uint32_t* curPreFlags = nullptr;  // PqtSrArgs::total of the pass just launched ([2]: capacity flag)
   uint32_t srSlotBits = 0, srProbes = 128; bool srStats = false; const unsigned long long* srStatPtr = nullptr;  // test / measurement knobs of the pass (pqt_index_set_option)
+  unsigned long long* d_srSeg = nullptr; uint64_t srSegCap = 0; int srScanSplit = 1, srScanDepth = 4;  // opt-in range scan of the selection (pqt_k_sr_scan_seg / pqt_k_sr_merge)
   int srKernel = 1;  // evaluating kernel of the pass: 1 pqt_k_sr_adc (one table per query), 2 pqt_k_sr_adc2 (pair-interleaved tables, decode hoisted)
   uint32_t* d_filter1 = nullptr; uint32_t filter1Bits = 0; int useFilter1 = -1 /* -1 auto, 0 off, 1 on */;  // first level of the presence bitmap, folded for the LDS (wide enumeration)
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)

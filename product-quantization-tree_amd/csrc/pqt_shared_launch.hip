@@ -132,7 +132,30 @@ static int launchSel(pqt_index* idx, hipStream_t st, const float* qL1virt, const
   // (table copy in LDS) -- the best lists travel through global memory (2 KB per query)
   if ((rc = growArr(&idx->d_srKeys, &idx->srKeysCap, (uint64_t)nq * 257))) return rc;
   rargs.preKeys = idx->d_srKeys; rargs.preCnt = reinterpret_cast<uint32_t*>(idx->d_srKeys + (size_t)nq * 256);
-  {
+  if (idx->srScanSplit > 1 || idx->srScanDepth != 4) {
+    // opt-in (round 6): the scan over position ranges of a query with a deeper request queue, then the merge of a query's range lists
+    const uint32_t seg = (uint32_t)idx->srScanSplit;
+    if ((rc = growArr(&idx->d_srSeg, &idx->srSegCap, (uint64_t)nq * seg * 257))) return rc;
+    unsigned long long* const segKeys = idx->d_srSeg;
+    uint32_t* const segCnt = reinterpret_cast<uint32_t*>(idx->d_srSeg + (size_t)nq * seg * 256);
+    const size_t lds = (size_t)NW * ((size_t)1024 * 8);
+    const uint32_t items = nq * seg;
+    const uint32_t grid = std::min<uint32_t>((items + NW - 1) / NW, (uint32_t)idx->numCUs * PQT_SR_SEL_WGS);
+#define PQT_SCAN_SEG(SEGV, QDV)                                                                                     \
+    do { auto kern = pqt_k_sr_scan_seg<NW, SEGV, QDV>;                                                              \
+         if ((rc = allowLds(kern, lds))) return rc;                                                                 \
+         hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, rargs, segKeys, segCnt); } while (0)
+    const bool deep = idx->srScanDepth == 8;
+    if (seg == 1) { if (deep) PQT_SCAN_SEG(1, 8); else PQT_SCAN_SEG(1, 4); }
+    else if (seg == 2) { if (deep) PQT_SCAN_SEG(2, 8); else PQT_SCAN_SEG(2, 4); }
+    else { if (deep) PQT_SCAN_SEG(4, 8); else PQT_SCAN_SEG(4, 4); }
+#undef PQT_SCAN_SEG
+    constexpr int MW = 4;
+    const uint32_t mgrid = (nq + MW - 1) / MW;
+    if (seg == 1) hipLaunchKernelGGL((pqt_k_sr_merge<MW, 1>), dim3(mgrid), dim3(MW * 64), 0, st, rargs, (const unsigned long long*)segKeys, (const uint32_t*)segCnt);
+    else if (seg == 2) hipLaunchKernelGGL((pqt_k_sr_merge<MW, 2>), dim3(mgrid), dim3(MW * 64), 0, st, rargs, (const unsigned long long*)segKeys, (const uint32_t*)segCnt);
+    else hipLaunchKernelGGL((pqt_k_sr_merge<MW, 4>), dim3(mgrid), dim3(MW * 64), 0, st, rargs, (const unsigned long long*)segKeys, (const uint32_t*)segCnt);
+  } else {
     auto kern = pqt_k_sr_select<NW, LPV, UV, SH, 6, false, 2>;
     const size_t lds = (size_t)NW * ((size_t)1024 * 8);  // the lean scan: 1024 key slots per wavefront, nothing else
     if ((rc = allowLds(kern, lds))) return rc;

@@ -563,6 +563,151 @@ __device__ __forceinline__ void pqt_sr_scan_query(const PqtRsArgs& A, const uint
   if (lane == 0) A.preCnt[q] = off0;
 }
 
+// 5a'. the scan over POSITION RANGES (round 6, opt-in: option "sr_scan_split" = 2 | 4, "sr_scan_depth" = 4 | 8).  Why: the scan launch moves
+// 4 bytes per candidate at half the stream rate (0.26-0.31 ms for 0.92 GB).  One wavefront per query means 10 k items of very different
+// length (20 k .. 45 k candidates) on 4096 resident wavefronts -- 2.4 items per wavefront, so the last third of the launch runs on a
+// fraction of the device -- and each wavefront has 4 KB in flight.  Here an item is one of SEG position ranges of a query (multiples of 256
+// candidates), QD requests of 16 bytes per lane are in flight, every range leaves its own <= 256 best keys, and pqt_k_sr_merge reduces the
+// SEG lists of a query to the list the band launch expects (exact radix select of the 256 smallest of <= SEG * 256 unique keys, sorted).
+// The final best list is the same SET of keys as the one-wavefront scan's (every key below the 256-th smallest of the query is among the 256
+// smallest of its range), sorted the same way: same bits downstream.
+template <int NSLOT, int QD>
+__device__ __forceinline__ uint32_t pqt_sr_scan_range(const float* const row, const uint32_t jb, const uint32_t je, uint64_t* const sKeys) {
+  const uint32_t lane = threadIdx.x & 63;
+  constexpr uint32_t BESTN = 256, SLOTS = NSLOT;
+  constexpr int RK = NSLOT / 64;
+  static_assert(SLOTS >= 768, "a block of 256 appended keys must fit behind the best list and a half-full pending area");
+  uint32_t off0 = 0, npend = 0, tauHi = 0xffffffffu;
+  auto flush = [&](const bool final) {
+    uint32_t have = off0 + npend;
+    if (have > BESTN) {
+      uint64_t key[RK];
+#pragma unroll
+      for (int r = 0; r < RK; ++r) { const uint32_t e = r * 64 + lane; key[r] = (e < have) ? sKeys[e] : ~0ull; }
+      __builtin_amdgcn_wave_barrier();
+      const uint64_t tau = pqt_wave_kth_u64<RK>(key, BESTN, reinterpret_cast<uint32_t*>(sKeys + BESTN));
+      tauHi = (uint32_t)(tau >> 32);
+      uint32_t cnt = 0;
+#pragma unroll
+      for (int r = 0; r < RK; ++r) {
+        uint32_t tot;
+        const uint32_t rk = pqt_ballot_rank(key[r] <= tau, &tot);
+        if (key[r] <= tau) sKeys[cnt + rk] = key[r];
+        cnt += tot;
+      }
+      have = BESTN;
+      __builtin_amdgcn_wave_barrier();
+    }
+    (void)final;
+    npend = 0;
+    off0 = have;
+  };
+  if (jb >= je) return 0u;
+  float4 qv[QD];
+  const uint32_t lastQuad = (je - 1u) & ~3u;
+#pragma unroll
+  for (int d = 0; d < QD; ++d) { const uint32_t j = jb + ((uint32_t)d * 64u + lane) * 4u; qv[d] = *reinterpret_cast<const float4*>(row + (j < je ? j : lastQuad)); }
+  for (uint32_t base = jb; base < je; base += 256) {
+    const float4 v = qv[0];
+#pragma unroll
+    for (int d = 0; d + 1 < QD; ++d) qv[d] = qv[d + 1];
+    {  // (unconditional, clamped: the compiler must be able to count the requests in flight)
+      const uint32_t j = base + (uint32_t)QD * 256u + lane * 4u;
+      qv[QD - 1] = *reinterpret_cast<const float4*>(row + (j < je ? j : lastQuad));
+    }
+    const float c4[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t j0 = base + lane * 4u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint32_t k32 = pqt_f2key(c4[c]);
+      const bool pass = j0 + c < je && k32 <= tauHi;
+      const unsigned long long m = __ballot(pass);
+      if (m) {  // (uniform)
+        const uint32_t rk = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pass) sKeys[off0 + npend + rk] = ((uint64_t)k32 << 32) | (j0 + c);
+        npend += (uint32_t)__popcll(m);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (off0 + npend + 256 > SLOTS) flush(false);
+  }
+  flush(true);
+  return off0;  // the <= 256 smallest keys of the range sit in sKeys[0 .. off0), unsorted
+}
+
+// item = (query, range): segKeys[(q * SEG + s) * 256 ..], segCnt[q * SEG + s]; range 0 of a query also says whether the query is handed back
+// (preCnt[q] = 0xffffffff, fbList) or not (preCnt[q] = 0: pqt_k_sr_merge fills it in)
+template <int NW, int SEG, int QD>
+__global__ __launch_bounds__(NW * 64) void pqt_k_sr_scan_seg(const PqtRsArgs A, unsigned long long* const segKeys, uint32_t* const segCnt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int NSLOT = 1024;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t* const sKeys = reinterpret_cast<uint64_t*>(smem_raw) + (size_t)wave * NSLOT;
+  // (what the evaluating kernel does for the next call: statistics block and the schedule's registration block zeroed)
+  if (blockIdx.x == 0 && threadIdx.x < 8 && A.zero8) A.zero8[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && A.poolNext) for (uint32_t t = threadIdx.x; t < 16u + 8u * PQT_SCHED_CLASSES; t += NW * 64) A.poolNext[t] = 0;
+  const uint64_t items = (uint64_t)A.qn * SEG;
+  for (uint64_t it = (uint64_t)blockIdx.x * NW + wave; it < items; it += (uint64_t)gridDim.x * NW) {
+    const uint32_t q = (uint32_t)(it / SEG), sg = (uint32_t)(it % SEG);
+    const uint32_t n = A.nLocal[q];
+    const bool back = n && (A.preOk[q] == 0u || (A.preFlags && A.preFlags[2]));
+    if (sg == 0 && lane == 0) {
+      if (back) A.fbList[atomicAdd(A.fbCount, 1u)] = q;
+      A.preCnt[q] = back ? 0xffffffffu : 0u;
+    }
+    uint32_t got = 0;
+    if (!back && n) {
+      const uint32_t per = ((n + (uint32_t)SEG * 256u - 1u) / ((uint32_t)SEG * 256u)) * 256u;
+      const uint32_t jb = sg * per, je = n < jb + per ? n : jb + per;
+      got = pqt_sr_scan_range<NSLOT, QD>(A.preDist + (size_t)q * A.stride, jb < n ? jb : n, je, sKeys);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < got) segKeys[(size_t)it * 256 + e] = sKeys[e]; }
+    }
+    if (lane == 0) segCnt[it] = got;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// the SEG best lists of a query -> its <= 256 smallest keys, ascending, in preKeys[q][256] / preCnt[q] (what the band launch reads)
+template <int NW, int SEG>
+__global__ __launch_bounds__(NW * 64) void pqt_k_sr_merge(const PqtRsArgs A, const unsigned long long* const segKeys, const uint32_t* const segCnt) {
+  __shared__ __attribute__((aligned(16))) uint64_t sAll[NW][256 + 136];  // per wavefront: 256 compaction slots + the radix select's 1056 bytes
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t q = blockIdx.x * NW + wave;
+  if (q >= A.qn) return;
+  if (A.preCnt[q] == 0xffffffffu) return;  // handed back by the scan
+  uint64_t* const sK = sAll[wave];
+  constexpr int RK = SEG * 4;
+  uint64_t key[RK];
+  uint32_t have = 0;
+#pragma unroll
+  for (int sg = 0; sg < SEG; ++sg) {
+    const uint32_t c = segCnt[(size_t)q * SEG + sg];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; key[sg * 4 + r] = e < c ? segKeys[((size_t)q * SEG + sg) * 256 + e] : ~0ull; }
+    have += c;
+  }
+  uint64_t tau = ~0ull - 1ull;
+  if (have > 256u) tau = pqt_wave_kth_u64<RK>(key, 256u, reinterpret_cast<uint32_t*>(sK + 256));
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int r = 0; r < RK; ++r) {
+    uint32_t tot;
+    const bool keep = key[r] <= tau;  // (absent entries are ~0: never kept)
+    const uint32_t rk = pqt_ballot_rank(keep, &tot);
+    if (keep) sK[cnt + rk] = key[r];
+    cnt += tot;
+  }
+  __builtin_amdgcn_wave_barrier();
+  uint64_t k4[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const uint32_t e = lane * 4 + r; k4[r] = e < cnt ? sK[e] : ~0ull; }
+  pqt_wave_sort_u64<4>(k4);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { const uint32_t e = lane * 4 + r; if (e < cnt) A.preKeys[(size_t)q * 256 + e] = k4[r]; }
+  if (lane == 0) A.preCnt[q] = cnt;
+}
+
 // 5. selection: one wavefront per query over the distances of step 4 (pqt_rs_query PRE): no row is read before the band re-evaluation, the
 // query's table stays in global memory (the band reads ~k entries of it), so a wavefront needs its key slots and run list only -- 5 KB of LDS
 // instead of 12.5 KB, and none of the row registers of the evaluating kernel.

@@ -1655,6 +1655,19 @@ def test_shared_row_evaluating_kernels_agree_bit_for_bit(knobs):
             st = idx.shared_rows_stats()
         a, b = out[1], out[2]
         assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        # the selection's scan over position ranges of a query (2 or 4 per query, 4 or 8 requests in flight) + the merge of the range lists:
+        # the same best list, hence the same everything
+        fb0 = int(idx.stats()["filter_fallbacks"])
+        for kern, split, depth in ((1, 2, 4), (2, 4, 8), (1, 1, 8), (2, 4, 4)):
+            idx.set_option("sr_kernel", kern)
+            idx.set_option("sr_scan_split", split)
+            idx.set_option("sr_scan_depth", depth)
+            c = idx.query(f.queries, bv, bb, k)
+            assert "-shared" in idx.last_path(), idx.last_path()
+            assert np.array_equal(a[0], c[0]) and np.array_equal(bits(a[1]), bits(c[1])) and np.array_equal(a[2], c[2]), (kern, split, depth)
+            assert int(idx.stats()["filter_fallbacks"]) == fb0
+        idx.set_option("sr_scan_split", 1)
+        idx.set_option("sr_scan_depth", 4)
         (n1, d1), (n2, d2) = dist[1], dist[2]
         assert np.array_equal(n1, n2) and int(n1.sum()) > 0
         for q in range(qn):
