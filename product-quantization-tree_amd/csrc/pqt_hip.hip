@@ -378,6 +378,8 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   const bool sharedPass = runsBig && useFilter && sharedRowsShape(idx) && !(idx->dbg & 0xffffu) &&
                           (idx->sharedRows == 1 || (idx->sharedRows < 0 && (size_t)idx->nIds * d.LP * 4 >= ((size_t)1 << 30) &&
                                                     (!idx->sharded || (uint64_t)Bv * 2 >= idx->maxBin)));
+  // cooperative filter scan (opt-in, round 6): the same shapes as the pass, where the pass does not run
+  const bool coopPass = idx->coopRerank == 1 && !sharedPass && runsBig && useFilter && sharedRowsShape(idx) && !(idx->dbg & 0xffffu);
   // X-code rows for the exact rerank with the LDS table at C1 = 32 (SIFT1M shape): a second copy of the line store with cheaper
   // address arithmetic (pqt_rs_query XC); not for stores beyond 16 GiB (the copy doubles their footprint) and not with bin runs
   bool xcode = idx->useXCode != 0 && fused && !useBias && !wgG && coarseLds && d.C1 == 32 && (d.LP == 4 || d.LP == 8 || d.LP == 16 || d.LP == 32) && !emitRuns &&
@@ -566,6 +568,9 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
             idx->evMask[idx->ringPos][c] |= 1u << EV_SELECT;
           }
           rc = launchSharedSelect(idx, grid, lRunsBig, st, v, nl, stride, k, nq, oI, oD, oP);
+        } else if (coopPass) {
+          // two wavefronts per query around one table copy (pqt_k_pair_scan) + merge + band launches: pqt_shared_rows.h
+          rc = launchCoopRerank(idx, st, v, nl, stride, k, nq, oI, oD, oP);
         } else
         rc = launchRSBiasAny(idx, biasNW, useFilter, grid, biasNW == 12 ? (runsBig ? lRunsBig : lBias12) : lBias6, st, v, nl, stride, k, nq, oI, oD, oP);
         if (rc) return rc;
@@ -681,6 +686,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
   idx->lastFilter = useFilter || usedSmallFirst;  // (pqt_stats.filter_fallbacks then counts the queries the short-list kernel handed to the block-wide one)
   idx->lastRuns = emitRuns;
   idx->lastShared = sharedPass;
+  idx->lastCoop = coopPass;
   {
     // which kernels ran (pqt_get_last_path): tests assert the path, not only the result
     std::string tp = !travFused ? "traverse=staged" : (travWide ? "traverse=fused-wide" : "traverse=fused");
@@ -693,7 +699,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
     }
     std::string rp;
     if (fused) {
-      if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "") + (sharedPass ? "-shared" : "");
+      if (useBias) rp = std::string(useFilter ? "rerank=mode2" : "rerank=mode1") + (biasNW == 12 ? "-nw12" : "-nw6") + (runsBig ? "-runs" : "") + (sharedPass ? "-shared" : "") + (coopPass ? "-coop" : "");
       else if (wgG) rp = "rerank=wg-g" + std::to_string(wgG);
       else rp = std::string(coarseLds ? "rerank=lds-table" : "rerank=l2-table") + (emitRuns ? "-runs" : "") + ((xcode && !usedOneLaunch) ? "-xcode" : "");
     } else if (bigK) rp = std::string(bigCL ? "rerank=big-lds-table" : "rerank=big-l2-table") + (usedSmallFirst ? (usedMid ? "+small-lists+mid-lists" : "+small-lists") : "");
@@ -786,7 +792,7 @@ void pqt_index_destroy(pqt_index* idx) {
   }
   void* ptrs[] = {idx->d_cb1, idx->d_cb1L, idx->d_cb2, idx->d_cb2T, idx->d_coarse, idx->d_heur, idx->d_heur8, idx->d_heur4, idx->d_tstamp, idx->d_table, idx->d_filter, idx->d_lower, idx->d_ids,
                   idx->codesOwned ? idx->d_codes : nullptr, idx->d_codesBin, idx->d_codesGrp, idx->d_codesX, idx->d_bias, idx->d_qL1virt, idx->d_segD, idx->d_segBin, idx->d_cand,
-                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1, idx->d_srKeys, idx->d_srSeg};
+                  idx->d_candDist, idx->d_candPos, idx->d_runs, idx->d_runGpos, idx->d_nRuns, idx->d_fbList, idx->d_fbCount, idx->d_tvList, idx->d_tvCount, idx->h2dQ, idx->h2dI, idx->h2dD, idx->h2dC, idx->d_nCand, idx->d_nLocal, idx->d_nIncl, idx->d_ovList, idx->d_ovCount, idx->d_sortKeys, idx->d_counters, idx->d_schedList, idx->d_seq2d, idx->d_heurQ, idx->d_srTable, idx->d_srPairs, idx->d_srBlocks, idx->d_srItems, idx->d_filter1, idx->d_srKeys, idx->d_srSeg, idx->d_coopErr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (idx->evCreated) for (int r = 0; r < kRing; ++r) for (int c = 0; c < kMaxChunks; ++c) for (int e = 0; e < EV_COUNT; ++e) (void)hipEventDestroy(idx->evRing[r][c][e]);
   if (idx->stream) (void)hipStreamDestroy(idx->stream);
@@ -842,6 +848,8 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // 16-byte requests in flight per lane (4 | 8)
   if (strcmp(name, "sr_scan_split") == 0) { if (value != 1 && value != 2 && value != 4) return fail(PQT_ERR_INVALID, "sr_scan_split: 1, 2 or 4"); idx->srScanSplit = value; return PQT_OK; }
   if (strcmp(name, "sr_scan_depth") == 0) { if (value != 4 && value != 8) return fail(PQT_ERR_INVALID, "sr_scan_depth: 4 or 8"); idx->srScanDepth = value; return PQT_OK; }
+  // cooperative filter scan of the filtered rerank (configs[2]/[3] shape, where the shared-row pass does not run): 0 off (default), 1 on
+  if (strcmp(name, "coop_rerank") == 0) { idx->coopRerank = value != 0; return PQT_OK; }
   if (strcmp(name, "sr_kernel") == 0) { if (value != 1 && value != 2) return fail(PQT_ERR_INVALID, "sr_kernel: 1 or 2"); idx->srKernel = value; return PQT_OK; }
   // first level of the presence bitmap in LDS for the wide enumeration (512 < bound_bins <= 4096, pqt_k_traverse_f1): 1 = on where it exists,
   // 0 / -1 (default) off.  MEASURED AND NOT THE DEFAULT (scripts/r05_wide_ab.py, SIFT1M shape): (4096, 4096) traversal 0.205 -> 0.197 ms,
@@ -1263,7 +1271,7 @@ int pqt_kmeans_assign(int device, const float* x_dev, uint64_t n, uint32_t dim, 
 namespace {
 struct SharedWords {
   PqtDevParams dp; pqt_params prm;
-  const void* p[20]; uint64_t u[8]; uint32_t w[8]; float f[12]; int i[10]; bool b[16];
+  const void* p[20]; uint64_t u[8]; uint32_t w[8]; float f[12]; int i[12]; bool b[16];
 };
 void captureShared(const pqt_index* x, SharedWords& v) {
   memset(&v, 0, sizeof(v));
@@ -1275,7 +1283,7 @@ void captureShared(const pqt_index* x, SharedWords& v) {
   v.w[0] = x->tableBits; v.w[1] = x->maxBin; v.w[2] = x->filterBits; v.w[3] = x->dbg; v.w[4] = x->seq2dDc; v.w[5] = x->filter1Bits;
   v.f[0] = x->coarseMax;
   for (int j = 0; j < 9; ++j) v.f[1 + j] = x->slopeThr[j];
-  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1; v.i[8] = x->srKernel; v.i[9] = x->srScanSplit | (x->srScanDepth << 8);
+  v.i[0] = x->grpG; v.i[1] = x->useRuns; v.i[2] = x->numCUs; v.i[3] = x->balance; v.i[4] = x->xcodeShift; v.i[5] = x->useXCode; v.i[6] = x->sharedRows; v.i[7] = x->useFilter1; v.i[8] = x->srKernel; v.i[9] = x->srScanSplit | (x->srScanDepth << 8); v.i[10] = x->coopRerank;
   const bool bs[] = {x->haveTree, x->sharded, x->haveBins, x->binOrdered, x->linesDropped, x->biasReady, x->adcBias, x->exactFilter, x->smallLists,
                      x->forceUnfused, x->useWgRerank, x->noShape, x->heur2d};
   for (size_t j = 0; j < sizeof(bs) / sizeof(bs[0]); ++j) v.b[j] = bs[j];
@@ -1291,7 +1299,7 @@ void applyShared(pqt_index* t, const SharedWords& v) {
   t->tableBits = v.w[0]; t->maxBin = v.w[1]; t->filterBits = v.w[2]; t->dbg = v.w[3]; t->seq2dDc = v.w[4]; t->filter1Bits = v.w[5];
   t->coarseMax = v.f[0];
   for (int j = 0; j < 9; ++j) t->slopeThr[j] = v.f[1 + j];
-  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7]; t->srKernel = v.i[8] ? v.i[8] : 1; if (v.i[9]) { t->srScanSplit = v.i[9] & 0xff; t->srScanDepth = v.i[9] >> 8; }
+  t->grpG = v.i[0]; t->useRuns = v.i[1]; t->numCUs = v.i[2]; t->balance = v.i[3]; t->xcodeShift = v.i[4]; t->useXCode = v.i[5]; t->sharedRows = v.i[6]; t->useFilter1 = v.i[7]; t->srKernel = v.i[8] ? v.i[8] : 1; if (v.i[9]) { t->srScanSplit = v.i[9] & 0xff; t->srScanDepth = v.i[9] >> 8; } t->coopRerank = v.i[10];
   t->haveTree = v.b[0]; t->sharded = v.b[1]; t->haveBins = v.b[2]; t->binOrdered = v.b[3]; t->linesDropped = v.b[4]; t->biasReady = v.b[5]; t->adcBias = v.b[6];
   t->exactFilter = v.b[7]; t->smallLists = v.b[8]; t->forceUnfused = v.b[9]; t->useWgRerank = v.b[10]; t->noShape = v.b[11]; t->heur2d = v.b[12];
   t->stageTiming = 0;  // a view never carries stage events (timed calls are not split)
@@ -1713,6 +1721,12 @@ int pqt_get_stats(const pqt_index* cidx, pqt_stats* out) {
   int rc = setDevice(idx);
   if (rc) return rc;
   HIPCHK(hipDeviceSynchronize());
+  if (idx->d_coopErr) {
+    // the cooperative scan's wavefronts meet through LDS with a bounded wait: a wavefront that gave up left its queries unanswered
+    uint32_t ce = 0;
+    HIPCHK(hipMemcpy(&ce, idx->d_coopErr, 4, hipMemcpyDeviceToHost));
+    if (ce) return fail(PQT_ERR_DEVICE, "cooperative rerank: a wavefront gave up waiting for its partner (results of that call are incomplete)");
+  }
   unsigned long long c[8] = {0};
   HIPCHK(hipMemcpy(c, idx->ctr ? idx->ctr : idx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
   pqt_stats s{};

@@ -102,6 +102,7 @@ struct pqt_index {
   const uint32_t* curPreFlags = nullptr;  // PqtSrArgs::total of the pass just launched ([2]: capacity flag)
   uint32_t srSlotBits = 0, srProbes = 128; bool srStats = false; const unsigned long long* srStatPtr = nullptr;  // test / measurement knobs of the pass (pqt_index_set_option)
   unsigned long long* d_srSeg = nullptr; uint64_t srSegCap = 0; int srScanSplit = 1, srScanDepth = 4;  // opt-in range scan of the selection (pqt_k_sr_scan_seg / pqt_k_sr_merge)
+  int coopRerank = 0; uint32_t* d_coopErr = nullptr; bool lastCoop = false;  // opt-in cooperative filter scan (pqt_k_pair_scan); its give-up flag (never cleared: pqt_get_stats reports it)
   int srKernel = 1;  // evaluating kernel of the pass: 1 pqt_k_sr_adc (one table per query), 2 pqt_k_sr_adc2 (pair-interleaved tables, decode hoisted)
   uint32_t* d_filter1 = nullptr; uint32_t filter1Bits = 0; int useFilter1 = -1 /* -1 auto, 0 off, 1 on */;  // first level of the presence bitmap, folded for the LDS (wide enumeration)
   uint32_t* d_filter = nullptr; uint32_t filterBits = 0;  // presence bitmap over the bin keys (the fused traversal probes it first)
@@ -185,6 +186,7 @@ bool sharedRowsShape(const pqt_index* idx);
 int launchSharedRows(pqt_index* idx, hipStream_t st, const float* qL1virt, const uint32_t* nLocal, uint64_t stride, uint32_t nq, hipEvent_t ev0);
 // the queries a filtered selection handed back (fbList): exact distances by whole workgroups + the exact selection over them
 int launchHandedBack(pqt_index* idx, hipStream_t st, const PqtRsArgs& rargs);
+int launchCoopRerank(pqt_index* idx, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP);
 int launchSharedSelect(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
                        uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP);
 

@@ -925,11 +925,17 @@ struct PqtRsArgs {
 template <int LPV, int UREQ, bool COARSE_LDS, bool SHARDED, int C1M, int MODE = 0, bool RUNS = false, bool XC = false, int NSLOT = PQT_RS_BEST + PQT_RS_PEND,
           int PRE = 0 /* != 0: MODE 2 / 0 + RUNS, selection only (pqt_k_sr_select): the filter distances come from A.preDist (see PqtRsArgs), no row is
                          fetched in the batch loop; 1: the whole selection (sVirt may be the query's table in GLOBAL memory: only the band re-evaluation
-                         reads it); 2: the scan alone -- the best list goes to A.preKeys; 3: the band re-evaluation, sort and results alone, from A.preKeys */>
+                         reads it); 2: the scan alone -- the best list goes to A.preKeys; 3: the band re-evaluation, sort and results alone, from A.preKeys */,
+          int COOP = 0 /* 1 (MODE 2 + RUNS, round 6): the calling wavefront is one of TWO that scan the candidates of query q around ONE LDS copy of its
+                          table (pqt_k_pair_scan): it takes the batches coopHalf, coopHalf + 2, ... and leaves its <= 256 best filter keys in
+                          A.preKeys[(2 q + coopHalf) * 256 ..] / A.preCnt[2 q + coopHalf]; the lists of a pair are merged and the band re-evaluated by
+                          later launches (pqt_k_sr_merge, PRE = 3) */>
 __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t q, const uint32_t n, uint64_t* const sKeys, float* const sVirt,
                                              const float* const cz, const uint32_t qN, uint32_t& nN, const uint32_t slot, uint32_t& tiesAcc,
-                                             unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */) {
+                                             unsigned long long* const sRuns = nullptr /* PQT_RUNCAP u64 + PQT_RUNCAP u32 of this wave, or null */,
+                                             const uint32_t coopHalf = 0 /* COOP: 0 | 1 */) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  static_assert(!COOP || (MODE == 2 && RUNS && !PRE && !XC && !COARSE_LDS), "pair scan: the filtered rerank with bin runs");
   const uint32_t* __restrict__ codes = A.codes; const uint32_t* __restrict__ ids = A.ids; const float* __restrict__ qL1virt = A.qL1virt;
   const uint32_t* __restrict__ cand = A.cand; const uint32_t* __restrict__ candPos = A.candPos; const uint32_t* __restrict__ nLocal = A.nLocal;
   const uint64_t stride = A.stride; const uint32_t k = A.k; uint32_t* __restrict__ outIdx = A.outIdx; float* __restrict__ outDist = A.outDist;
@@ -940,6 +946,9 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   // one candidate is ~3 dependent memory round trips, so memory-level parallelism has to come from here.
   constexpr int U = UREQ;
   constexpr uint32_t LP = LPV * 4;
+  // candidates taken by this wavefront: base = jStart, jStart + jStep, ... (all of them unless COOP)
+  constexpr uint32_t jStep = COOP ? 2u * 64u * UREQ : 64u * UREQ;
+  const uint32_t jStart = COOP ? coopHalf * 64u * UREQ : 0u;
   const uint32_t C1 = C1M >= 2 ? (1u << C1M) : A.prm.C1;
   constexpr bool C1P2 = C1M != 0;
   const uint32_t c1sh = C1M >= 2 ? (uint32_t)C1M : (C1P2 ? (uint32_t)__builtin_ctz(C1) : 0u);  // power-of-two C1: shifts instead of quarter-rate multiplies
@@ -1039,7 +1048,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
   uint32_t idNext[UREQ];
 #pragma unroll
   for (int u = 0; u < UREQ; ++u) {
-    const uint32_t j = u * 64 + lane;
+    const uint32_t j = jStart + u * 64 + lane;
     idNext[u] = (!PRE && n && !useRuns) ? cid[j < n ? j : n - 1] : 0u;  // (PRE: positions are needed for the results only)
   }
   float qmax = 0.f;  // MODE 2: largest entry of the query's L1virt table
@@ -1237,7 +1246,7 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
     for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < off0) sKeys[e] = A.preKeys[(size_t)q * 256 + e]; }
     __builtin_amdgcn_wave_barrier();
   } else
-  for (uint32_t base = 0;; base += 64 * U) {
+  for (uint32_t base = jStart;; base += jStep) {
     if (base < n) {
       if (tstamp) ts0 = __builtin_readcyclecounter();
       uint32_t id[U];
@@ -1328,10 +1337,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       }
       }
       if constexpr (!PRE) {
-      if (!useRuns && base + 64 * U < n) {
+      if (!useRuns && base + jStep < n) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const uint32_t j = base + 64 * U + u * 64 + lane;
+          const uint32_t j = base + jStep + u * 64 + lane;
           idNext[u] = cid[j < n ? j : n - 1];
         }
       }
@@ -1460,10 +1469,10 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       if (tstamp) { const unsigned long long t = __builtin_readcyclecounter(); tsAdc += t - ts0; }
     }
     // single flush site: when the pending buffer could overflow on the next batch, and once at the end
-    const bool last = base + 64 * U >= n;
+    const bool last = base + jStep >= n;
     if (last && qN != 0xffffffffu && nN == 0xffffffffu) nN = (dbg & 2) ? 0u : nLocal[qN];
     if (kPhase1 && phase1) {
-      const uint32_t seen = base + 64 * U < n ? base + 64 * U : n;  // candidates evaluated so far = keys in the 32-bit slots
+      const uint32_t seen = base + 64 * U < n ? base + 64 * U : n;  // candidates evaluated so far = keys in the 32-bit slots (MODE 0: never COOP, jStep = 64 U)
       if (last || seen + 64 * U > CAP32) {
         if (tstamp) ts0 = __builtin_readcyclecounter();
         flush32(seen, last);
@@ -1476,6 +1485,13 @@ __device__ __forceinline__ void pqt_rs_query(const PqtRsArgs& A, const uint32_t 
       if (tstamp) tsFlush += __builtin_readcyclecounter() - ts0;
     }
     if (last) break;
+  }
+  if constexpr (COOP) {
+    // pair scan: this wavefront's best list (<= 256 keys of ITS batches) and, from half 0, the largest table entry (the band's error bound)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const uint32_t e = r * 64 + lane; if (e < off0) A.preKeys[((size_t)q * 2 + coopHalf) * 256 + e] = sKeys[e]; }
+    if (lane == 0) { A.preCnt[(size_t)q * 2 + coopHalf] = off0; if (coopHalf == 0) const_cast<float*>(A.preQmax)[q] = qmax; }
+    return;
   }
   if constexpr (PRE == 2) {
     // scan launch: the best list (<= 256 keys, ascending after the final flush) goes to global memory for the band launch

@@ -181,6 +181,64 @@ static int launchSel(pqt_index* idx, hipStream_t st, const float* qL1virt, const
 #endif
   return launchHandedBack(idx, st, rargs);
 }
+// Cooperative filter scan (pqt_k_pair_scan: two wavefronts per query around one table copy) + merge of the pair's lists + the band launch
+// + the handed-back queries: the filtered rerank of one chunk in four launches.  Opt-in ("coop_rerank" = 1).
+template <bool SH>
+static int launchCoop(pqt_index* idx, hipStream_t st, const float* qL1virt, const uint32_t* nLocal, uint64_t stride, uint32_t k, uint32_t nq,
+                      uint32_t* oI, float* oD, uint32_t* oP) {
+  constexpr int LPV = 8, UV = 2;
+  const double lp = idx->dp.LP;
+  const float kappa = (float)(2.02 * (lp * lp + 8.0 * lp + 2.0) / 16777216.0);
+  PqtRsArgs rargs{idx->d_codesBin, idx->d_ids, qL1virt, idx->d_coarse, idx->d_cand, idx->d_candPos, nLocal, stride, k, nq, idx->dp, oI, oD, oP,
+                  idx->ctr, idx->dbg, nullptr, 0u, idx->curZero8,
+                  (const uint4*)idx->d_codesGrp, (uint64_t)idx->nIds, idx->d_bias, kappa, 20.f * idx->coarseMax, idx->d_fbList, idx->d_fbCount,
+                  idx->d_fbList, idx->d_fbCount, idx->curRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap, idx->curPool, idx->curPoolNext, idx->curPool ? idx->curPool + 16 : nullptr, idx->d_schedList, idx->curSchedCap};
+  int rc;
+  if ((rc = growArr(&idx->d_srSeg, &idx->srSegCap, (uint64_t)nq * 2 * 257))) return rc;   // the two lists of every query + their lengths
+  if ((rc = growArr(&idx->d_srKeys, &idx->srKeysCap, (uint64_t)nq * 257))) return rc;     // the merged list + its length
+  if ((rc = growArr(&idx->d_srPairs, &idx->srPairCap, (uint64_t)nq * 2))) return rc;      // preOk (all ones) | largest table entry per query
+  if (!idx->d_coopErr) { if ((rc = devAlloc(&idx->d_coopErr, 1))) return rc; HIPCHK(hipMemsetAsync(idx->d_coopErr, 0, 4, st)); }
+  unsigned long long* const segKeys = idx->d_srSeg;
+  uint32_t* const segCnt = reinterpret_cast<uint32_t*>(idx->d_srSeg + (size_t)nq * 2 * 256);
+  uint32_t* const ones = idx->d_srPairs;
+  float* const qmax = reinterpret_cast<float*>(idx->d_srPairs + nq);
+  HIPCHK(hipMemsetAsync(ones, 0x01, (size_t)nq * 4, st));
+  HIPCHK(hipMemsetAsync(idx->d_fbCount, 0, 4, st));
+  // 1. the scan: its lists go to segKeys / segCnt (through the preKeys / preCnt fields), the table maxima to qmax
+  {
+    PqtRsArgs sargs = rargs;
+    sargs.preKeys = segKeys; sargs.preCnt = segCnt; sargs.preQmax = qmax;
+    auto kern = pqt_k_pair_scan<LPV, UV, SH, 6>;
+    const size_t lds = (size_t)8 * idx->dp.LP * idx->dp.C1 * 4 + (size_t)16 * (512 * 8 + (size_t)idx->curRunCap * 12) + 64;
+    if ((rc = allowLds(kern, lds))) return rc;
+    const uint32_t grid = std::min<uint32_t>((nq + 7) / 8, (uint32_t)idx->numCUs);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(1024), (uint32_t)lds, st, idx->lev0, nullptr, 0u, sargs, idx->d_coopErr);
+  }
+  // 2. the two lists of a query -> its 256 smallest keys, ascending
+  rargs.preDist = idx->d_candDist; rargs.preOk = ones; rargs.preQmax = qmax; rargs.preFlags = nullptr;
+  rargs.preKeys = idx->d_srKeys; rargs.preCnt = reinterpret_cast<uint32_t*>(idx->d_srKeys + (size_t)nq * 256);
+  HIPCHK(hipMemsetAsync(rargs.preCnt, 0, (size_t)nq * 4, st));  // (0xffffffff would mean "handed back by the scan")
+  {
+    constexpr int MW = 4;
+    hipLaunchKernelGGL((pqt_k_sr_merge<MW, 2>), dim3((nq + MW - 1) / MW), dim3(MW * 64), 0, st, rargs, (const unsigned long long*)segKeys, (const uint32_t*)segCnt);
+  }
+  // 3. band re-evaluation with the reference association, sort, results (the launch that follows the shared-row pass's scan)
+  {
+    constexpr int BW = 12;
+    auto kern = pqt_k_sr_select<BW, LPV, UV, SH, 6, false, 3>;
+    const size_t lds = (size_t)BW * ((PQT_RS_BEST + PQT_RS_PEND) * 8 + (size_t)idx->curRunCap * 12 + (size_t)idx->dp.LP * idx->dp.C1 * 4);
+    if ((rc = allowLds(kern, lds))) return rc;
+    const uint32_t grid = std::min<uint32_t>((nq + BW - 1) / BW, (uint32_t)idx->numCUs);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(BW * 64), (uint32_t)lds, st, nullptr, idx->lev1, 0u, rargs);
+  }
+  // 4. queries whose near-tie band did not fit the 256 slots: exact distances by whole workgroups, exact selection
+  return launchHandedBack(idx, st, rargs);
+}
+int launchCoopRerank(pqt_index* idx, hipStream_t st, const float* v, const uint32_t* nl, uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
+  if (!sharedRowsShape(idx)) return pqtFail(PQT_ERR_LIMIT, "cooperative rerank: 32 line parts, C1 = 64 only");
+  return idx->sharded ? launchCoop<true>(idx, st, v, nl, stride, k, nq, oI, oD, oP) : launchCoop<false>(idx, st, v, nl, stride, k, nq, oI, oD, oP);
+}
+
 int launchSharedSelect(pqt_index* idx, uint32_t grid, size_t lds, hipStream_t st, const float* v, const uint32_t* nl,
                        uint64_t stride, uint32_t k, uint32_t nq, uint32_t* oI, float* oD, uint32_t* oP) {
   (void)grid; (void)lds;

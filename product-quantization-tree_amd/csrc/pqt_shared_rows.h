@@ -708,6 +708,61 @@ __global__ __launch_bounds__(NW * 64) void pqt_k_sr_merge(const PqtRsArgs A, con
   if (lane == 0) A.preCnt[q] = cnt;
 }
 
+// ---- cooperative filter scan (round 6; opt-in: option "coop_rerank" = 1) ------------------------------------------
+// The wave-per-query filter kernel (pqt_k_rerank_select MODE 2) keeps a private 8 KB copy of the query's table per wavefront: 12 wavefronts
+// per CU (3 per SIMD), and at a few hundred to a few thousand candidates per query (range shards) a wavefront sits in s_waitcnt for half of
+// its cycles with nothing else to issue (DESIGN_HISTORY round 4: "what would move it is a fourth wavefront per SIMD, which the 8 KB copy per
+// wavefront rules out").  Here a workgroup is 8 query slots x 2 wavefronts: the two wavefronts of a slot work on the SAME query around ONE
+// table copy (8 x 8 KB + 16 x (4 KB of key slots + run list) = 140 KB: 16 wavefronts per CU, 4 per SIMD), take alternate batches of its
+// candidates and each keep the 256 smallest filter keys of their share; pqt_k_sr_merge<.., 2> reduces the two lists to the query's best list
+// and the band launch (pqt_k_sr_select PHASE 3) finishes it exactly as after the shared-row pass.  Every candidate's filter key is computed
+// by pqt_rs_query's own MODE 2 instruction sequence (COOP only changes which batches a wavefront takes): same keys, same band, same results.
+// The two wavefronts of a slot meet once per query, before the table is overwritten ("my partner no longer reads the previous table"); both
+// then write the WHOLE new table (identical values to identical addresses: a wavefront reads only entries it has written itself).  The
+// meeting is a counter in LDS; a wavefront that waits longer than 2^22 polls gives up, raises errFlag and leaves (a hang would take the
+// device with it; its partner gives up the same way) -- pqt_get_stats reports PQT_ERR_DEVICE.
+__device__ __forceinline__ bool pqt_pair_meet(uint32_t* const cnt, uint32_t& target) {
+  target += 2u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (uint32_t spins = 0;; ++spins) {
+    const uint32_t c = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((int32_t)(c - target) >= 0) break;
+    if (spins > (1u << 22)) return false;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return true;
+}
+
+template <int LPV, int UREQ, bool SHARDED, int C1M>
+__global__ __launch_bounds__(1024) void pqt_k_pair_scan(const PqtRsArgs A, uint32_t* const errFlag) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr uint32_t LP = LPV * 4, C1 = 1u << C1M, TB = LP * C1 * 4, NSLOT = 512, NPAIR = 8;
+  const uint32_t wave = threadIdx.x >> 6, pair = wave >> 1, half = wave & 1u;
+  float* const sTab = reinterpret_cast<float*>(smem_raw + (size_t)pair * TB);
+  uint64_t* const sKeys = reinterpret_cast<uint64_t*>(smem_raw + (size_t)NPAIR * TB) + (size_t)wave * NSLOT;
+  unsigned long long* const sRuns = reinterpret_cast<unsigned long long*>(smem_raw + (size_t)NPAIR * TB + (size_t)2 * NPAIR * NSLOT * 8) + (size_t)wave * (A.runCap + A.runCap / 2);
+  uint32_t* const sMeet = reinterpret_cast<uint32_t*>(smem_raw + (size_t)NPAIR * TB + (size_t)2 * NPAIR * (NSLOT * 8 + (size_t)A.runCap * 12));
+  // (what the evaluating kernel does for the next call: statistics block and the schedule's registration block zeroed)
+  if (blockIdx.x == 0 && threadIdx.x < 8 && A.zero8) A.zero8[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && A.poolNext) for (uint32_t t = threadIdx.x; t < 16u + 8u * PQT_SCHED_CLASSES; t += 1024) A.poolNext[t] = 0;
+  if (threadIdx.x < NPAIR) sMeet[threadIdx.x] = 0u;
+  __syncthreads();
+  uint32_t target = 0, tiesAcc = 0, nN = 0;
+  bool first = true;
+  // static shares: slot (workgroup, pair) owns the queries slot, slot + #slots, ... -- both wavefronts of a pair walk the same sequence
+  for (uint32_t q = blockIdx.x * NPAIR + pair; q < A.qn; q += gridDim.x * NPAIR) {
+    if (!first && !pqt_pair_meet(&sMeet[pair], target)) {
+      if ((threadIdx.x & 63u) == 0u) atomicAdd(errFlag, 1u);
+      return;
+    }
+    first = false;
+    pqt_rs_query<LPV, UREQ, false, SHARDED, C1M, 2, true, false, NSLOT, 0, 1>(A, q, A.nLocal[q], sKeys, sTab, A.coarse, 0xffffffffu, nN, 0u, tiesAcc, sRuns, half);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // 5. selection: one wavefront per query over the distances of step 4 (pqt_rs_query PRE): no row is read before the band re-evaluation, the
 // query's table stays in global memory (the band reads ~k entries of it), so a wavefront needs its key slots and run list only -- 5 KB of LDS
 // instead of 12.5 KB, and none of the row registers of the evaluating kernel.

@@ -1722,6 +1722,90 @@ def test_shared_row_pass_hands_back_what_it_cannot_hold():
         idx.close()
 
 
+@pytest.mark.parametrize("knobs", [(400, 500), (5000, 500), (10 ** 6, 512), (3000, 64), (1, 500), (130, 500)])
+def test_cooperative_filter_scan_changes_no_bit(knobs):
+    """Round 6: option "coop_rerank" -- two wavefronts per query around ONE LDS copy of its table take alternate
+    batches of the candidates (pqt_k_pair_scan, 16 wavefronts per CU instead of 12), their two best lists are merged (pqt_k_sr_merge) and the
+    band launch finishes the query.  Same ids, distance bits and counts as the wave-per-query filter kernel, unsharded, on range shards
+    (merged), through a view; lists shorter than one batch (the second wavefront of a pair has nothing to do), plain candidate lists (more
+    than 64 runs) and the tie-cluster hand-back included; pqt_get_stats reports no wavefront that gave up waiting for its partner."""
+    import torch
+    bv, bb = knobs
+    f = fixture("cfg3_small")
+    idx = f.hip_index()
+    n = f.oracle.num_vectors
+    shards = [f.hip_index(shard=(0, n // 3)), f.hip_index(shard=(n // 3, n))]
+    try:
+        k = 100
+        a = idx.query(f.queries, bv, bb, k)
+        fa = int(idx.stats()["filter_fallbacks"])
+        assert "-coop" not in idx.last_path()
+        idx.set_option("coop_rerank", 1)
+        b = idx.query(f.queries, bv, bb, k)
+        assert "rerank=mode2-nw12-runs-coop" in idx.last_path(), idx.last_path()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+        assert int(idx.stats()["filter_fallbacks"]) == fa
+        q = torch.from_numpy(f.queries).cuda()
+        qn = q.shape[0]
+        I = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Dd = torch.empty((2, qn, k), dtype=torch.float32, device="cuda")
+        Pp = torch.empty((2, qn, k), dtype=torch.int32, device="cuda")
+        Cc = torch.empty((2, qn), dtype=torch.int32, device="cuda")
+        for s_, sh in enumerate(shards):
+            sh.set_option("coop_rerank", 1)
+            sh.query_shard_dev(q, bv, bb, k, I[s_], Dd[s_], Pp[s_], Cc[s_], sync=True)
+            assert "-coop" in sh.last_path(), sh.last_path()
+            sh.stats()
+        oI = torch.empty((qn, k), dtype=torch.int32, device="cuda")
+        oD = torch.empty((qn, k), dtype=torch.float32, device="cuda")
+        shards[0].merge_topk_dev(2, qn, k, I, Dd, Pp, oI, oD, sync=True)
+        assert np.array_equal(oI.cpu().numpy().view(np.uint32), a[0]) and np.array_equal(bits(oD.cpu().numpy()), bits(a[1]))
+        v = idx.view()
+        try:
+            c = v.query(f.queries[::-1].copy(), bv, bb, k)
+            assert "-coop" in v.last_path()
+            assert np.array_equal(c[0], a[0][::-1]) and np.array_equal(bits(c[1]), bits(a[1][::-1]))
+            v.stats()
+        finally:
+            v.close()
+        # the pass has priority where both are asked for
+        idx.set_option("shared_rows", 1)
+        d_ = idx.query(f.queries, bv, bb, k)
+        assert "-shared" in idx.last_path() and "-coop" not in idx.last_path()
+        assert np.array_equal(a[0], d_[0]) and np.array_equal(bits(a[1]), bits(d_[1]))
+    finally:
+        idx.close()
+        for sh in shards:
+            sh.close()
+
+
+def test_cooperative_filter_scan_keeps_the_tie_cluster_fallback():
+    """the band overflow (hundreds of exactly tied candidates around the k-th distance) reaches the exact list kernels from the band launch
+    behind the cooperative scan as well"""
+    from common import Fixture
+
+    def clustered(n, D, seed):
+        protos = np.random.default_rng(777).integers(0, 256, (20, D)).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        x = protos[rng.integers(0, 20, n)]
+        noisy = rng.random(n) < 0.5
+        x[noisy] = np.clip(np.rint(x[noisy] + rng.normal(0, 25, (int(noisy.sum()), D))), 0, 255)
+        return x.astype(np.float32)
+
+    f = Fixture(D=64, P=2, C1=64, C2=4, W=2, LP=32, n_base=12000, n_query=8, seed=68, heur_rows=64, train=3000, data=clustered)
+    idx = f.hip_index()
+    try:
+        a = idx.query(f.queries, 10 ** 6, 64, 100)
+        fa = int(idx.stats()["filter_fallbacks"])
+        idx.set_option("coop_rerank", 1)
+        b = idx.query(f.queries, 10 ** 6, 64, 100)
+        assert "-coop" in idx.last_path(), idx.last_path()
+        assert int(idx.stats()["filter_fallbacks"]) == fa and fa > 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2])
+    finally:
+        idx.close()
+
+
 def test_shared_row_pass_keeps_the_tie_cluster_fallback():
     """The band overflow of the filter (hundreds of exactly tied candidates around the k-th distance) still sends the query to the plain
     exact kernel when the distances come from the shared-row pass."""
