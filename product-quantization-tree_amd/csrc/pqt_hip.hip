@@ -462,7 +462,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
                         emitRuns ? idx->d_runs : nullptr, idx->d_runGpos, idx->d_nRuns, idx->curRunCap,
                         countDirect ? outCount + q0 : nullptr, (idx->dbg >> 5) & 3u,
                         schedCntArg, idx->d_schedList, idx->curSchedCap, nullptr, nullptr, nullptr, 0u,
-                        (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits};
+                        (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits, idx->useFilter1 == 2 ? 1u : 0u};
       if (binsIn) {
         // query-sharded traversal, receiving side: distance tables of every query, the exchanged bin lists resolved against this
         // shard's table, and the (normally empty) list of queries whose list overflowed at the sender traversed here
@@ -695,7 +695,7 @@ int queryImpl(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t Bv, uint
       const bool twoOk = idx->d_heur4 && idx->d_filter && !(idx->dbg & (4096u | 2048u | 32u)) && !d.hashMod;
       const int shape = (idx->noShape || !twoOk) ? 0 : pqt_shape_of(d);
       tp += shape ? (shape == 1 ? "-shape1" : "-shape2") : (travP2 ? "-p2" : "-generic");
-      if (idx->lastTravF1) tp += "-f1";  // pqt_k_traverse_f1 really ran (launchFusedTraversal falls back to the plain kernel when the first level does not exist or fit)
+      if (idx->lastTravF1) tp += idx->useFilter1 == 2 ? "-f1c" : "-f1";  // pqt_k_traverse_f1 really ran (launchFusedTraversal falls back to the plain kernel when the first level does not exist or fit)
     }
     std::string rp;
     if (fused) {
@@ -856,7 +856,8 @@ int pqt_index_set_option(pqt_index* idx, const char* name, int64_t value) {
   // (20000, 2048) 0.123 -> 0.147, (4096, 1024) 0.085 -> 0.116; 100 M: no change.  A query's enumeration takes half the clocks (133 k -> 72 k
   // per query) but 8 wavefronts per CU behind the 64 KB copy instead of 15 answer exactly as many queries per clock: the wide mode is not
   // bound by the probe rate of the 512 KB bitmap
-  if (strcmp(name, "filter_l1") == 0) { idx->useFilter1 = value < 0 ? -1 : (value != 0); return PQT_OK; }
+  // (2, round 6: the rows that pass the first level are compacted and the bitmap is asked for full wavefronts of them only)
+  if (strcmp(name, "filter_l1") == 0) { idx->useFilter1 = value < 0 ? -1 : (value >= 2 ? 2 : (value != 0)); return PQT_OK; }
   if (strcmp(name, "bin_runs") == 0) { idx->useRuns = value < 0 ? -1 : (value != 0); return PQT_OK; }
   if (strcmp(name, "overlap") == 0) { idx->overlap = value < 0 ? -1 : (int)std::min<int64_t>(value, pqt_index::kMaxViews + 1); return PQT_OK; }  // batch pieces on their own streams: 0 / -1 (default) never, 1 = two pieces whenever possible, 2..4 = that many pieces
   if (strcmp(name, "one_launch") == 0) { idx->oneLaunch = value < 0 ? -1 : (value != 0); return PQT_OK; }  // SIFT1M shape: traversal + rerank of a query by one wavefront in one launch (opt-in: measured slower)
@@ -1442,7 +1443,7 @@ int pqt_traverse_bins(pqt_index* idx, const float* q_dev, uint32_t qn, uint32_t 
                             (idx->dbg & 2048u) ? nullptr : idx->d_filter, idx->filterBits,
                             nullptr, nullptr, nullptr, 0u, nullptr, (idx->dbg >> 5) & 3u,
                             nullptr, nullptr, 0u, nullptr, nullptr, out_bins_dev, cap,
-                            (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits};
+                            (idx->useFilter1 > 0 && !(idx->dbg & 2048u)) ? idx->d_filter1 : nullptr, idx->filter1Bits, idx->useFilter1 == 2 ? 1u : 0u};
     launchFusedTraversal(idx, targs, tp, qn, st, nullptr, nullptr);
   }
   HIPCHK(hipGetLastError());

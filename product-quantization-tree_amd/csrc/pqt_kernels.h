@@ -1962,6 +1962,7 @@ struct PqtTravArgs {
   // wide enumeration (He > 512), pqt_k_traverse_f1 only: first level of the presence bitmap, folded to 2^filter1Bits bits (bit i = OR of the
   // 2^(filterBits - filter1Bits) bits of `filter` whose index starts with i) -- small enough for the LDS of a workgroup; or null
   const uint32_t* filter1; uint32_t filter1Bits;
+  uint32_t f1Compact;  // pqt_k_traverse_f1: 1 = the bitmap is asked for full wavefronts of the rows that passed the first level (round 6), 0 = masked lanes of every row
 };
 
 // the whole traversal of query q by the calling wavefront; base = its private LDS slice of perWaveBytes bytes
@@ -2735,6 +2736,66 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
           f[r] = filter[hbit >> 5];
         }
       };
+      if (sF1 && A.f1Compact) {
+        // Round 6: the first level in LDS masked LANES of the 64 bitmap gathers a 4096-row query issues, but the
+        // texture path is bounded by gather INSTRUCTIONS here -- per-CU throughput did not move.  So the rows that pass the first level (the
+        // set fraction of the folded bitmap, 12-24 % of the rows) are appended to a small ring in LDS (the record area is free in this phase)
+        // and the bitmap is asked only for FULL wavefronts of them: 8-16 gather instructions per query instead of 64.  A batch's words are
+        // requested one step before they are tested (the next batch's request, or the end of the enumeration, stands between).
+        uint64_t* const sRing = sBin;  // 128 entries (row | bin id << 32)
+        uint32_t c = 0, pendN = 0, pendW = 0;
+        uint64_t pendE = 0;
+        auto consume = [&]() {
+          if (pendN) {  // (uniform)
+            const bool bit = lane < pendN && ((pendW >> (pqt_hash_filter((uint32_t)(pendE >> 32), filterBits) & 31u)) & 1u);
+            uint32_t tot;
+            const uint32_t rk = pqt_ballot_rank(bit, &tot);
+            if (bit && nwork + rk < 512) sWork[nwork + rk] = pendE;
+            nwork += tot;
+          }
+        };
+        auto issue = [&](const uint32_t take) {  // the first `take` (<= 64) ring entries leave: their bitmap words are requested, the rest moves down
+          const uint64_t e = lane < take ? sRing[lane] : 0ull;
+          const uint32_t wv = lane < take ? filter[pqt_hash_filter((uint32_t)(e >> 32), filterBits) >> 5] : 0u;
+          const uint64_t mv = 64u + lane < c ? sRing[64u + lane] : 0ull;
+          __builtin_amdgcn_wave_barrier();
+          if (64u + lane < c) sRing[lane] = mv;
+          __builtin_amdgcn_wave_barrier();
+          consume();  // the batch requested one step ago
+          pendE = e; pendW = wv; pendN = take;
+          c -= take;
+        };
+        for (uint32_t hb = 0; hb < He; hb += 512) {
+          if (hb == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const uint32_t h = lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+          }
+          uint32_t w[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) w[r] = hw[r];
+          if (hb + 512 < He) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { const uint32_t h = hb + 512 + lane + 64 * r; hw[r] = h < He ? heur4[h] : 0u; }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            const uint32_t h = hb + lane + 64 * r;
+            uint32_t gg = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) if ((uint32_t)p < P) gg += sSegB[PQT_MUL((uint32_t)p, WC, shWC) + ((w[r] >> (8 * p)) & 0xffu)];
+            const uint32_t i1 = pqt_hash_filter(gg, filterBits) >> (filterBits - A.filter1Bits);
+            const bool pass1 = h < He && ((sF1[i1 >> 5] >> (i1 & 31u)) & 1u);
+            uint32_t tot;
+            const uint32_t rk = pqt_ballot_rank(pass1, &tot);
+            if (pass1) sRing[c + rk] = (uint64_t)h | ((uint64_t)gg << 32);
+            c += tot;
+            __builtin_amdgcn_wave_barrier();
+            if (c >= 64u) issue(64u);  // (uniform)
+          }
+        }
+        if (c) issue(c);
+        consume();
+      } else {
       stageA(0, gA, fA);
       for (uint32_t hb = 0; hb < He; hb += 512) {
         uint32_t gB[8], fB[8];
@@ -2753,6 +2814,7 @@ __device__ __forceinline__ void pqt_traverse_query(const PqtTravArgs& A, const u
 #pragma unroll
           for (int r = 0; r < 8; ++r) { gA[r] = gB[r]; fA[r] = fB[r]; }
         }
+      }
       }
       __builtin_amdgcn_wave_barrier();
       if (nwork > 512) {  // more "maybe" rows than the list holds: workgroup-per-query kernel with the full-size arena

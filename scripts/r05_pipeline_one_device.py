@@ -50,6 +50,9 @@ sh.set_bins_local(uk.cpu().numpy(), gs.cpu().numpy(), low.cpu().numpy(), ls.cpu(
 sh.set_lines_dev(codes0, 0)
 if os.environ.get("PQT_SHARED_ROWS") is not None:
     sh.set_option("shared_rows", int(os.environ["PQT_SHARED_ROWS"]))  # round 5: the shared-row pass on the shard (-1 automatic, 0 off, 1 on)
+# round 6: any other option of the shard handle, e.g. PQT_SHARD_OPTIONS="coop_rerank=1" or "shared_rows=1,sr_kernel=2" (set before the view is made: a view copies them)
+for ov_ in filter(None, os.environ.get("PQT_SHARD_OPTIONS", "").split(",")):
+    sh.set_option(ov_.split("=")[0], int(ov_.split("=")[1]))
 view = sh.view()
 for h_ in (sh, view):
     h_.set_option("stage_timing", 0)
@@ -98,7 +101,7 @@ def timed(fn, reps=10):
     return a.elapsed_time(b) / reps
 
 
-out = {"shared_rows_on_the_shard": os.environ.get("PQT_SHARED_ROWS", "automatic"), "workload": "%s: N=%d (configs[2] shape), rank 0 of an 8-way range-sharded run on ONE device, %d queries per batch, k=%d" % (wl, n, qn, k),
+out = {"shared_rows_on_the_shard": os.environ.get("PQT_SHARED_ROWS", "automatic"), "options": os.environ.get("PQT_SHARD_OPTIONS", ""), "workload": "%s: N=%d (configs[2] shape), rank 0 of an 8-way range-sharded run on ONE device, %d queries per batch, k=%d" % (wl, n, qn, k),
        "what": "per-rank step of sharding.sharded_query (one batch at a time) vs sharded_query_pipelined (two half batches in flight) vs BatchesInFlight (two whole batches in flight: "
                "consecutive steps alternate between the index and a view of it on two streams) with every "
                "collective holding its stream for delay_us after moving its bytes; unsharded = the whole database on this device",
@@ -142,7 +145,7 @@ for bv, bb in ((20000, 500), (4096, 4096)):
     out["knobs"]["%d_%d" % (bv, bb)] = res
     del buf, pbuf
 # the denominator: the same database unsharded on this device (only when it fits comfortably)
-if n <= 100_000_000:
+if n <= 100_000_000 and not os.environ.get("PQT_SKIP_UNSHARDED"):
     sh.close()
     del codes0
     torch.cuda.empty_cache()

@@ -1850,7 +1850,14 @@ def test_wide_enumeration_with_the_lds_first_level_of_the_bitmap(name):
             pb = idx.last_path()
             idx.set_option("filter_l1", 0)
             # the token says pqt_k_traverse_f1 really ran (the launcher falls back silently when the first level does not exist or fit)
-            assert "fused-wide" in pa and "-f1" not in pa and "fused-wide" in pb and "-f1" in pb, (pa, pb)
+            assert "fused-wide" in pa and "-f1" not in pa and "fused-wide" in pb and "-f1" in pb and "-f1c" not in pb, (pa, pb)
             assert np.array_equal(a[0], b[0]) and np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(a[2], b[2]), (bv, bb)
+            # 2 (round 6): the rows that pass the first level are compacted, the bitmap is asked for full wavefronts of them
+            idx.set_option("filter_l1", 2)
+            c = idx.query(f.queries, bv, bb, 64)
+            pc = idx.last_path()
+            idx.set_option("filter_l1", 0)
+            assert "-f1c" in pc, pc
+            assert np.array_equal(a[0], c[0]) and np.array_equal(bits(a[1]), bits(c[1])) and np.array_equal(a[2], c[2]), (bv, bb)
     finally:
         idx.close()
