@@ -6,7 +6,8 @@ cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/r06; mkdir -p $O
 case "$1" in
 suite)   # HEAD on a GPU first: the whole -m gpu suite + the guarded 8-rank bare command
-  timeout 1700 python -m pytest tests -m gpu -q > $O/gpu_suite.log 2>&1 < /dev/null; tail -5 $O/gpu_suite.log
+  timeout 1700 python -m pytest tests -m gpu -q --deselect tests/test_gpu_zz_round6_optin.py > $O/gpu_suite.log 2>&1 < /dev/null; tail -5 $O/gpu_suite.log
+  timeout 1200 python -m pytest tests/test_gpu_zz_round6_optin.py -q > $O/gpu_optin.log 2>&1 < /dev/null; tail -5 $O/gpu_optin.log   # the round's opt-in kernels, apart (first run on a device)
   PQT_TEST_EIGHT_RANKS=1 timeout 1200 python -m pytest tests/test_gpu_bench_sharded.py -q -k eight_ranks > $O/eight_ranks.log 2>&1 < /dev/null; tail -3 $O/eight_ranks.log ;;
 bench)   # the driver's exact command, then the extras line
   timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r06_bench_default.json 2> $O/bench_default.log < /dev/null; echo "bench rc=$?"; tail -c 600 $O/r06_bench_default.json

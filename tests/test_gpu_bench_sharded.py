@@ -102,29 +102,6 @@ def test_default_line_carries_the_hbm_roofline_leg():
         assert "rerank=mode2" in e["kernel_path"] and e["filter_fallbacks"] == 0
 
 
-def test_hbm_leg_prices_the_shared_row_pass_on_deduplicated_bytes():
-    """when the shared-row pass runs, roofline.frac of the leg prices what one launch of pqt_k_sr_adc must move at the least
-    (distinct rows + the distances it writes, counted on the device in the run), stays below 1, and SURVEY 8(d)'s per-candidate bytes ride
-    along as a speed-up (algorithmic_equivalent_*), not as a fraction.  Small stand-in workload with the pass forced on."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu", "--hbm-workload", "synth1m", "--option", "shared_rows=1",
-                          "--no-live-traffic"], capture_output=True, text=True, cwd=ROOT, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    leg = d["config"]["hbm_roofline_leg"]
-    assert "error" not in leg, leg
-    for knobs in ("knobs_20000_500", "knobs_4096_4096"):
-        e = leg[knobs]
-        r = e["roofline"]
-        assert "-shared" in e["kernel_path"] and r["kernel"] == "pqt_k_sr_adc", (e["kernel_path"], r["kernel"])
-        dd = r["deduplicated"]
-        assert dd["capacity_flag"] == 0 and 0 < dd["distinct_rows"] <= dd["rows_read_by_the_kernel"] and dd["distances_written"] > 0
-        assert dd["bytes_per_launch"] == dd["distinct_rows"] * (4 * 32 + 4) + 4 * dd["distances_written"] == r["algorithmic_bytes_per_launch"]
-        assert 0 < r["frac"] < 1 and abs(r["achieved"] - dd["bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1e-6 * r["achieved"] + 1e-9
-        assert dd["algorithmic_equivalent_speedup"] >= 1.0 and dd["survey_8d_bytes_per_launch"] >= dd["bytes_per_launch"]
-        assert 0 < e["path_frac_of_hbm_peak"] < 1
-        assert 0 < r["selection_kernel"]["frac"] < 1 and r["selection_kernel"]["bytes_per_launch"] > 0
-
-
 def test_eight_gpu_default_code_path_with_two_ranks_and_small_stand_ins():
     """`--gpus 8` (no --workload): `value` is the big configuration and the sweep's workload rides beside it as config.strong_scaling_leg
     with its own one-GPU denominator.  The same code path with two gloo ranks on one device and small stand-in workloads."""
