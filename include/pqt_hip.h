@@ -325,6 +325,13 @@ int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t bou
                     uint32_t* out_idx_dev0, float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync);
 int pqt_multi_query_host(pqt_multi* m, const float* q_host, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t k,
                          uint32_t* out_idx_host, float* out_dist_host, uint32_t* out_count_host);
+/* Two batches in flight behind one multi handle (no reference counterpart: its loop answers one batch at a time, tool_query.cpp:152-160;
+ * host/pqt/PerturbationProTree::queryKNNAsync with setDevices uses it).  lane 0 = the shard indices (pqt_multi_query is lane 0), lane 1 = a
+ * view of every shard (pqt_index_create_view: own scratch, same loaded shard) with streams, events and exchange buffers of its own, created on
+ * first use.  Two calls on different lanes with sync = 0 (and different hip_stream arguments, or NULL) overlap; a lane answers its batches in
+ * the order they were issued.  Outputs and the query array must stay valid until the lane's batch has completed on its stream. */
+int pqt_multi_query_lane(pqt_multi* m, int lane, const float* q_dev0, uint32_t qn, uint32_t bound_vectors, uint32_t bound_bins, uint32_t k,
+                         uint32_t* out_idx_dev0, float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync);
 
 /* ---- stage-level read-back (parity tests; not a fast path) ------------------------------------------
  * After a pqt_query* call the handle still holds the intermediates of that batch:

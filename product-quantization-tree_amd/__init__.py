@@ -50,7 +50,7 @@ EXPORTS = [
     "pqt_get_rerank_launch_ms", "pqt_get_stage_ms_history", "pqt_dev_triangle", "pqt_get_last_path", "pqt_get_shared_rows_stats", "pqt_debug_stream_read", "pqt_debug_sort_scan", "pqt_traverse_bins", "pqt_query_shard_bins",
     "pqt_multi_last_error", "pqt_multi_create", "pqt_multi_destroy", "pqt_multi_shards", "pqt_multi_shard", "pqt_multi_shard_range", "pqt_multi_set_option",
     "pqt_multi_set_codebooks", "pqt_multi_build_heuristic", "pqt_multi_build_heuristic_cuda", "pqt_multi_build_heuristic_2d", "pqt_multi_set_heuristic", "pqt_multi_set_bins", "pqt_multi_set_lines_host", "pqt_multi_query",
-    "pqt_multi_query_host",
+    "pqt_multi_query_host", "pqt_multi_query_lane",
 ]
 
 
@@ -139,6 +139,7 @@ def lib():
     L.pqt_multi_set_bins.argtypes = [C.c_void_p, C.c_uint64, u32p, u32p, u32p, C.c_uint64]
     L.pqt_multi_set_lines_host.argtypes = [C.c_void_p, u32p, C.c_uint64]
     L.pqt_multi_query.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.pqt_multi_query_lane.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.pqt_multi_query_host.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, f32p, u32p]
     L.pqt_dev_triangle.argtypes = [f32p, f32p, f32p, f32p, C.c_uint32, f32p, f32p, C.POINTER(C.c_uint16), f32p, C.c_int]
     _LIB = L
@@ -443,6 +444,11 @@ class PqtMulti:
     def query_dev(self, q, Bv, Bb, k, out_idx, out_dist, out_count=None, stream=None, sync=False):
         self._chk(self.L.pqt_multi_query(self.h, q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
                                          out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
+
+    def query_lane_dev(self, lane, q, Bv, Bb, k, out_idx, out_dist, out_count=None, stream=None, sync=False):
+        """pqt_multi_query_lane: lane 0 = the shards, lane 1 = views of them (two batches in flight behind one handle)."""
+        self._chk(self.L.pqt_multi_query_lane(self.h, int(lane), q.data_ptr(), q.shape[0], Bv, Bb, k, out_idx.data_ptr(), out_dist.data_ptr(),
+                                              out_count.data_ptr() if out_count is not None else None, stream, int(sync)))
 
     def query(self, Q, Bv, Bb, k):
         Q = _np(Q, np.float32).reshape(-1, self.D)

@@ -37,25 +37,34 @@ int mfail(int code, const std::string& msg) { g_merr = msg; return code; }
   } while (0)
 }  // namespace
 
+// What ONE batch in flight needs: the handles it runs on (lane 0: the shard indices; lane 1: a view of each, pqt_index_create_view -- own
+// scratch, same loaded shard), a stream and two events per shard, the exchange buffers.  Two lanes = two batches in flight behind one
+// multi handle (round 6, VERDICT r05 #10: pqt_multi_query_lane; PerturbationProTree::queryKNNAsync with setDevices).
+struct MultiLane {
+  std::vector<pqt_index*> h;
+  std::vector<hipStream_t> st;
+  std::vector<hipEvent_t> evT, evR;  // traversal of the shard's query slice done / shard's top-k done
+  hipEvent_t evIn = nullptr;
+  hipEvent_t evDone = nullptr;       // end of the lane's previous batch on the stream it was enqueued on
+  // per-shard device buffers, grown on demand
+  std::vector<float*> dQ; std::vector<unsigned long long*> dBins; std::vector<uint32_t*> dPack; std::vector<uint32_t*> dCount;
+  std::vector<size_t> capQ, capBins, capPack, capCount;
+  uint32_t* dGather = nullptr; size_t capGather = 0;  // on device 0: [n][3][qn][k]
+  bool ready = false;
+};
 struct pqt_multi {
   pqt_params prm{};
   int n = 0;
   std::vector<pqt_index*> sh;
   std::vector<int> dev;
-  std::vector<hipStream_t> st;
-  std::vector<hipEvent_t> evT, evR;  // traversal of the shard's query slice done / shard's top-k done
-  hipEvent_t evIn = nullptr;
+  MultiLane lane[2];
+  std::vector<hipStream_t>& st = lane[0].st;   // (lane 0's streams: the host-pointer entry and the growth drain use them by this name)
   uint64_t nTotal = 0;
   std::vector<uint64_t> lo, hi;      // id range of every shard
-  // per-shard device buffers, grown on demand
-  std::vector<float*> dQ; std::vector<unsigned long long*> dBins; std::vector<uint32_t*> dPack; std::vector<uint32_t*> dCount;
-  std::vector<size_t> capQ, capBins, capPack, capCount;
-  uint32_t* dGather = nullptr; size_t capGather = 0;  // on device 0: [n][3][qn][k]
   float* hQ = nullptr; uint32_t* hI = nullptr; float* hD = nullptr; uint32_t* hC = nullptr;  // staging of pqt_multi_query_host (device 0)
   size_t capHQ = 0, capHK = 0, capHC = 0;
   bool replicatedTraversal = false;
   bool drained = false;                 // growDev: all streams already synchronised in this call
-  hipEvent_t evDone = nullptr;          // end of the previous pqt_multi_query on the stream it was enqueued on
 };
 
 namespace {
@@ -66,8 +75,11 @@ template <class T>
 int growDev(pqt_multi* m, int device, T** p, size_t* cap, size_t want) {
   if (want <= *cap) return PQT_OK;
   if (*p && m && !m->drained) {
-    for (int s = 0; s < m->n; ++s) { MHIP(hipSetDevice(m->dev[s])); MHIP(hipStreamSynchronize(m->st[s])); }
-    if (m->evDone) MHIP(hipEventSynchronize(m->evDone));  // the previous batch's merge on the caller's stream (reads dGather)
+    for (MultiLane& L : m->lane) {
+      if (!L.ready) continue;
+      for (int s = 0; s < m->n; ++s) { MHIP(hipSetDevice(m->dev[s])); MHIP(hipStreamSynchronize(L.st[s])); }
+      if (L.evDone) MHIP(hipEventSynchronize(L.evDone));  // the lane's previous batch's merge on the caller's stream (reads dGather)
+    }
     m->drained = true;
   }
   MHIP(hipSetDevice(device));
@@ -108,6 +120,48 @@ int broadcastHeuristic(pqt_multi* m, uint64_t rows) {
 }
 }  // namespace
 
+namespace {
+// streams, events and (lane 1) the views of a lane; idempotent
+int laneInit(pqt_multi* m, int li) {
+  MultiLane& L = m->lane[li];
+  if (L.ready) return PQT_OK;
+  const int n = m->n;
+  L.h.assign(n, nullptr); L.st.assign(n, nullptr); L.evT.assign(n, nullptr); L.evR.assign(n, nullptr);
+  L.dQ.assign(n, nullptr); L.dBins.assign(n, nullptr); L.dPack.assign(n, nullptr); L.dCount.assign(n, nullptr);
+  L.capQ.assign(n, 0); L.capBins.assign(n, 0); L.capPack.assign(n, 0); L.capCount.assign(n, 0);
+  for (int s = 0; s < n; ++s) {
+    if (li == 0) L.h[s] = m->sh[s];
+    else MPQT(pqt_index_create_view(m->sh[s], &L.h[s]));
+    MHIP(hipSetDevice(m->dev[s]));
+    MHIP(hipStreamCreateWithFlags(&L.st[s], hipStreamNonBlocking));
+    MHIP(hipEventCreateWithFlags(&L.evT[s], hipEventDisableTiming));
+    MHIP(hipEventCreateWithFlags(&L.evR[s], hipEventDisableTiming));
+  }
+  MHIP(hipSetDevice(m->dev[0]));
+  MHIP(hipEventCreateWithFlags(&L.evIn, hipEventDisableTiming));
+  MHIP(hipEventCreateWithFlags(&L.evDone, hipEventDisableTiming));
+  L.ready = true;
+  return PQT_OK;
+}
+void laneFree(pqt_multi* m, int li) {
+  MultiLane& L = m->lane[li];
+  for (int s = 0; s < (int)L.st.size(); ++s) {
+    (void)hipSetDevice(m->dev[s]);
+    if (L.st[s]) (void)hipStreamSynchronize(L.st[s]);
+    for (void* p : {(void*)L.dQ[s], (void*)L.dBins[s], (void*)L.dPack[s], (void*)L.dCount[s]}) if (p) (void)hipFree(p);
+    if (L.evT[s]) (void)hipEventDestroy(L.evT[s]);
+    if (L.evR[s]) (void)hipEventDestroy(L.evR[s]);
+    if (L.st[s]) (void)hipStreamDestroy(L.st[s]);
+    if (li == 1 && L.h[s]) pqt_index_destroy(L.h[s]);  // the views go before the shards they look at
+  }
+  if (m->n) (void)hipSetDevice(m->dev[0]);
+  if (L.dGather) (void)hipFree(L.dGather);
+  if (L.evIn) (void)hipEventDestroy(L.evIn);
+  if (L.evDone) (void)hipEventDestroy(L.evDone);
+  L = MultiLane();
+}
+}  // namespace
+
 extern "C" {
 
 const char* pqt_multi_last_error(void) { return g_merr.c_str(); }
@@ -116,21 +170,14 @@ int pqt_multi_create(const pqt_params* prm, int nshards, const int* devices, pqt
   if (!prm || !out || nshards < 1 || nshards > 64) return mfail(PQT_ERR_INVALID, "bad arguments (1 <= nshards <= 64)");
   pqt_multi* m = new pqt_multi();
   m->prm = *prm; m->n = nshards;
-  m->sh.assign(nshards, nullptr); m->dev.resize(nshards); m->st.assign(nshards, nullptr);
-  m->evT.assign(nshards, nullptr); m->evR.assign(nshards, nullptr);
+  m->sh.assign(nshards, nullptr); m->dev.resize(nshards);
   m->lo.assign(nshards, 0); m->hi.assign(nshards, 0);
-  m->dQ.assign(nshards, nullptr); m->dBins.assign(nshards, nullptr); m->dPack.assign(nshards, nullptr); m->dCount.assign(nshards, nullptr);
-  m->capQ.assign(nshards, 0); m->capBins.assign(nshards, 0); m->capPack.assign(nshards, 0); m->capCount.assign(nshards, 0);
   for (int s = 0; s < nshards; ++s) {
     m->dev[s] = devices ? devices[s] : s;
     int rc = pqt_index_create(prm, m->dev[s], &m->sh[s]);
-    if (rc == PQT_OK && (hipSetDevice(m->dev[s]) != hipSuccess || hipStreamCreateWithFlags(&m->st[s], hipStreamNonBlocking) != hipSuccess ||
-                         hipEventCreateWithFlags(&m->evT[s], hipEventDisableTiming) != hipSuccess ||
-                         hipEventCreateWithFlags(&m->evR[s], hipEventDisableTiming) != hipSuccess)) {
-      rc = PQT_ERR_DEVICE; g_merr = "stream / event creation failed";
-    } else if (rc != PQT_OK) g_merr = pqt_last_error();
-    if (rc != PQT_OK) { pqt_multi_destroy(m); return rc; }
+    if (rc != PQT_OK) { g_merr = pqt_last_error(); pqt_multi_destroy(m); return rc; }
   }
+  { int rc = laneInit(m, 0); if (rc != PQT_OK) { pqt_multi_destroy(m); return rc; } }
   // peer access between the devices (xGMI): without it hipMemcpyPeerAsync stages through the host
   for (int a = 0; a < nshards; ++a)
     for (int b = 0; b < nshards; ++b)
@@ -142,30 +189,17 @@ int pqt_multi_create(const pqt_params* prm, int nshards, const int* devices, pqt
           (void)hipGetLastError();
         }
       }
-  if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventCreateWithFlags(&m->evIn, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&m->evDone, hipEventDisableTiming) != hipSuccess) {
-    pqt_multi_destroy(m);
-    return mfail(PQT_ERR_DEVICE, "event creation failed");
-  }
   *out = m;
   return PQT_OK;
 }
 
 void pqt_multi_destroy(pqt_multi* m) {
   if (!m) return;
-  for (int s = 0; s < m->n; ++s) {
-    (void)hipSetDevice(m->dev[s]);
-    if (m->st[s]) (void)hipStreamSynchronize(m->st[s]);
-    for (void* p : {(void*)m->dQ[s], (void*)m->dBins[s], (void*)m->dPack[s], (void*)m->dCount[s]}) if (p) (void)hipFree(p);
-    if (m->evT[s]) (void)hipEventDestroy(m->evT[s]);
-    if (m->evR[s]) (void)hipEventDestroy(m->evR[s]);
-    if (m->st[s]) (void)hipStreamDestroy(m->st[s]);
-    if (m->sh[s]) pqt_index_destroy(m->sh[s]);
-  }
+  laneFree(m, 1);
+  laneFree(m, 0);
+  for (int s = 0; s < m->n; ++s) if (m->sh[s]) pqt_index_destroy(m->sh[s]);
   if (m->n) (void)hipSetDevice(m->dev[0]);
-  for (void* p : {(void*)m->dGather, (void*)m->hQ, (void*)m->hI, (void*)m->hD, (void*)m->hC}) if (p) (void)hipFree(p);
-  if (m->evIn) (void)hipEventDestroy(m->evIn);
-  if (m->evDone) (void)hipEventDestroy(m->evDone);
+  for (void* p : {(void*)m->hQ, (void*)m->hI, (void*)m->hD, (void*)m->hC}) if (p) (void)hipFree(p);
   delete m;
 }
 
@@ -184,6 +218,7 @@ int pqt_multi_set_option(pqt_multi* m, const char* name, int64_t value) {
   // "replicated_traversal" = 1: every shard traverses the whole batch itself (no exchange of bin lists); results are identical
   if (strcmp(name, "replicated_traversal") == 0) { m->replicatedTraversal = value != 0; return PQT_OK; }
   for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_option(m->sh[s], name, value));
+  if (m->lane[1].ready) for (int s = 0; s < m->n; ++s) MPQT(pqt_index_set_option(m->lane[1].h[s], name, value));
   return PQT_OK;
 }
 
@@ -244,8 +279,15 @@ int pqt_multi_set_lines_host(pqt_multi* m, const uint32_t* codes_host, uint64_t 
 
 int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* out_idx_dev0,
                     float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync) {
-  if (!m || !out_idx_dev0 || !out_dist_dev0 || (qn && !q_dev0) || !k) return mfail(PQT_ERR_INVALID, "bad query arguments");
+  return pqt_multi_query_lane(m, 0, q_dev0, qn, Bv, Bb, k, out_idx_dev0, out_dist_dev0, out_count_dev0, hip_stream, sync);
+}
+
+int pqt_multi_query_lane(pqt_multi* m, int lane, const float* q_dev0, uint32_t qn, uint32_t Bv, uint32_t Bb, uint32_t k, uint32_t* out_idx_dev0,
+                         float* out_dist_dev0, uint32_t* out_count_dev0, void* hip_stream, int sync) {
+  if (!m || !out_idx_dev0 || !out_dist_dev0 || (qn && !q_dev0) || !k || lane < 0 || lane > 1) return mfail(PQT_ERR_INVALID, "bad query arguments");
   if (qn == 0) return PQT_OK;
+  { int rc = laneInit(m, lane); if (rc) return rc; }
+  MultiLane& L = m->lane[lane];
   const int n = m->n;
   const uint32_t D = m->prm.dim;
   const uint32_t kBinCap = binCapFor(Bb);
@@ -253,68 +295,68 @@ int pqt_multi_query(pqt_multi* m, const float* q_dev0, uint32_t qn, uint32_t Bv,
   m->drained = false;
   for (int s = 0; s < n; ++s) {
     int rc;
-    if (s > 0 && (rc = growDev(m, m->dev[s], &m->dQ[s], &m->capQ[s], (size_t)qn * D))) return rc;
-    if ((rc = growDev(m, m->dev[s], &m->dBins[s], &m->capBins[s], wordsBins))) return rc;
-    if ((rc = growDev(m, m->dev[s], &m->dPack[s], &m->capPack[s], wordsPack))) return rc;
-    if ((rc = growDev(m, m->dev[s], &m->dCount[s], &m->capCount[s], (size_t)qn))) return rc;
+    if (s > 0 && (rc = growDev(m, m->dev[s], &L.dQ[s], &L.capQ[s], (size_t)qn * D))) return rc;
+    if ((rc = growDev(m, m->dev[s], &L.dBins[s], &L.capBins[s], wordsBins))) return rc;
+    if ((rc = growDev(m, m->dev[s], &L.dPack[s], &L.capPack[s], wordsPack))) return rc;
+    if ((rc = growDev(m, m->dev[s], &L.dCount[s], &L.capCount[s], (size_t)qn))) return rc;
   }
-  { int rc; if ((rc = growDev(m, m->dev[0], &m->dGather, &m->capGather, (size_t)n * wordsPack))) return rc; }
+  { int rc; if ((rc = growDev(m, m->dev[0], &L.dGather, &L.capGather, (size_t)n * wordsPack))) return rc; }
   MHIP(hipSetDevice(m->dev[0]));
-  hipStream_t st0 = hip_stream ? (hipStream_t)hip_stream : m->st[0];
+  hipStream_t st0 = hip_stream ? (hipStream_t)hip_stream : L.st[0];
   // the batch is ready (and the previous batch of this handle fully merged) once everything enqueued on st0 so far has run
-  MHIP(hipEventRecord(m->evIn, st0));
+  MHIP(hipEventRecord(L.evIn, st0));
   const uint32_t qs = (qn + (uint32_t)n - 1) / (uint32_t)n;
   // 1. queries to every shard, traversal of the shard's own query slice
   for (int s = 0; s < n; ++s) {
     MHIP(hipSetDevice(m->dev[s]));
-    hipStream_t st = s == 0 ? st0 : m->st[s];
+    hipStream_t st = s == 0 ? st0 : L.st[s];
     const float* q = q_dev0;
     if (s > 0) {
-      MHIP(hipStreamWaitEvent(st, m->evIn, 0));
-      int rc = peerCopy(m->dQ[s], m->dev[s], q_dev0, m->dev[0], (size_t)qn * D * 4, st);
+      MHIP(hipStreamWaitEvent(st, L.evIn, 0));
+      int rc = peerCopy(L.dQ[s], m->dev[s], q_dev0, m->dev[0], (size_t)qn * D * 4, st);
       if (rc) return rc;
-      q = m->dQ[s];
+      q = L.dQ[s];
     }
     if (!m->replicatedTraversal) {
       const uint32_t a = std::min<uint32_t>((uint32_t)s * qs, qn), b = std::min<uint32_t>((uint32_t)(s + 1) * qs, qn);
-      if (b > a) MPQT(pqt_traverse_bins(m->sh[s], q + (size_t)a * D, b - a, Bv, Bb, kBinCap, m->dBins[s] + (size_t)a * (kBinCap + 1), st, 0));
-      MHIP(hipEventRecord(m->evT[s], st));
+      if (b > a) MPQT(pqt_traverse_bins(L.h[s], q + (size_t)a * D, b - a, Bv, Bb, kBinCap, L.dBins[s] + (size_t)a * (kBinCap + 1), st, 0));
+      MHIP(hipEventRecord(L.evT[s], st));
     }
   }
   // 2. every shard pulls the other slices' bin lists (the all-gather), reranks its slice of the database
   for (int d = 0; d < n; ++d) {
     MHIP(hipSetDevice(m->dev[d]));
-    hipStream_t st = d == 0 ? st0 : m->st[d];
-    const float* q = d == 0 ? q_dev0 : m->dQ[d];
-    uint32_t* pk = m->dPack[d];
+    hipStream_t st = d == 0 ? st0 : L.st[d];
+    const float* q = d == 0 ? q_dev0 : L.dQ[d];
+    uint32_t* pk = L.dPack[d];
     if (m->replicatedTraversal) {
-      MPQT(pqt_query_shard(m->sh[d], q, qn, Bv, Bb, k, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k, m->dCount[d], st, 0));
+      MPQT(pqt_query_shard(L.h[d], q, qn, Bv, Bb, k, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k, L.dCount[d], st, 0));
     } else {
       for (int s = 0; s < n; ++s) {
         if (s == d) continue;
         const uint32_t a = std::min<uint32_t>((uint32_t)s * qs, qn), b = std::min<uint32_t>((uint32_t)(s + 1) * qs, qn);
         if (b <= a) continue;
-        MHIP(hipStreamWaitEvent(st, m->evT[s], 0));
-        int rc = peerCopy(m->dBins[d] + (size_t)a * (kBinCap + 1), m->dev[d], m->dBins[s] + (size_t)a * (kBinCap + 1), m->dev[s],
+        MHIP(hipStreamWaitEvent(st, L.evT[s], 0));
+        int rc = peerCopy(L.dBins[d] + (size_t)a * (kBinCap + 1), m->dev[d], L.dBins[s] + (size_t)a * (kBinCap + 1), m->dev[s],
                           (size_t)(b - a) * (kBinCap + 1) * 8, st);
         if (rc) return rc;
       }
-      MPQT(pqt_query_shard_bins(m->sh[d], q, qn, Bv, Bb, k, m->dBins[d], kBinCap, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k,
-                                m->dCount[d], st, 0));
+      MPQT(pqt_query_shard_bins(L.h[d], q, qn, Bv, Bb, k, L.dBins[d], kBinCap, pk, reinterpret_cast<float*>(pk + (size_t)qn * k), pk + (size_t)2 * qn * k,
+                                L.dCount[d], st, 0));
     }
-    MHIP(hipEventRecord(m->evR[d], st));
+    MHIP(hipEventRecord(L.evR[d], st));
   }
   // 3. per-shard top-k to device 0, exact (distance, position) merge
   MHIP(hipSetDevice(m->dev[0]));
   for (int s = 0; s < n; ++s) {
-    if (s > 0) MHIP(hipStreamWaitEvent(st0, m->evR[s], 0));
-    int rc = peerCopy(m->dGather + (size_t)s * wordsPack, m->dev[0], m->dPack[s], m->dev[s], wordsPack * 4, st0);
+    if (s > 0) MHIP(hipStreamWaitEvent(st0, L.evR[s], 0));
+    int rc = peerCopy(L.dGather + (size_t)s * wordsPack, m->dev[0], L.dPack[s], m->dev[s], wordsPack * 4, st0);
     if (rc) return rc;
   }
-  MPQT(pqt_merge_topk(m->sh[0], (uint32_t)n, qn, k, m->dGather, reinterpret_cast<const float*>(m->dGather + (size_t)qn * k), m->dGather + (size_t)2 * qn * k,
+  MPQT(pqt_merge_topk(L.h[0], (uint32_t)n, qn, k, L.dGather, reinterpret_cast<const float*>(L.dGather + (size_t)qn * k), L.dGather + (size_t)2 * qn * k,
                       (uint64_t)wordsPack, out_idx_dev0, out_dist_dev0, st0, 0));
-  if (out_count_dev0) MHIP(hipMemcpyAsync(out_count_dev0, m->dCount[0], (size_t)qn * 4, hipMemcpyDeviceToDevice, st0));
-  MHIP(hipEventRecord(m->evDone, st0));
+  if (out_count_dev0) MHIP(hipMemcpyAsync(out_count_dev0, L.dCount[0], (size_t)qn * 4, hipMemcpyDeviceToDevice, st0));
+  MHIP(hipEventRecord(L.evDone, st0));
   if (sync) MHIP(hipStreamSynchronize(st0));
   return PQT_OK;
 }

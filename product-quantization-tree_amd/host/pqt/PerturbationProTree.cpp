@@ -703,9 +703,12 @@ int PerturbationProTree::queryKNNAsync(const float* _Q, uint _QN, uint _nVec) {
       ensureSlot(s, n, _QN, s.compact);
       uint* cnt = s.compact ? s.d_resCnt : nullptr;
       if (d_multi) {
-        // several devices: pqt_multi_query runs the batch on the multi handle's own streams and is waited for here (one batch at a time)
+        // several devices: slot si = lane si of the multi handle (lane 1: a view of every shard with its own streams and exchange buffers,
+        // pqt_multi_query_lane); the batch is fanned out from the slot's stream and nothing is waited for here -- two batches in flight
+        // like on one device (round 6; before, the batch ran to completion at issue time)
         s.h = h;
-        if (pqt_multi_query(d_multi, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, nullptr, 1) != PQT_OK) throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error());
+        if (pqt_multi_query_lane(d_multi, si, _Q, _QN, d_boundVectors, d_boundBins, _nVec, s.d_resIdx, s.d_resDist, cnt, s.stream, 0) != PQT_OK)
+          throw std::runtime_error(std::string("queryKNN: ") + pqt_multi_last_error());
       } else {
         if (si == 0) s.h = h;
         else if (!s.h) check(pqt_index_create_view(h, &s.h), "pqt_index_create_view");

@@ -150,7 +150,8 @@ class PerturbationProTree : public ProTree {
    *  returns a ticket without waiting; queryKNNCollect(ticket, ..) waits for that batch and hands it over exactly like queryKNN (which
    *  is queryKNNAsync + queryKNNCollect).  A caller that issues batch i + 1 before it collects batch i has batch i + 1's kernels running
    *  under batch i's copies and host-side scatter.  At most two tickets are outstanding; tickets are collected in the order they were
-   *  issued.  _Q must stay valid until the ticket is collected.  With several devices (setDevices) the batch runs at issue time. */
+   *  issued.  _Q must stay valid until the ticket is collected.  With several devices (setDevices) slot i is lane i of the multi handle
+   *  (pqt_multi_query_lane: lane 1 = a view of every shard), so two batches are in flight there as well. */
   int queryKNNAsync(const float* _Q, uint _QN, uint _nVec);
   void queryKNNCollect(int _ticket, std::vector<uint>& _resIdx, std::vector<float>& _resDist);
   /** The padding of a row (id 0xffffffff, distance +inf behind its filled prefix) is remembered per result storage: a caller that hands

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from common import fixture
+from common import fixture, pqt_pkg
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -235,3 +235,79 @@ def test_hbm_leg_prices_the_shared_row_pass_on_deduplicated_bytes():
         assert dd["algorithmic_equivalent_speedup"] >= 1.0 and dd["survey_8d_bytes_per_launch"] >= dd["bytes_per_launch"]
         assert 0 < e["path_frac_of_hbm_peak"] < 1
         assert 0 < r["selection_kernel"]["frac"] < 1 and r["selection_kernel"]["bytes_per_launch"] > 0
+
+
+@pytest.mark.parametrize("name,nsh", [("cfg2_small", 3), ("cfg3_small", 2)])
+def test_multi_handle_two_batches_in_flight_on_two_lanes(name, nsh):
+    """pqt_multi_query_lane -- lane 1 is a view of every shard with streams, events and exchange buffers of its own, so two
+    batches are in flight behind ONE multi handle; issued on two streams without a host synchronisation in between, alternating lanes, every
+    batch returns the single-index result bit for bit."""
+    import torch
+    pkg = pqt_pkg()
+    f = fixture(name)
+    c = f.cfg
+    ref = f.hip_index()
+    m = pkg.PqtMulti(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], [0] * nsh)
+    try:
+        m.set_codebooks(f.cb1, f.cb2)
+        m.set_heuristic(f.heur)
+        m.set_bins(f.bin_ids, f.bin_sizes, f.members)
+        m.set_lines(f.codes)
+        bv, bb, k = 400, 500, 50
+        q = torch.from_numpy(f.queries).cuda()
+        qrev = q.flip(0).contiguous()
+        qn = q.shape[0]
+        r_ids, r_d, r_c = ref.query(f.queries, bv, bb, k)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [[torch.empty((qn, k), dtype=torch.int32, device="cuda"), torch.empty((qn, k), dtype=torch.float32, device="cuda"), torch.empty(qn, dtype=torch.int32, device="cuda")]
+                for _ in range(2)]
+        torch.cuda.synchronize()
+        for step in range(6):
+            lane = step & 1
+            qq = qrev if lane else q
+            m.query_lane_dev(lane, qq, bv, bb, k, outs[lane][0], outs[lane][1], outs[lane][2], stream=streams[lane].cuda_stream)
+        torch.cuda.synchronize()
+        for lane in (0, 1):
+            want = (r_ids[::-1], r_d[::-1], r_c[::-1]) if lane else (r_ids, r_d, r_c)
+            assert np.array_equal(outs[lane][0].cpu().numpy().view(np.uint32), want[0]), lane
+            assert np.array_equal(bits(outs[lane][1].cpu().numpy()), bits(want[1])), lane
+            assert np.array_equal(outs[lane][2].cpu().numpy().view(np.uint32), want[2]), lane
+        # the plain entry is lane 0 and still answers after the lanes were used
+        m.query_dev(q, bv, bb, k, outs[0][0], outs[0][1], outs[0][2], sync=True)
+        assert np.array_equal(outs[0][0].cpu().numpy().view(np.uint32), r_ids)
+    finally:
+        m.close()
+        ref.close()
+
+
+def test_frontend_two_shards_two_batches_in_flight():
+    """the kept C++ front-end with setDevices (two shards on device 0): queryKNNAsync / queryKNNCollect now keep two batches in flight on the
+    two lanes of the multi handle; every collected batch equals the single-index engine's padded arrays"""
+    import importlib
+    import torch
+    fe_mod = importlib.import_module("product-quantization-tree_amd.frontend")
+    f = fixture("cfg2_small")
+    c = f.cfg
+    nvec, bv, bb = 256, 3000, 512
+    fe = fe_mod.FrontEnd(c["D"], c["P"], c["C1"], c["C2"], c["W"], c["LP"], f.cb1, f.cb2, f.bin_ids, f.bin_sizes, f.members, f.codes, devices=(0, 0))
+    idx = f.hip_index()
+    try:
+        qa = torch.from_numpy(f.queries).cuda()
+        qb = torch.from_numpy(np.ascontiguousarray(f.queries[::-1] * 0.5 + 20.0)).cuda()
+        qn = qa.shape[0]
+        idx.build_heuristic(bb)
+
+        def engine(q):
+            gi = torch.empty((qn, nvec), dtype=torch.int32, device="cuda"); gd = torch.empty((qn, nvec), dtype=torch.float32, device="cuda"); gc = torch.empty(qn, dtype=torch.int32, device="cuda")
+            idx.query_dev(q, bv, bb, nvec, gi, gd, gc, sync=True)
+            return gi.cpu().numpy().view(np.uint32), gd.cpu().numpy().view(np.uint32)
+        ea, eb = engine(qa), engine(qb)
+        for reps in (1, 2, 5):
+            ms, oi, od = fe.queryKNN_inflight(qa.data_ptr(), qb.data_ptr(), qn, nvec, bv, bb, reps=reps, keep_padding=True)
+            want = ea if reps % 2 == 1 else eb
+            assert np.array_equal(oi, want[0]) and np.array_equal(od.view(np.uint32), want[1]), reps
+        tm, oi, od = fe.queryKNN(qa.data_ptr(), qn, nvec, bv, bb, reps=2)
+        assert np.array_equal(oi, ea[0]) and np.array_equal(od.view(np.uint32), ea[1])
+    finally:
+        fe.close()
+        idx.close()
