@@ -356,6 +356,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_
   static_assert(NW == 8, "one wavefront per query of a chunk sets the chunk up; two wavefronts interleave one pair of tables");
   static_assert((NP - 1) * PB + (LP - 1) * C1 * 8 + (C1 - 1) * 8 + 8 <= 65536, "look-up offsets must fit the DS instructions' 16-bit offset field");
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  typedef __attribute__((address_space(3))) const pqt_f2* lds_f2p;
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)smem_raw != 0u) __builtin_trap();  // (uniform; cannot happen: the kernel has no static LDS)
   uint32_t* const sJ0 = reinterpret_cast<uint32_t*>(smem_raw + (size_t)NP * PB);  // [QC][64] first visiting positions of the query's visits of this bin
   uint32_t* const sNv = sJ0 + QC * 64;                                               // [QC] their number
   uint32_t* const sQ = sNv + QC;                                                     // [QC] the query
@@ -429,8 +431,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(PQT_SR_
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
               const uint32_t partBase = k * PB + (uint32_t)(v * 4 + x) * (C1 * 8);  // compile-time: the DS offset field
-              const pqt_f2 sb = *reinterpret_cast<const pqt_f2*>(smem_raw + partBase + offA[x]);
-              const pqt_f2 sa = *reinterpret_cast<const pqt_f2*>(smem_raw + partBase + offB[x]);
+              // absolute LDS addresses (the dynamic segment starts at 0: no static LDS in this kernel, checked once below) -- through smem_raw the
+              // compiler adds the segment's link-time base to every address (one v_add per look-up, 18 % of this kernel's VALU instructions)
+              const pqt_f2 sb = *(lds_f2p)(uintptr_t)(partBase + offA[x]);
+              const pqt_f2 sa = *(lds_f2p)(uintptr_t)(partBase + offB[x]);
               const pqt_f2 l2 = {lam[x], lam[x]};
               const pqt_f2 d2 = sb + l2 * (sa - sb);
               acc[k] = acc[k] + d2;
