@@ -39,11 +39,17 @@ wide)
 prof)    # kernel statistics + counters of the default line and of the 100 M leg (rocprofv3; --pmc passes separate from the trace)
   bash scripts/r05_profile.sh > $O/profile.log 2>&1; tail -5 $O/profile.log
   bash scripts/r05_profile_100m.sh > $O/profile_100m.log 2>&1; tail -5 $O/profile_100m.log ;;
+variants)  # development libraries of the pass (tune/lib_<tag>.so, scripts/r05_devlib_sr.sh: tile of 1024 / 4096 rows, 8-wavefront scan workgroups) against the
+         # build in csrc/, evaluating kernel 1 and 2 each, (20000, 500) only
+  for t in base t1024 t4096 sel8; do
+    lib=$PWD/tune/lib_$t.so; [ $t = base ] && lib=$PWD/product-quantization-tree_amd/csrc/libpqt_hip.so
+    echo "=== $t"; PQT_LIB=$lib timeout 500 python scripts/r06_sr_ab.py --workload synth100m --steps 10 --knobs "20000,500" --variants "sr_kernel=1;sr_kernel=2;sr_kernel=2,sr_scan_split=4,sr_scan_depth=8" --out $O/var_$t.json 2>&1 < /dev/null | grep "^\[\|identical"
+  done ;;
 asan)    # device-side AddressSanitizer (tune/lib_asan.so rebuilt from the round's sources by /tmp/build_asan.sh's recipe: hipcc -O1 -g
          # --offload-arch=gfx950:xnack+ -fsanitize=address -shared-libsan): default-path fixtures + the round's opt-in kernels
   RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
   export HSA_XNACK=1 ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 LD_PRELOAD=$RT PQT_LIB=$PWD/tune/lib_asan.so
   timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "(cfg2_small or ties or wrap) and fused and (test_candidates_and_full_sorted_list or test_topk_select_path or test_edge_bounds)" > $O/device_asan.log 2>&1 < /dev/null; echo "device asan (default path) rc=$?"; tail -3 $O/device_asan.log | cut -c1-240
   timeout 900 python -m pytest tests/test_gpu_zz_round6_optin.py -x -q -k "agree_bit_for_bit or hands_back or cooperative or compacted" > $O/device_asan_optin.log 2>&1 < /dev/null; echo "device asan (opt-in kernels) rc=$?"; tail -3 $O/device_asan_optin.log | cut -c1-240 ;;
-*) echo "usage: $0 suite|bench|srab|shard100m|shard1b|wide|prof|asan" ;;
+*) echo "usage: $0 suite|bench|srab|variants|shard100m|shard1b|wide|prof|asan" ;;
 esac
